@@ -1,0 +1,265 @@
+/*
+ * samd_hip.h -- C ABI of libsamd_hip.so: the MI355X (gfx950) draft+verify hot path of SAM-Decoding.
+ *
+ * Drop-in boundary.  The reference is pure Python; every entry point below
+ * names the reference function it replaces (paths relative to the reference repo;
+ * SO/ = samd_sam_only/, S/ = samd/).  The Python packages sam-decoding_amd/samd_sam_only and
+ * sam-decoding_amd/samd bind these symbols with ctypes and re-expose the reference's classes
+ * (SamdConfig, DraftModel, SamdModel, DynSAM, StaticSAM, build_sam/load_sam/dump_sam ...).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  `d_` = device pointer (HBM), `h_` = host pointer.
+ *   - every function returns an int status: 0 = ok, <0 = SAMD_E_* ; never throws across the ABI.
+ *   - `stream` is a hipStream_t passed as void*; all device work is enqueued on it, no internal
+ *     synchronisation unless the name ends in `_sync` or the doc says "host result".
+ *   - handles are not thread-safe; distinct handles are independent.
+ *   - device tensors handed in (logits, KV cache, q/k/v) are BORROWED: the caller keeps them alive.
+ */
+#ifndef SAMD_HIP_H
+#define SAMD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAMD_OK 0
+#define SAMD_E_INVALID (-1)   /* bad argument */
+#define SAMD_E_CAPACITY (-2)  /* arena / table capacity exceeded */
+#define SAMD_E_HIP (-3)       /* a HIP runtime call failed (see samd_last_error) */
+#define SAMD_E_IO (-4)        /* file could not be read / written / has a bad header */
+#define SAMD_E_NODEVICE (-5)  /* no gfx950 device visible */
+
+#define SAMD_MAX_DRAFT 64     /* a draft (sequence or tree) holds at most 64 nodes: one wavefront, one u64 mask row */
+#define SAMD_TOPK 8           /* SO/sam/static_sam.py:137 keeps 8 successors per state */
+
+/* automaton flavours */
+#define SAMD_KIND_COUNT 0     /* samd_sam_only StaticSAM: cnt_endpos + top-k (SO/sam/static_sam.py:24-29) */
+#define SAMD_KIND_ENDPOS 1    /* samd StaticSAM / both DynSAMs: min_endpos + input_ids (S/sam/static_sam.py:10-15) */
+
+/* dtypes of borrowed floating-point tensors */
+#define SAMD_F16 0
+#define SAMD_BF16 1
+#define SAMD_F32 2
+
+typedef struct samd_static samd_static_t;   /* immutable corpus automaton, host image + HBM image */
+typedef struct samd_session samd_session_t; /* one request stream: dynamic automaton, cursors, draft, verdict */
+typedef struct samd_recycle samd_recycle_t; /* Token-Recycle [V,8] successor table */
+
+const char *samd_last_error(void);
+int samd_device_count(void);
+/* library + device facts: out[0]=ABI version, out[1]=CU count, out[2]=wavefront size, out[3]=LDS bytes/CU */
+int samd_device_info(int64_t out[4]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Static (corpus) suffix automaton
+ * ---------------------------------------------------------------------------------------------- */
+
+/* StaticSAM.build(batch_tokens, eos_token)  -- SO/sam/static_sam.py:31-40 (+add_batch_tokens :131-135,
+ * add_state :67-96, init_topk_next :137-146); S/sam/static_sam.py:31-46 for SAMD_KIND_ENDPOS.
+ * Host-side construction (sequential by nature, offline in the reference: tools/gen_sam_alpaca_sam_only.py).
+ * h_tokens holds all documents back to back; document d is h_tokens[h_doc_offsets[d] .. h_doc_offsets[d+1]). */
+int samd_static_build(const int32_t *h_tokens, const int64_t *h_doc_offsets, int64_t n_docs, int32_t eos_token,
+                      int32_t kind, samd_static_t **out);
+/* importer for automata built elsewhere (e.g. a converted reference pickle, SO/sam/utils.py:20-39):
+ * per-state link/length/aux and the edges of all states, state-major, each state's edges in the
+ * reference's dict (insertion) order; h_text may be NULL for SAMD_KIND_COUNT. */
+int samd_static_from_tables(int32_t kind, int64_t n_states, const int32_t *h_link, const int32_t *h_length,
+                            const int32_t *h_aux, const int32_t *h_deg, const int32_t *h_edge_tok,
+                            const int32_t *h_edge_dst, const int32_t *h_text, int64_t n_text, samd_static_t **out);
+/* dump_sam / load_sam  -- SO/sam/utils.py:20-39 (flat binary image instead of a pickle) */
+int samd_static_save(const samd_static_t *sam, const char *path);
+int samd_static_load(const char *path, samd_static_t **out);
+void samd_static_free(samd_static_t *sam);
+/* copy the image into HBM on the current device (idempotent); blocking */
+int samd_static_upload(samd_static_t *sam);
+/* out: [0]=n_states [1]=n_edges [2]=n_spill_edges [3]=vocab (root table size) [4]=device bytes [5]=kind
+ *      [6]=n_text [7]=uploaded */
+int samd_static_info(const samd_static_t *sam, int64_t out[8]);
+/* host read-back of the built automaton (tests / converters): arrays sized from samd_static_info.
+ * Edges come state-major in STORED order: the first min(deg,8) are the top-k order of
+ * init_topk_next (SO/sam/static_sam.py:140-146), the rest ascending by token. */
+int samd_static_export(const samd_static_t *sam, int32_t *h_link, int32_t *h_length, int32_t *h_aux, int32_t *h_deg,
+                       int32_t *h_edge_tok, int32_t *h_edge_dst);
+/* device pointers of the HBM image, for callers that broadcast it with RCCL (multi-GPU request
+ * parallelism): out[0]=nodes, out[1]=root table, out[2]=spill edges, out[3]=text; bytes in out_bytes[]. */
+int samd_static_device_image(const samd_static_t *sam, void *out_ptrs[4], int64_t out_bytes[4]);
+/* create an un-filled device image of the same shape on this rank (to receive a broadcast) */
+int samd_static_alloc_like(const int64_t info[8], samd_static_t **out);
+
+/* transfer_tokens / lookup over B independent cursors  -- SO/sam/static_sam.py:98-125.
+ * d_cursors: int32 [B][2] = (index, length) per stream.  d_tokens: int32 [T][B] (time-major).
+ * Each stream consumes its T tokens in order.  commit=1 writes the final cursors back
+ * (transfer_tokens), commit=0 leaves them (lookup).  d_trace (optional) receives int32 [T][B][2]
+ * = the (index,length) after every token.  This is the batched-streams form of the walk kernel
+ * whose HBM traffic bench.py reports. */
+int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
+                     int32_t commit, int32_t *d_trace, void *stream);
+
+/* same launch; additionally adds the number of states visited by all streams to *d_visited (u64 on the
+ * device).  bench.py multiplies it by 16 B to get the algorithmic bytes. */
+int samd_static_walk_counted(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
+                             int32_t commit, uint64_t *d_visited, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Session = one request stream (what DraftModel + DynSAM + the StaticSAM cursor hold in the reference)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* draft hyper-parameters: SamdConfig of both variants (SO/samd_config.py:9-17, S/samd_config.py:9-43) */
+typedef struct samd_params {
+    int32_t variant;        /* 0 = samd_sam_only rule (SO/draft.py:50-59), 1 = samd rule (S/draft.py:52-63) */
+    int32_t max_predicts;   /* SO: cap of the draft size */
+    double alpha;           /* SO: n = min(max_predicts, 1 + int(match * alpha)) */
+    int32_t K;              /* SO: per-depth width of the tree search */
+    int32_t len_bias;       /* both */
+    int32_t n_predicts;     /* S: fixed sequence-draft length */
+    int32_t len_threshold;  /* S: SAM draft iff max(match) >= threshold */
+    int32_t static_null;    /* S: 1 = NullStaticSAM (S/sam/static_sam.py:128-137) */
+    int32_t reserved;
+} samd_params_t;
+
+/* host view of a finished draft (returned by samd_session_read_draft; host result => synchronises) */
+typedef struct samd_draft_host {
+    int32_t type;                           /* 0 = sequence, 1 = tree, 2 = defer to the tree model (S variant) */
+    int32_t n;                              /* number of draft nodes */
+    int32_t n_leaves, max_depth;            /* shape of retrieve */
+    int32_t index_dyn, match_dyn, index_static, match_static;   /* lookup results (match_static after len_bias) */
+    int32_t tokens[SAMD_MAX_DRAFT];
+    int32_t parent[SAMD_MAX_DRAFT];         /* anc_tree; sequence: i-1 */
+    int32_t position[SAMD_MAX_DRAFT];       /* tree_position_ids / seq_position_ids */
+    uint64_t mask[SAMD_MAX_DRAFT];          /* row i: bit j set iff node i attends node j (tree_attn_mask) */
+    int32_t retrieve[SAMD_MAX_DRAFT * SAMD_MAX_DRAFT];  /* [n_leaves][max_depth], -1 padded */
+} samd_draft_host_t;
+
+/* host view of a verdict (eval_posterior + update_state outputs) */
+typedef struct samd_verdict_host {
+    int32_t best, accept, next_node, next_token;
+    int32_t tokens[SAMD_MAX_DRAFT];         /* candidate_tokens[best][:accept] */
+    int32_t kv_index[SAMD_MAX_DRAFT];       /* retrieve[best][:accept] (tree) or 0..accept-1 (sequence) */
+} samd_verdict_host_t;
+
+/* DynSAM() + cursors.  max_tokens bounds prompt + generated tokens (the reference's max_cache_len). */
+int samd_session_create(int32_t max_tokens, samd_session_t **out);
+void samd_session_free(samd_session_t *s);
+/* DraftModel.reset  -- SO/draft.py:45-47: DynSAM.reset (SO/sam/dyn_sam.py:37-43) + static cursor to root */
+int samd_session_reset(samd_session_t *s, void *stream);
+
+/* DynSAM.add_tokens  -- SO/sam/dyn_sam.py:101-105 (cursor transfer first, then add_state :50-76).
+ * d_tokens: int32 [n]; if d_n != NULL the count is read from device memory (sync-free chaining). */
+int samd_dyn_add_tokens(samd_session_t *s, const int32_t *d_tokens, int32_t n, const int32_t *d_n, void *stream);
+/* DynSAM.transfer_tokens (commit=1) / lookup (commit=0, n=1)  -- SO/sam/dyn_sam.py:78-114.
+ * d_out (optional): int32 [2] final (index,length). */
+int samd_dyn_walk(samd_session_t *s, const int32_t *d_tokens, int32_t n, int32_t commit, int32_t *d_out, void *stream);
+/* StaticSAM.transfer_tokens / lookup on the session's static cursor (single stream) */
+int samd_session_static_walk(samd_session_t *s, const samd_static_t *sam, const int32_t *d_tokens, int32_t n,
+                             const int32_t *d_n, int32_t commit, int32_t *d_out, void *stream);
+/* host read-back of the dynamic automaton (tests): out_info: [0]=n_states [1]=n_edges [2]=n_text [3]=last
+ * [4]=max_length [5]=cur_index [6]=cur_length [7]=static cur_index [8]=static cur_length [9]=error flag.
+ * Pass NULL arrays to query sizes only.  Edges state-major in dict (insertion) order.  Synchronises. */
+int samd_session_export(samd_session_t *s, int64_t out_info[10], int32_t *h_link, int32_t *h_length, int32_t *h_minend,
+                        int32_t *h_deg, int32_t *h_edge_tok, int32_t *h_edge_dst, int32_t *h_text, void *stream);
+/* set the cursors explicitly (tests; mirrors assigning cur_index/cur_length in the reference objects) */
+int samd_session_set_cursors(samd_session_t *s, int32_t dyn_index, int32_t dyn_length, int32_t st_index,
+                             int32_t st_length, void *stream);
+
+/* DraftModel.lookup  -- SO/draft.py:50-59 (variant 0) / S/draft.py:52-63 (variant 1):
+ * both lookups, len_bias, the dyn-vs-static rule, then
+ *   sequence: DynSAM.gen_draft (SO/sam/dyn_sam.py:116-121; S/sam/dyn_sam.py:99-113 with to_anc; S/sam/static_sam.py:119-125)
+ *   tree:     StaticSAM.gen_draft best-first search (SO/sam/static_sam.py:182-215, CPython heapq order, float64 prob)
+ * and gen_buffers (SO/sam/static_sam.py:148-180).  d_start_token: int32 [1] on the device.
+ * The draft stays in the session (device); read it with samd_session_read_draft or feed it to the
+ * verify kernels through samd_session_device_draft. `sam` may be NULL (empty static automaton). */
+int samd_session_draft(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p,
+                       const int32_t *d_start_token, void *stream);
+/* forced forms of the two SO draft generators (granular API of DynSAM.gen_draft / StaticSAM.gen_draft) */
+int samd_session_draft_seq(samd_session_t *s, const samd_params_t *p, int32_t index, int32_t match, int32_t start_token,
+                           void *stream);
+int samd_session_draft_tree(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, int32_t index,
+                            int32_t match, int32_t start_token, void *stream);
+/* S-variant fixed-length drafts (granular): source 0 = DynSAM (to_anc), 1 = StaticSAM */
+int samd_session_draft_fixed(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, int32_t source,
+                             int32_t index, int32_t start_token, void *stream);
+/* install an externally produced draft (Token-Recycle / EAGLE tree) so that verify + accept can run on it:
+ * tokens and parent array on the device, n on the host. */
+int samd_session_set_draft(samd_session_t *s, const int32_t *d_tokens, const int32_t *d_parent, int32_t n, int32_t type,
+                           void *stream);
+int samd_session_read_draft(samd_session_t *s, samd_draft_host_t *out, void *stream);
+
+/* device view of the session's draft/verdict block (fixed layout, see samd_session_block_t in DESIGN.md):
+ * out[0]=tokens int32[64] out[1]=parent int32[64] out[2]=position int32[64] out[3]=mask u64[64]
+ * out[4]=retrieve int32[64*64] out[5]=meta int32[16] {type,n,n_leaves,max_depth,...}
+ * out[6]=verdict int32[8] {best,accept,next_node,next_token,...} out[7]=accepted tokens int32[64]
+ * out[8]=kv_index int32[64] out[9]=start_token int32[1] out[10]=cache_length int32[1]
+ * out[11]=history int32[max_tokens] (all committed tokens) out[12]=counters int32[8] */
+int samd_session_device_views(samd_session_t *s, void *out[16]);
+
+/* gen_buffers(anc_tree) standalone  -- SO/sam/static_sam.py:148-180.  d_parent int32[n] ->
+ * d_position int32[n], d_mask u64[n], d_mask_bool u8[n*n] (optional), d_retrieve int32[n*n] (optional),
+ * d_shape int32[2] = {n_leaves, max_depth}. reverse_leaves=1 gives Token-Recycle's row order
+ * (S/tree_model/token_recycle/utils.py:88). */
+int samd_tree_buffers(const int32_t *d_parent, int32_t n, int32_t reverse_leaves, int32_t *d_position, uint64_t *d_mask,
+                      uint8_t *d_mask_bool, int32_t *d_retrieve, int32_t *d_shape, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Verify side
+ * ---------------------------------------------------------------------------------------------- */
+
+/* torch.argmax(logits, -1) per row, first maximum wins  -- SO/utils.py:86 and :131.
+ * d_logits [rows][row_stride] of `dtype`; d_out int32 [rows]. d_rows (optional) = device row count. */
+int samd_argmax_rows(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride,
+                     const int32_t *d_rows, int32_t *d_out, void *stream);
+
+/* eval_posterior (greedy) + the token/index selection of update_state
+ * -- SO/utils.py:127-141, SO/samd_model.py:158-170 -- on the session's current draft, from per-node
+ * arg-max tokens d_node_argmax int32[n].  Mirrors the reference's -1 padding quirk. */
+int samd_session_accept(samd_session_t *s, const int32_t *d_node_argmax, void *stream);
+int samd_session_read_verdict(samd_session_t *s, samd_verdict_host_t *out, void *stream);
+/* DraftModel.update(tokens) with the accepted tokens of the last verdict  -- SO/draft.py:62-67 */
+int samd_session_commit(samd_session_t *s, const samd_static_t *sam, void *stream);
+/* one fused single-wavefront launch: accept -> commit -> lookup(next start token) -> draft -> buffers.
+ * This is what SamdModel.decode runs between two LM forwards (SO/samd_model.py:116-156). */
+int samd_session_step(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p,
+                      const int32_t *d_node_argmax, void *stream);
+
+/* SamdStaticCache.select_indices  -- SO/cache.py:118-133: for every K and V tensor copy rows
+ * start+idx[j] -> start+j (j < accept), then cache_length += accept.  d_tensors: device array of
+ * n_tensors base pointers, each [n_heads][max_len][head_dim] of `elem_bytes`-byte elements.
+ * start / idx / accept are read from the session (device side); is_tree==0 (sequence) skips the copy. */
+int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len,
+                    int32_t head_dim, int32_t elem_bytes, void *stream);
+
+/* SamdStaticCache.reset / set_length  -- SO/cache.py:89-94: the committed KV length lives in the session
+ * (device scalar) so that accept, compaction and attention chain without host round trips. */
+int samd_session_set_cache_length(samd_session_t *s, int32_t length, void *stream);
+int samd_session_get_cache_length(samd_session_t *s, int32_t *h_out, void *stream);   /* host result */
+
+/* tree-mask attention of the n draft tokens over L cached + n new keys
+ * -- SO/model_patch/llama.py:82-96 (mask semantics) + the SDPA call it feeds.
+ * q [n_q_pad][H][D], k_cache/v_cache [H_kv][max_len][D] (new rows already written at [L, L+n)),
+ * out [n_q_pad][H][D] (rows >= n are zeroed); mask u64[n] row i bit j; L and n are read from device
+ * memory (d_cache_length, d_n).  head_dim must be 128, dtype f16 or bf16.  d_workspace: scratch of
+ * samd_tree_attention_workspace() bytes (split-KV partials). */
+int64_t samd_tree_attention_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim);
+int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype,
+                        int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                        const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
+                        void *d_workspace, int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token Recycle (S/tree_model/token_recycle/token_recycle.py:18-63)
+ * ---------------------------------------------------------------------------------------------- */
+int samd_recycle_create(int32_t vocab, const int32_t *h_child_offsets, const int32_t *h_children, int32_t n_nodes,
+                        samd_recycle_t **out);
+void samd_recycle_free(samd_recycle_t *t);
+/* update: logits.topk(8) of every verified token, cache[token] = top-8, later rows win (:40-48) */
+int samd_recycle_update(samd_recycle_t *t, const int32_t *d_tokens, const void *d_logits, int32_t dtype, int32_t n,
+                        const int32_t *d_n, int64_t vocab, int64_t row_stride, void *stream);
+/* gen_draft: fill the static tree from the table (:50-60); d_out int32[n_nodes] */
+int samd_recycle_draft(samd_recycle_t *t, const int32_t *d_start_token, int32_t *d_out, void *stream);
+int samd_recycle_export(samd_recycle_t *t, int32_t *h_table, uint8_t *h_present, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMD_HIP_H */

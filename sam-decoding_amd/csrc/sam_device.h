@@ -1,0 +1,474 @@
+// sam_device.h -- gfx950 device functions of the suffix-automaton path (included by sam_kernels.hip).
+//
+// Two execution shapes share this code:
+//   * lane-per-stream (batched walk): every lane owns an independent cursor; st_transfer() is ordinary
+//     per-lane code, each visited state costs one 64-byte line (4 x dwordx4 from the same line).
+//   * single wavefront per request (bs=1 decode step): the 64 lanes run the sequential control flow
+//     uniformly (uniform addresses -> one request per load) and fan out where the work is parallel:
+//     64 hash slots per probe of the dynamic automaton (ballot), 8 successors per tree expansion,
+//     one tree node / leaf row per lane for the buffers and the greedy posterior.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "samd_common.h"
+
+#define WAVE 64
+#define PATH_PAD 255
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// make the wave's own earlier global stores visible to its later loads (single-CU, workgroup scope)
+__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// ------------------------------------------------------------------------------------------------
+// static automaton: one longest-suffix-match transition
+// reference: transfer_state, samd_sam_only/sam/static_sam.py:98-107 (== samd/sam/static_sam.py:81-90)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int spill_search(const SamEdge *tail, int count, int tok) {
+    int lo = 0, hi = count;                       // lower_bound over edges sorted by token
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        int t = tail[mid].tok;
+        if (t < tok) lo = mid + 1; else hi = mid;
+    }
+    if (lo < count) { SamEdge e = tail[lo]; if (e.tok == tok) return e.dst; }
+    return -1;
+}
+
+__device__ __forceinline__ int node_find(const StaticDev &S, const int4 &w0, const int4 &w1, const int4 &w2,
+                                         const int4 &w3, int tok) {
+    int nx = -1;
+    nx = (w1.x == tok) ? w1.y : nx;
+    nx = (w1.z == tok) ? w1.w : nx;
+    nx = (w2.x == tok) ? w2.y : nx;
+    nx = (w2.z == tok) ? w2.w : nx;
+    nx = (w3.x == tok) ? w3.y : nx;
+    if (nx < 0 && w0.w > SAMD_INLINE_EDGES)
+        nx = spill_search(S.spill + w3.z + SAMD_SPILL_HEAD, w0.w - SAMD_INLINE_EDGES, tok);
+    return nx;
+}
+
+// returns the number of states visited (for the bytes-per-visit accounting of the bench)
+__device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &len, int tok) {
+    int visited = 0;
+    bool hopped = false;
+    if (tok < 0) { idx = 0; len = 0; return 1; }   // no state has an edge on a negative token
+    for (;;) {
+        visited++;
+        if (idx == 0) {                            // root: dense table; failing here ends in (0,0)
+            int nx = (tok < S.vocab) ? S.root_next[tok] : -1;
+            if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
+            return visited;
+        }
+        const int4 *np = reinterpret_cast<const int4 *>(S.nodes + idx);
+        const int4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        if (hopped) len = w0.y;                    // length <- states[link].length (static_sam.py:101)
+        int nx = node_find(S, w0, w1, w2, w3, tok);
+        if (nx >= 0) { idx = nx; len += 1; return visited; }
+        idx = w0.x; hopped = true;
+        if (idx == 0) len = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic automaton (single wavefront, uniform control flow)
+// reference: samd_sam_only/sam/dyn_sam.py:50-114 (identical in samd/sam/dyn_sam.py:41-97)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t dyn_key(int state, int tok) { return ((uint64_t)(uint32_t)state << 32) | (uint32_t)tok; }
+__device__ __forceinline__ uint32_t dyn_hash(uint64_t k) {
+    k *= 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(k >> 29);
+}
+
+// `tok in states[state].next` : 64 consecutive slots per probe round, one ballot decides.
+// returns the slot (== edge id) or -1; *free_slot = first empty slot of the probe sequence.
+__device__ __forceinline__ int dyn_find(const SessionDev &D, int state, int tok, int *free_slot) {
+    const uint64_t key = dyn_key(state, tok);
+    uint32_t h = dyn_hash(key) & D.hmask;
+    const int lane = lane_id();
+    for (uint32_t round = 0; round <= D.hmask; round += WAVE) {
+        const uint32_t slot = (h + lane) & D.hmask;
+        const uint64_t k = D.hkey[slot];
+        const unsigned long long hit = __ballot(k == key);
+        const unsigned long long empty = __ballot(k == SAMD_HEMPTY);
+        if (hit) return (int)((h + (uint32_t)(__ffsll((long long)hit) - 1)) & D.hmask);
+        if (empty) { *free_slot = (int)((h + (uint32_t)(__ffsll((long long)empty) - 1)) & D.hmask); return -1; }
+        h = (h + WAVE) & D.hmask;
+    }
+    *free_slot = -1;
+    return -1;
+}
+
+// states[state].next[tok] = dst for a new key, appended to the state's dict order
+__device__ __forceinline__ void dyn_insert(const SessionDev &D, int slot, int state, int tok, int dst) {
+    if (lane_id() == 0) {
+        D.hkey[slot] = dyn_key(state, tok); D.hdst[slot] = dst; D.hnext[slot] = -1;
+        const int t = D.tail[state];
+        if (t < 0) D.head[state] = slot; else D.hnext[t] = slot;
+        D.tail[state] = slot;
+    }
+    wave_mem_sync();
+}
+
+__device__ __forceinline__ void dyn_transfer(const SessionDev &D, int &idx, int &len, int tok) {
+    int fs, e;
+    while (idx != 0 && (e = dyn_find(D, idx, tok, &fs)) < 0) {
+        idx = D.link[idx];
+        len = D.length[idx];
+    }
+    e = dyn_find(D, idx, tok, &fs);
+    if (e >= 0) { idx = D.hdst[e]; len += 1; } else { idx = 0; len = 0; }
+}
+
+struct DynRegs { int n_states, n_edges, last, max_length, error; };
+
+__device__ __forceinline__ int dyn_new_state(const SessionDev &D, DynRegs &R, int link, int length, int minend) {
+    const int s = R.n_states++;
+    if (lane_id() == 0) { D.link[s] = link; D.length[s] = length; D.minend[s] = minend; D.head[s] = -1; D.tail[s] = -1; }
+    return s;
+}
+
+// add_state (dyn_sam.py:50-76)
+__device__ __forceinline__ void dyn_add_state(const SessionDev &D, DynRegs &R, int tok) {
+    if (R.n_states + 2 > D.cap_states || (uint32_t)(R.n_edges + 8) * 2 > D.hmask) { R.error = SAMD_E_CAPACITY; return; }
+    R.max_length += 1;
+    const int cur = dyn_new_state(D, R, -1, R.max_length, R.max_length);
+    wave_mem_sync();
+    int p = R.last, e = -1, fs = -1;
+    while (p != -1) {
+        e = dyn_find(D, p, tok, &fs);
+        if (e >= 0) break;
+        if (fs < 0 || (uint32_t)(R.n_edges + 8) * 2 > D.hmask) { R.error = SAMD_E_CAPACITY; return; }
+        dyn_insert(D, fs, p, tok, cur); R.n_edges++;
+        p = D.link[p];
+    }
+    if (p == -1) {
+        if (lane_id() == 0) D.link[cur] = 0;
+    } else {
+        const int q = D.hdst[e];
+        if (D.length[p] + 1 == D.length[q]) {
+            if (lane_id() == 0) D.link[cur] = q;
+        } else {
+            // clone = deepcopy(q): same dict (order kept), link, min_endpos; length = len(p)+1
+            const int clone = dyn_new_state(D, R, D.link[q], D.length[p] + 1, D.minend[q]);
+            wave_mem_sync();
+            for (int qe = D.head[q]; qe >= 0; qe = D.hnext[qe]) {
+                const int t = (int)(uint32_t)D.hkey[qe];
+                const int d = D.hdst[qe];
+                (void)dyn_find(D, clone, t, &fs);
+                if ((uint32_t)(R.n_edges + 8) * 2 > D.hmask || fs < 0) { R.error = SAMD_E_CAPACITY; return; }
+                dyn_insert(D, fs, clone, t, d); R.n_edges++;
+            }
+            while (p != -1) {
+                const int pe = dyn_find(D, p, tok, &fs);
+                if (pe < 0 || D.hdst[pe] != q) break;
+                if (lane_id() == 0) D.hdst[pe] = clone;      // re-point: dict order unchanged
+                p = D.link[p];
+            }
+            if (lane_id() == 0) { D.link[q] = clone; D.link[cur] = clone; }
+        }
+    }
+    R.last = cur;
+    wave_mem_sync();
+}
+
+__device__ __forceinline__ void dyn_load(const SessionDev &D, DynRegs &R) {
+    R.n_states = D.meta[M_NSTATES]; R.n_edges = D.meta[M_NEDGES]; R.last = D.meta[M_LAST];
+    R.max_length = D.meta[M_MAXLEN]; R.error = D.meta[M_ERROR];
+}
+__device__ __forceinline__ void dyn_store(const SessionDev &D, const DynRegs &R) {
+    if (lane_id() == 0) {
+        D.meta[M_NSTATES] = R.n_states; D.meta[M_NEDGES] = R.n_edges; D.meta[M_LAST] = R.last;
+        D.meta[M_MAXLEN] = R.max_length; D.meta[M_ERROR] = R.error;
+    }
+}
+
+// DynSAM.add_tokens (dyn_sam.py:101-105): per token transfer the cursor FIRST, then extend; the tokens
+// are appended to input_ids afterwards.  `toks` may live in global memory or LDS.
+__device__ __forceinline__ void dyn_add_tokens(const SessionDev &D, const int *toks, int n) {
+    DynRegs R; dyn_load(D, R);
+    int ci = D.meta[M_CUR_IDX], cl = D.meta[M_CUR_LEN], nt = D.meta[M_NTEXT];
+    if (nt + n > D.cap_text) { R.error = SAMD_E_CAPACITY; n = 0; }
+    for (int i = 0; i < n && R.error == 0; i++) {
+        const int t = toks[i];
+        dyn_transfer(D, ci, cl, t);
+        dyn_add_state(D, R, t);
+    }
+    if (R.error == 0) {
+        for (int i = lane_id(); i < n; i += WAVE) D.text[nt + i] = toks[i];
+        nt += n;
+    }
+    dyn_store(D, R);
+    if (lane_id() == 0) { D.meta[M_CUR_IDX] = ci; D.meta[M_CUR_LEN] = cl; D.meta[M_NTEXT] = nt; }
+    wave_mem_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// drafts
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int draft_size(int match, double alpha, int max_predicts) {
+    // n = min(max_predicts, 1 + int(match_length * alpha))   (dyn_sam.py:117, static_sam.py:183)
+    int n = 1 + (int)((double)match * alpha);
+    n = n < max_predicts ? n : max_predicts;
+    return n > SAMD_MAX_DRAFT ? SAMD_MAX_DRAFT : n;
+}
+
+// LDS scratch of the single-wavefront kernels
+struct StepShared {
+    // draft under construction
+    int tokens[SAMD_MAX_DRAFT];
+    int parent[SAMD_MAX_DRAFT];
+    int position[SAMD_MAX_DRAFT];
+    unsigned long long mask[SAMD_MAX_DRAFT];
+    unsigned char path[SAMD_MAX_DRAFT][SAMD_MAX_DRAFT];   // retrieve rows, PATH_PAD padded
+    int node_argmax[SAMD_MAX_DRAFT];
+    int accepted[SAMD_MAX_DRAFT];
+    unsigned long long child_mask;
+    int red[4];
+    // best-first search heap (static_sam.py:184-214): <= 1 + 8*(n-1) live items
+    double h_prob[8 * SAMD_MAX_DRAFT + 8];
+    int h_tok[8 * SAMD_MAX_DRAFT + 8], h_idx[8 * SAMD_MAX_DRAFT + 8], h_anc[8 * SAMD_MAX_DRAFT + 8], h_dep[8 * SAMD_MAX_DRAFT + 8];
+    int dep_cnt[SAMD_MAX_DRAFT + 2];
+    int c_tok[SAMD_TOPK], c_dst[SAMD_TOPK], c_cnt[SAMD_TOPK];
+    int pop_ok, pop_tok, pop_idx, pop_anc, pop_dep; double pop_prob;
+};
+
+// sequence draft [start] + input_ids[e+1 : e+n] from `text` (dyn_sam.py:118-119); returns its length
+__device__ __forceinline__ int seq_draft_var(StepShared &sh, const int *text, int n_text, int endpos, int n, int start) {
+    const int lo = endpos + 1;
+    int hi = endpos + n; hi = hi > n_text ? n_text : hi;
+    const int m = 1 + (hi > lo ? hi - lo : 0);
+    const int i = lane_id();
+    if (i < m) { sh.tokens[i] = (i == 0) ? start : text[endpos + i]; sh.parent[i] = i - 1; }
+    __syncthreads();
+    return m;
+}
+
+// fixed-length, zero padded (samd/sam/dyn_sam.py:107-113, samd/sam/static_sam.py:119-125)
+__device__ __forceinline__ int seq_draft_fixed(StepShared &sh, const int *text, int n_text, int endpos, int n_predicts, int start) {
+    const int i = lane_id();
+    if (i < n_predicts) {
+        int v = 0;
+        if (i == 0) v = start; else if (endpos + i < n_text) v = text[endpos + i];
+        sh.tokens[i] = v; sh.parent[i] = i - 1;
+    }
+    __syncthreads();
+    return n_predicts;
+}
+
+// CPython heapq on SearchItem(prob) (static_sam.py:13-19): lane 0 only
+__device__ __forceinline__ void hq_set(StepShared &sh, int pos, double p, int t, int i, int a, int d) {
+    sh.h_prob[pos] = p; sh.h_tok[pos] = t; sh.h_idx[pos] = i; sh.h_anc[pos] = a; sh.h_dep[pos] = d;
+}
+__device__ __forceinline__ void hq_move(StepShared &sh, int dst, int src) {
+    sh.h_prob[dst] = sh.h_prob[src]; sh.h_tok[dst] = sh.h_tok[src]; sh.h_idx[dst] = sh.h_idx[src];
+    sh.h_anc[dst] = sh.h_anc[src]; sh.h_dep[dst] = sh.h_dep[src];
+}
+__device__ __forceinline__ void hq_siftdown(StepShared &sh, int start, int pos, double p, int t, int i, int a, int d) {
+    while (pos > start) {                         // _siftdown: move parents down while new < parent
+        const int par = (pos - 1) >> 1;
+        if (p < sh.h_prob[par]) { hq_move(sh, pos, par); pos = par; continue; }
+        break;
+    }
+    hq_set(sh, pos, p, t, i, a, d);
+}
+__device__ __forceinline__ void hq_push(StepShared &sh, int &hn, double p, int t, int i, int a, int d) {
+    hn++;
+    hq_siftdown(sh, 0, hn - 1, p, t, i, a, d);
+}
+__device__ __forceinline__ void hq_pop(StepShared &sh, int &hn, double &p, int &t, int &i, int &a, int &d) {
+    hn--;
+    const double lp = sh.h_prob[hn]; const int lt = sh.h_tok[hn], li = sh.h_idx[hn], la = sh.h_anc[hn], ld = sh.h_dep[hn];
+    if (hn == 0) { p = lp; t = lt; i = li; a = la; d = ld; return; }
+    p = sh.h_prob[0]; t = sh.h_tok[0]; i = sh.h_idx[0]; a = sh.h_anc[0]; d = sh.h_dep[0];
+    int pos = 0, child = 1;                       // _siftup: to a leaf, right child when `not left < right`
+    while (child < hn) {
+        const int right = child + 1;
+        if (right < hn && !(sh.h_prob[child] < sh.h_prob[right])) child = right;
+        hq_move(sh, pos, child); pos = child; child = 2 * pos + 1;
+    }
+    hq_siftdown(sh, 0, pos, lp, lt, li, la, ld);
+}
+
+// StaticSAM.gen_draft (static_sam.py:182-215): best-first tree of <= n nodes, <= K per depth
+__device__ __forceinline__ int tree_draft(StepShared &sh, const StaticDev &S, int index, int n, int K, int start) {
+    const int lane = lane_id();
+    int hn = 0, m = 0;
+    if (lane <= SAMD_MAX_DRAFT) sh.dep_cnt[lane] = 0;
+    if (lane == 0) { sh.dep_cnt[SAMD_MAX_DRAFT + 1] = 0; hq_push(sh, hn, -1.0, start, index, -1, 0); }
+    __syncthreads();
+    while (m != n) {
+        if (lane == 0) {
+            int ok = 0; double p = 0; int t = 0, i = 0, a = 0, d = 0;
+            while (hn > 0) {
+                hq_pop(sh, hn, p, t, i, a, d);
+                if (sh.dep_cnt[d] + 1 > K) continue;          // this depth is full: drop without expanding
+                sh.dep_cnt[d] += 1; ok = 1; break;
+            }
+            sh.pop_ok = ok; sh.pop_prob = p; sh.pop_tok = t; sh.pop_idx = i; sh.pop_anc = a; sh.pop_dep = d;
+        }
+        __syncthreads();
+        if (!sh.pop_ok) break;
+        const int cur = m;
+        if (lane == 0) { sh.tokens[m] = sh.pop_tok; sh.parent[m] = sh.pop_anc; }
+        m++;
+        if (m == n) break;
+        // expand: the first min(K, 8, deg) successors in top-k order, one lane each
+        const int4 *np = reinterpret_cast<const int4 *>(S.nodes + sh.pop_idx);
+        const int4 w0 = np[0];
+        int kk = w0.w < SAMD_TOPK ? w0.w : SAMD_TOPK; kk = kk < K ? kk : K;
+        if (lane < kk) {
+            int tk, ds;
+            if (lane < SAMD_INLINE_EDGES) { const int *e = reinterpret_cast<const int *>(np) + 4 + 2 * lane; tk = e[0]; ds = e[1]; }
+            else { const int sp = reinterpret_cast<const int *>(np)[14]; const SamEdge ed = S.spill[sp + lane - SAMD_INLINE_EDGES]; tk = ed.tok; ds = ed.dst; }
+            sh.c_tok[lane] = tk; sh.c_dst[lane] = ds; sh.c_cnt[lane] = S.nodes[ds].aux;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const double cnt_sum = (double)w0.z, pp = sh.pop_prob;
+            const int dep = sh.pop_dep + 1;
+            for (int j = 0; j < kk; j++) {
+                const double n_prob = (double)sh.c_cnt[j] / cnt_sum;      // Python int / int
+                hq_push(sh, hn, pp * n_prob, sh.c_tok[j], sh.c_dst[j], cur, dep);
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return m;
+}
+
+// gen_buffers (static_sam.py:148-180): depth, ancestor mask, root->leaf rows.  One lane per node.
+// reverse = Token-Recycle row order (samd/tree_model/token_recycle/utils.py:88).
+__device__ __forceinline__ void build_buffers(StepShared &sh, int n, int reverse, int &n_leaves, int &max_depth) {
+    const int i = lane_id();
+    if (i == 0) sh.child_mask = 0ull;
+    __syncthreads();
+    int depth = 0; unsigned long long m = 0ull;
+    if (i < n) {
+        for (int j = i; j != -1; j = sh.parent[j]) { m |= 1ull << j; depth++; }
+        depth -= 1;
+        sh.position[i] = depth; sh.mask[i] = m;
+        if (i > 0) atomicOr(&sh.child_mask, 1ull << sh.parent[i]);
+    }
+    int md = depth + 1;
+    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(md, o); md = v > md ? v : md; }
+    __syncthreads();
+    const unsigned long long valid = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    const unsigned long long leaf = valid & ~sh.child_mask;
+    const int nl = __popcll(leaf);
+    for (int k = i; k < SAMD_MAX_DRAFT * SAMD_MAX_DRAFT; k += WAVE) (&sh.path[0][0])[k] = PATH_PAD;
+    __syncthreads();
+    if (i < n && ((leaf >> i) & 1ull)) {
+        int r = __popcll(leaf & ((1ull << i) - 1ull));
+        if (reverse) r = nl - 1 - r;
+        for (int j = i; j != -1; j = sh.parent[j]) sh.path[r][sh.position[j]] = (unsigned char)j;
+    }
+    __syncthreads();
+    n_leaves = nl; max_depth = md;
+}
+
+__device__ __forceinline__ void store_draft(const SessionDev &D, StepShared &sh, int type, int n, int n_leaves, int max_depth,
+                                            int idx_dyn, int m_dyn, int idx_st, int m_st, int reverse) {
+    const int i = lane_id();
+    if (i < n) { D.tokens[i] = sh.tokens[i]; D.parent[i] = sh.parent[i]; D.position[i] = sh.position[i]; D.mask[i] = sh.mask[i]; }
+    else { D.tokens[i] = 0; D.parent[i] = i - 1; D.position[i] = 0; D.mask[i] = 0ull; }   // padded rows attend nothing
+    for (int k = i; k < n_leaves * max_depth; k += WAVE) {
+        const unsigned char v = sh.path[k / max_depth][k % max_depth];
+        D.retrieve[k] = v == PATH_PAD ? -1 : (int)v;
+    }
+    if (i == 0) {
+        D.dmeta[D_TYPE] = type; D.dmeta[D_N] = n; D.dmeta[D_NLEAVES] = n_leaves; D.dmeta[D_MAXDEPTH] = max_depth;
+        D.dmeta[D_IDX_DYN] = idx_dyn; D.dmeta[D_MATCH_DYN] = m_dyn; D.dmeta[D_IDX_ST] = idx_st; D.dmeta[D_MATCH_ST] = m_st;
+        D.dmeta[8] = reverse;
+    }
+}
+
+// DraftModel.lookup (samd_sam_only/draft.py:50-59 | samd/draft.py:52-63) + gen_buffers
+__device__ __forceinline__ void do_draft(const SessionDev &D, const StaticDev &S, bool have_static, const samd_params_t &P,
+                                         StepShared &sh, int start) {
+    int id = D.meta[M_CUR_IDX], md = D.meta[M_CUR_LEN];
+    dyn_transfer(D, id, md, start);
+    int is = 0, ms = 0;
+    if (have_static) { is = D.meta[M_ST_IDX]; ms = D.meta[M_ST_LEN]; st_transfer(S, is, ms, start); }
+    ms -= P.len_bias;
+    int type, n;
+    if (P.variant == 0) {
+        if (md >= ms || !have_static) {
+            type = 0;
+            n = seq_draft_var(sh, D.text, D.meta[M_NTEXT], D.minend[id], draft_size(md, P.alpha, P.max_predicts), start);
+        } else {
+            type = 1;
+            n = tree_draft(sh, S, is, draft_size(ms, P.alpha, P.max_predicts), P.K, start);
+        }
+    } else {
+        const int best = md > ms ? md : ms;
+        if (best >= P.len_threshold) {
+            type = 0;
+            if (md >= ms || !have_static) {
+                // to_anc (samd/sam/dyn_sam.py:99-105)
+                int a = id;
+                if (a != 0) {
+                    const int maxlen = D.meta[M_MAXLEN];
+                    int to_end = maxlen - D.minend[a];
+                    while (D.link[a] != 0 && P.n_predicts > to_end) { a = D.link[a]; to_end = maxlen - D.minend[a]; }
+                }
+                n = seq_draft_fixed(sh, D.text, D.meta[M_NTEXT], D.minend[a], P.n_predicts, start);
+            } else {
+                n = seq_draft_fixed(sh, S.text, S.n_text, S.nodes[is].aux, P.n_predicts, start);
+            }
+        } else {
+            type = 2; n = 1;                      // the tree model drafts (samd/draft.py:63): only the start token here
+            if (lane_id() == 0) { sh.tokens[0] = start; sh.parent[0] = -1; }
+            __syncthreads();
+        }
+    }
+    int nl, mxd;
+    build_buffers(sh, n, 0, nl, mxd);
+    store_draft(D, sh, type, n, nl, mxd, id, md, is, ms, 0);
+}
+
+// eval_posterior, greedy (samd_sam_only/utils.py:127-141) + update_state's selection
+// (samd_sam_only/samd_model.py:165-169), on the draft held in LDS (tokens, path rows).
+__device__ __forceinline__ void do_accept(const SessionDev &D, StepShared &sh, const int *node_argmax, int type, int n,
+                                          int n_leaves, int max_depth, int &accept_out, int &next_token_out) {
+    const int i = lane_id();
+    if (i < n) sh.node_argmax[i] = node_argmax[i];
+    __syncthreads();
+    int acc = -1;
+    if (i < n_leaves) {
+        acc = 0;
+        for (int j = 1; j < max_depth; j++) {
+            const int cj = sh.path[i][j], pj = sh.path[i][j - 1];
+            const int cand = cj == PATH_PAD ? 0 : sh.tokens[cj];              // pad token 0 (utils.py:95-96)
+            const int am = sh.node_argmax[pj == PATH_PAD ? n - 1 : pj];       // logits[-1] = last node (samd_model.py:144)
+            if (cand != am) break;
+            acc++;
+        }
+    }
+    // first maximum over rows: key = acc * 64 + (63 - row)
+    int key = acc < 0 ? -1 : acc * WAVE + (WAVE - 1 - i);
+    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(key, o); key = v > key ? v : key; }
+    const int best_acc = key / WAVE, best = WAVE - 1 - (key % WAVE);
+    const int a = best_acc + 1;
+    if (i < a) {
+        const int node = sh.path[best][i];
+        const int tk = node == PATH_PAD ? 0 : sh.tokens[node];
+        sh.accepted[i] = tk;
+        D.acc_tokens[i] = tk;
+        D.kv_index[i] = node == PATH_PAD ? -1 : node;
+    }
+    const int nn_raw = sh.path[best][best_acc];
+    const int nn = nn_raw == PATH_PAD ? n - 1 : nn_raw;
+    const int next_token = sh.node_argmax[nn];
+    if (i == 0) {
+        const int start = D.cache_length[0];
+        D.verdict[V_BEST] = best; D.verdict[V_ACCEPT] = a; D.verdict[V_NEXT_NODE] = nn; D.verdict[V_NEXT_TOKEN] = next_token;
+        D.verdict[V_KV_START] = start; D.verdict[V_IS_TREE] = (type != 0);
+        D.cache_length[0] = start + a;                                         // cache.py:133
+        D.start_token[0] = next_token;
+        D.counters[C_STEPS] += 1; D.counters[C_TOKENS] += a;
+        D.counters[type == 0 ? C_SEQ_STEPS : C_TREE_STEPS] += 1;
+    }
+    __syncthreads();
+    accept_out = a; next_token_out = next_token;
+}

@@ -1,0 +1,472 @@
+// sam_kernels.hip -- gfx950 kernels + C ABI of the suffix-automaton draft path.
+// Reference functions replaced: see include/samd_hip.h (one citation per entry point).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "sam_device.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { samd_set_error("%s: %s", #x, hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
+#define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
+
+static inline StaticDev static_view(const samd_static_t *s) {
+    StaticDev v;
+    if (!s) { memset(&v, 0, sizeof(v)); return v; }
+    v.nodes = s->d_nodes; v.root_next = s->d_root; v.spill = s->d_spill; v.text = s->d_text;
+    v.n_states = (int32_t)s->n_states; v.vocab = (int32_t)s->vocab; v.n_text = (int32_t)s->n_text; v.kind = s->kind;
+    return v;
+}
+
+// ================================================================================================
+// batched walk: one lane per cursor, T tokens each (time-major token matrix => coalesced token loads)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__restrict__ cursors,
+                                                     const int32_t *__restrict__ tokens, int B, int T, int commit,
+                                                     int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long visited = 0;
+    if (b < B) {
+        int2 c = reinterpret_cast<const int2 *>(cursors)[b];
+        int idx = c.x, len = c.y;
+        int tok = tokens[b];
+        for (int t = 0; t < T; t++) {
+            const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;   // prefetch the next token
+            visited += st_transfer(S, idx, len, tok);
+            if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(idx, len);
+            tok = nxt;
+        }
+        if (commit) reinterpret_cast<int2 *>(cursors)[b] = make_int2(idx, len);
+    }
+    if (visited_total) {
+        for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
+        if ((threadIdx.x & 63) == 0 && visited) atomicAdd(visited_total, visited);
+    }
+}
+
+// ================================================================================================
+// single-wavefront session kernels
+// ================================================================================================
+enum { OP_RESET = 1, OP_ADD = 2, OP_DYN_WALK = 4, OP_ST_WALK = 8, OP_DRAFT = 16, OP_ACCEPT = 32, OP_COMMIT = 64,
+       OP_DRAFT_SEQ = 128, OP_DRAFT_TREE = 256, OP_DRAFT_FIXED = 512, OP_SET_DRAFT = 1024, OP_SET_CURSORS = 2048,
+       OP_BUFFERS_ONLY = 4096 };
+
+struct StepArgs {
+    int ops;
+    const int32_t *tokens;      // OP_ADD / walks / OP_SET_DRAFT
+    const int32_t *parents;     // OP_SET_DRAFT
+    const int32_t *d_n;         // optional device-side count
+    int n;
+    int commit;
+    int32_t *out2;              // optional (index,length) result of a walk
+    const int32_t *start_token; // OP_DRAFT
+    const int32_t *node_argmax; // OP_ACCEPT
+    int index, match, start, source, type, reverse;
+    int c0, c1, c2, c3;         // OP_SET_CURSORS
+    int have_static;
+};
+
+__device__ __forceinline__ void load_draft(const SessionDev &D, StepShared &sh, int &type, int &n, int &nl, int &md) {
+    const int i = lane_id();
+    type = D.dmeta[D_TYPE]; n = D.dmeta[D_N]; nl = D.dmeta[D_NLEAVES]; md = D.dmeta[D_MAXDEPTH];
+    if (i < n) { sh.tokens[i] = D.tokens[i]; sh.parent[i] = D.parent[i]; }
+    for (int k = i; k < SAMD_MAX_DRAFT * SAMD_MAX_DRAFT; k += WAVE) (&sh.path[0][0])[k] = PATH_PAD;
+    __syncthreads();
+    for (int k = i; k < nl * md; k += WAVE) {
+        const int v = D.retrieve[k];
+        sh.path[k / md][k % md] = v < 0 ? PATH_PAD : (unsigned char)v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_params_t P, StepArgs A) {
+    __shared__ StepShared sh;
+    const int lane = lane_id();
+
+    if (A.ops & OP_RESET) {
+        // DynSAM.reset (dyn_sam.py:37-43) + static cursor to root (static_sam.py:127-129)
+        for (uint32_t k = lane; k <= D.hmask; k += WAVE) D.hkey[k] = SAMD_HEMPTY;
+        if (lane == 0) {
+            D.link[0] = -1; D.length[0] = 0; D.minend[0] = 0; D.head[0] = -1; D.tail[0] = -1;
+            D.text[0] = -1;
+            for (int k = 0; k < M_COUNT; k++) D.meta[k] = 0;
+            D.meta[M_NSTATES] = 1; D.meta[M_NTEXT] = 1;
+            for (int k = 0; k < D_COUNT; k++) D.dmeta[k] = 0;
+            for (int k = 0; k < V_COUNT; k++) D.verdict[k] = 0;
+            for (int k = 0; k < C_COUNT; k++) D.counters[k] = 0;
+            D.start_token[0] = 0; D.cache_length[0] = 0;
+        }
+        wave_mem_sync();
+    }
+    if (A.ops & OP_SET_CURSORS) {
+        if (lane == 0) { D.meta[M_CUR_IDX] = A.c0; D.meta[M_CUR_LEN] = A.c1; D.meta[M_ST_IDX] = A.c2; D.meta[M_ST_LEN] = A.c3; }
+        wave_mem_sync();
+    }
+    int n_in = A.d_n ? A.d_n[0] : A.n;
+
+    if (A.ops & OP_ACCEPT) {
+        int type, n, nl, md, a, nt;
+        load_draft(D, sh, type, n, nl, md);
+        do_accept(D, sh, A.node_argmax, type, n, nl, md, a, nt);
+        wave_mem_sync();
+    }
+    if (A.ops & OP_COMMIT) {
+        // DraftModel.update(accepted tokens) (draft.py:62-67)
+        const int a = D.verdict[V_ACCEPT];
+        if (lane < a) sh.accepted[lane] = D.acc_tokens[lane];
+        __syncthreads();
+        dyn_add_tokens(D, sh.accepted, a);
+        if (A.have_static) {
+            int is = D.meta[M_ST_IDX], ms = D.meta[M_ST_LEN];
+            for (int i = 0; i < a; i++) st_transfer(S, is, ms, sh.accepted[i]);
+            if (lane == 0) { D.meta[M_ST_IDX] = is; D.meta[M_ST_LEN] = ms; }
+        }
+        wave_mem_sync();
+    }
+    if (A.ops & OP_ADD) dyn_add_tokens(D, A.tokens, n_in);
+    if (A.ops & OP_DYN_WALK) {
+        int ci = D.meta[M_CUR_IDX], cl = D.meta[M_CUR_LEN];
+        for (int i = 0; i < n_in; i++) dyn_transfer(D, ci, cl, A.tokens[i]);
+        if (A.commit && lane == 0) { D.meta[M_CUR_IDX] = ci; D.meta[M_CUR_LEN] = cl; }
+        if (A.out2 && lane == 0) { A.out2[0] = ci; A.out2[1] = cl; }
+        wave_mem_sync();
+    }
+    if (A.ops & OP_ST_WALK) {
+        int is = D.meta[M_ST_IDX], ms = D.meta[M_ST_LEN];
+        if (A.have_static) for (int i = 0; i < n_in; i++) st_transfer(S, is, ms, A.tokens[i]);
+        else if (n_in > 0) { is = 0; ms = 0; }
+        if (A.commit && lane == 0) { D.meta[M_ST_IDX] = is; D.meta[M_ST_LEN] = ms; }
+        if (A.out2 && lane == 0) { A.out2[0] = is; A.out2[1] = ms; }
+        wave_mem_sync();
+    }
+    if (A.ops & OP_DRAFT) {
+        do_draft(D, S, A.have_static != 0, P, sh, A.start_token[0]);
+    }
+    if (A.ops & OP_DRAFT_SEQ) {
+        const int n = seq_draft_var(sh, D.text, D.meta[M_NTEXT], D.minend[A.index], draft_size(A.match, P.alpha, P.max_predicts), A.start);
+        int nl, mxd; build_buffers(sh, n, 0, nl, mxd);
+        store_draft(D, sh, 0, n, nl, mxd, A.index, A.match, 0, 0, 0);
+    }
+    if (A.ops & OP_DRAFT_TREE) {
+        const int n = tree_draft(sh, S, A.index, draft_size(A.match, P.alpha, P.max_predicts), P.K, A.start);
+        int nl, mxd; build_buffers(sh, n, 0, nl, mxd);
+        store_draft(D, sh, 1, n, nl, mxd, 0, 0, A.index, A.match, 0);
+    }
+    if (A.ops & OP_DRAFT_FIXED) {
+        int n;
+        if (A.source == 0) {
+            int a = A.index;
+            if (a != 0) {
+                const int maxlen = D.meta[M_MAXLEN];
+                int to_end = maxlen - D.minend[a];
+                while (D.link[a] != 0 && P.n_predicts > to_end) { a = D.link[a]; to_end = maxlen - D.minend[a]; }
+            }
+            n = seq_draft_fixed(sh, D.text, D.meta[M_NTEXT], D.minend[a], P.n_predicts, A.start);
+            if (lane == 0) D.dmeta[9] = a;
+        } else {
+            n = seq_draft_fixed(sh, S.text, S.n_text, S.nodes[A.index].aux, P.n_predicts, A.start);
+        }
+        int nl, mxd; build_buffers(sh, n, 0, nl, mxd);
+        store_draft(D, sh, 0, n, nl, mxd, A.index, 0, A.index, 0, 0);
+    }
+    if (A.ops & OP_SET_DRAFT) {
+        if (lane < A.n) { sh.tokens[lane] = A.tokens[lane]; sh.parent[lane] = A.parents[lane]; }
+        __syncthreads();
+        int nl, mxd; build_buffers(sh, A.n, A.reverse, nl, mxd);
+        store_draft(D, sh, A.type, A.n, nl, mxd, 0, 0, 0, 0, A.reverse);
+    }
+}
+
+// standalone gen_buffers on a parent array
+__global__ __launch_bounds__(64) void k_tree_buffers(const int32_t *parent, int n, int reverse, int32_t *position, uint64_t *mask,
+                                                     uint8_t *mask_bool, int32_t *retrieve, int32_t *shape) {
+    __shared__ StepShared sh;
+    const int i = lane_id();
+    if (i < n) sh.parent[i] = parent[i];
+    __syncthreads();
+    int nl, md; build_buffers(sh, n, reverse, nl, md);
+    if (i < n) {
+        if (position) position[i] = sh.position[i];
+        if (mask) mask[i] = sh.mask[i];
+        if (mask_bool) for (int j = 0; j < n; j++) mask_bool[(size_t)i * n + j] = (uint8_t)((sh.mask[i] >> j) & 1ull);
+    }
+    if (retrieve) for (int k = i; k < nl * md; k += WAVE) { const unsigned char v = sh.path[k / md][k % md]; retrieve[k] = v == PATH_PAD ? -1 : (int)v; }
+    if (shape && i == 0) { shape[0] = nl; shape[1] = md; }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+extern "C" {
+
+int samd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int samd_device_info(int64_t out[4]) {
+    if (!out) return SAMD_E_INVALID;
+    out[0] = SAMD_ABI_VERSION; out[1] = out[2] = out[3] = 0;
+    int dev = 0;
+    if (samd_device_count() < 1) return SAMD_E_NODEVICE;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, dev));
+    out[1] = p.multiProcessorCount; out[2] = p.warpSize; out[3] = (int64_t)p.maxSharedMemoryPerMultiProcessor;
+    return SAMD_OK;
+}
+
+int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
+                     int32_t commit, int32_t *d_trace, void *stream) {
+    if (!sam || !sam->uploaded || !d_cursors || !d_tokens || B < 0 || T < 0) { samd_set_error("samd_static_walk: invalid argument"); return SAMD_E_INVALID; }
+    if (B == 0 || T == 0) return SAMD_OK;
+    const int threads = 256, blocks = (B + threads - 1) / threads;
+    hipLaunchKernelGGL(k_static_walk, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, static_view(sam), d_cursors, d_tokens,
+                       B, T, commit, d_trace, (unsigned long long *)nullptr);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+// same launch, additionally accumulating the number of visited states into *d_visited (u64, device);
+// used by bench.py to turn kernel time into algorithmic bytes (16 B per visited state).
+int samd_static_walk_counted(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
+                             int32_t commit, uint64_t *d_visited, void *stream) {
+    if (!sam || !sam->uploaded || !d_cursors || !d_tokens || B <= 0 || T <= 0 || !d_visited) return SAMD_E_INVALID;
+    const int threads = 256, blocks = (B + threads - 1) / threads;
+    hipLaunchKernelGGL(k_static_walk, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, static_view(sam), d_cursors, d_tokens,
+                       B, T, commit, (int32_t *)nullptr, (unsigned long long *)d_visited);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_session_create(int32_t max_tokens, samd_session_t **out) {
+    if (!out || max_tokens < 1 || max_tokens > (1 << 24)) { samd_set_error("samd_session_create: invalid max_tokens"); return SAMD_E_INVALID; }
+    if (samd_device_count() < 1) { samd_set_error("no HIP device"); return SAMD_E_NODEVICE; }
+    samd_session_t *s = (samd_session_t *)calloc(1, sizeof(samd_session_t));
+    s->max_tokens = max_tokens;
+    SessionDev &D = s->dev;
+    D.max_tokens = max_tokens;
+    D.cap_states = 2 * max_tokens + 2;
+    D.cap_text = max_tokens + 2;
+    uint32_t H = 1024; while (H < (uint32_t)max_tokens * 8u) H <<= 1;
+    D.hmask = H - 1;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_link = carve(4ull * D.cap_states), o_len = carve(4ull * D.cap_states), o_me = carve(4ull * D.cap_states),
+                 o_head = carve(4ull * D.cap_states), o_tail = carve(4ull * D.cap_states), o_hk = carve(8ull * H),
+                 o_hd = carve(4ull * H), o_hn = carve(4ull * H), o_text = carve(4ull * D.cap_text), o_meta = carve(4 * M_COUNT),
+                 o_tok = carve(4 * 64), o_par = carve(4 * 64), o_pos = carve(4 * 64), o_mask = carve(8 * 64), o_ret = carve(4 * 64 * 64),
+                 o_dm = carve(4 * D_COUNT), o_ver = carve(4 * V_COUNT), o_acc = carve(4 * 64), o_kv = carve(4 * 64),
+                 o_st = carve(4), o_cl = carve(4), o_cnt = carve(4 * C_COUNT);
+    s->arena_bytes = off;
+    if (hipMalloc(&s->arena, off) != hipSuccess) { free(s); samd_set_error("hipMalloc(session arena) failed"); return SAMD_E_HIP; }
+    char *base = (char *)s->arena;
+    D.link = (int32_t *)(base + o_link); D.length = (int32_t *)(base + o_len); D.minend = (int32_t *)(base + o_me);
+    D.head = (int32_t *)(base + o_head); D.tail = (int32_t *)(base + o_tail); D.hkey = (uint64_t *)(base + o_hk);
+    D.hdst = (int32_t *)(base + o_hd); D.hnext = (int32_t *)(base + o_hn); D.text = (int32_t *)(base + o_text);
+    D.meta = (int32_t *)(base + o_meta); D.tokens = (int32_t *)(base + o_tok); D.parent = (int32_t *)(base + o_par);
+    D.position = (int32_t *)(base + o_pos); D.mask = (uint64_t *)(base + o_mask); D.retrieve = (int32_t *)(base + o_ret);
+    D.dmeta = (int32_t *)(base + o_dm); D.verdict = (int32_t *)(base + o_ver); D.acc_tokens = (int32_t *)(base + o_acc);
+    D.kv_index = (int32_t *)(base + o_kv); D.start_token = (int32_t *)(base + o_st); D.cache_length = (int32_t *)(base + o_cl);
+    D.counters = (int32_t *)(base + o_cnt);
+    if (hipMemset(s->arena, 0, off) != hipSuccess) { (void)hipFree(s->arena); free(s); return SAMD_E_HIP; }
+    *out = s;
+    int rc = samd_session_reset(s, nullptr);
+    if (rc == SAMD_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = SAMD_E_HIP;
+    if (rc) { samd_session_free(s); *out = nullptr; }
+    return rc;
+}
+
+void samd_session_free(samd_session_t *s) {
+    if (!s) return;
+    if (s->arena) (void)hipFree(s->arena);
+    free(s);
+}
+
+static int launch_session(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, StepArgs &A, void *stream) {
+    if (!s) { samd_set_error("null session"); return SAMD_E_INVALID; }
+    if (sam && !sam->uploaded) { samd_set_error("static automaton not uploaded"); return SAMD_E_INVALID; }
+    samd_params_t P; memset(&P, 0, sizeof(P));
+    if (p) P = *p;
+    if (p && (P.max_predicts > SAMD_MAX_DRAFT || P.n_predicts > SAMD_MAX_DRAFT || P.max_predicts < 0 || P.n_predicts < 0)) {
+        samd_set_error("max_predicts / n_predicts must be in [0, %d]", SAMD_MAX_DRAFT); return SAMD_E_INVALID;
+    }
+    A.have_static = sam ? 1 : 0;
+    hipLaunchKernelGGL(k_session, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, s->dev, static_view(sam), P, A);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_session_reset(samd_session_t *s, void *stream) {
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_RESET;
+    return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_dyn_add_tokens(samd_session_t *s, const int32_t *d_tokens, int32_t n, const int32_t *d_n, void *stream) {
+    if (n < 0 || (!d_tokens && n > 0)) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_ADD; A.tokens = d_tokens; A.n = n; A.d_n = d_n;
+    return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_dyn_walk(samd_session_t *s, const int32_t *d_tokens, int32_t n, int32_t commit, int32_t *d_out, void *stream) {
+    if (n < 0 || (!d_tokens && n > 0)) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_DYN_WALK; A.tokens = d_tokens; A.n = n; A.commit = commit; A.out2 = d_out;
+    return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_session_static_walk(samd_session_t *s, const samd_static_t *sam, const int32_t *d_tokens, int32_t n,
+                             const int32_t *d_n, int32_t commit, int32_t *d_out, void *stream) {
+    if (n < 0 || (!d_tokens && n > 0)) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_ST_WALK; A.tokens = d_tokens; A.n = n; A.d_n = d_n; A.commit = commit; A.out2 = d_out;
+    return launch_session(s, sam, nullptr, A, stream);
+}
+
+int samd_session_set_cursors(samd_session_t *s, int32_t di, int32_t dl, int32_t si, int32_t sl, void *stream) {
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_SET_CURSORS; A.c0 = di; A.c1 = dl; A.c2 = si; A.c3 = sl;
+    return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_session_draft(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, const int32_t *d_start_token, void *stream) {
+    if (!p || !d_start_token) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_DRAFT; A.start_token = d_start_token;
+    return launch_session(s, sam, p, A, stream);
+}
+
+int samd_session_draft_seq(samd_session_t *s, const samd_params_t *p, int32_t index, int32_t match, int32_t start_token, void *stream) {
+    if (!p || index < 0) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_DRAFT_SEQ; A.index = index; A.match = match; A.start = start_token;
+    return launch_session(s, nullptr, p, A, stream);
+}
+
+int samd_session_draft_tree(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, int32_t index, int32_t match,
+                            int32_t start_token, void *stream) {
+    if (!p || !sam || index < 0 || index >= sam->n_states) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_DRAFT_TREE; A.index = index; A.match = match; A.start = start_token;
+    return launch_session(s, sam, p, A, stream);
+}
+
+int samd_session_draft_fixed(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, int32_t source, int32_t index,
+                             int32_t start_token, void *stream) {
+    if (!p || index < 0 || (source == 1 && (!sam || sam->kind != SAMD_KIND_ENDPOS || index >= sam->n_states))) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_DRAFT_FIXED; A.index = index; A.start = start_token; A.source = source;
+    return launch_session(s, sam, p, A, stream);
+}
+
+int samd_session_set_draft(samd_session_t *s, const int32_t *d_tokens, const int32_t *d_parent, int32_t n, int32_t type, void *stream) {
+    if (!d_tokens || !d_parent || n < 1 || n > SAMD_MAX_DRAFT) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_SET_DRAFT; A.tokens = d_tokens; A.parents = d_parent; A.n = n;
+    A.type = type & 0xff; A.reverse = (type >> 8) & 1;
+    return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_session_accept(samd_session_t *s, const int32_t *d_node_argmax, void *stream) {
+    if (!d_node_argmax) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_ACCEPT; A.node_argmax = d_node_argmax;
+    return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_session_commit(samd_session_t *s, const samd_static_t *sam, void *stream) {
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_COMMIT;
+    return launch_session(s, sam, nullptr, A, stream);
+}
+
+int samd_session_step(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, const int32_t *d_node_argmax, void *stream) {
+    if (!p || !d_node_argmax || !s) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_ACCEPT | OP_COMMIT | OP_DRAFT; A.node_argmax = d_node_argmax;
+    A.start_token = s->dev.start_token;
+    return launch_session(s, sam, p, A, stream);
+}
+
+int samd_session_device_views(samd_session_t *s, void *out[16]) {
+    if (!s || !out) return SAMD_E_INVALID;
+    const SessionDev &D = s->dev;
+    out[0] = D.tokens; out[1] = D.parent; out[2] = D.position; out[3] = D.mask; out[4] = D.retrieve; out[5] = D.dmeta;
+    out[6] = D.verdict; out[7] = D.acc_tokens; out[8] = D.kv_index; out[9] = D.start_token; out[10] = D.cache_length;
+    out[11] = D.text + 1; out[12] = D.counters; out[13] = D.meta; out[14] = nullptr; out[15] = nullptr;
+    return SAMD_OK;
+}
+
+#define D2H(dst, src, bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream))
+
+int samd_session_read_draft(samd_session_t *s, samd_draft_host_t *out, void *stream) {
+    if (!s || !out) return SAMD_E_INVALID;
+    const SessionDev &D = s->dev;
+    int32_t dm[D_COUNT];
+    D2H(dm, D.dmeta, sizeof(dm));
+    D2H(out->tokens, D.tokens, 4 * 64); D2H(out->parent, D.parent, 4 * 64); D2H(out->position, D.position, 4 * 64);
+    D2H(out->mask, D.mask, 8 * 64); D2H(out->retrieve, D.retrieve, 4 * 64 * 64);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    out->type = dm[D_TYPE]; out->n = dm[D_N]; out->n_leaves = dm[D_NLEAVES]; out->max_depth = dm[D_MAXDEPTH];
+    out->index_dyn = dm[D_IDX_DYN]; out->match_dyn = dm[D_MATCH_DYN]; out->index_static = dm[D_IDX_ST]; out->match_static = dm[D_MATCH_ST];
+    return SAMD_OK;
+}
+
+int samd_session_read_verdict(samd_session_t *s, samd_verdict_host_t *out, void *stream) {
+    if (!s || !out) return SAMD_E_INVALID;
+    const SessionDev &D = s->dev;
+    int32_t v[V_COUNT];
+    D2H(v, D.verdict, sizeof(v)); D2H(out->tokens, D.acc_tokens, 4 * 64); D2H(out->kv_index, D.kv_index, 4 * 64);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    out->best = v[V_BEST]; out->accept = v[V_ACCEPT]; out->next_node = v[V_NEXT_NODE]; out->next_token = v[V_NEXT_TOKEN];
+    return SAMD_OK;
+}
+
+int samd_session_export(samd_session_t *s, int64_t out_info[10], int32_t *h_link, int32_t *h_length, int32_t *h_minend,
+                        int32_t *h_deg, int32_t *h_edge_tok, int32_t *h_edge_dst, int32_t *h_text, void *stream) {
+    if (!s || !out_info) return SAMD_E_INVALID;
+    const SessionDev &D = s->dev;
+    int32_t m[M_COUNT];
+    D2H(m, D.meta, sizeof(m));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < 10; i++) out_info[i] = m[i];
+    const int ns = m[M_NSTATES], nt = m[M_NTEXT];
+    if (h_link) D2H(h_link, D.link, 4ull * ns);
+    if (h_length) D2H(h_length, D.length, 4ull * ns);
+    if (h_minend) D2H(h_minend, D.minend, 4ull * ns);
+    if (h_text) D2H(h_text, D.text, 4ull * nt);
+    if (h_deg || h_edge_tok || h_edge_dst) {
+        const size_t H = (size_t)D.hmask + 1;
+        std::vector<uint64_t> hk(H); std::vector<int32_t> hd(H), hn(H), head(ns);
+        D2H(hk.data(), D.hkey, 8 * H); D2H(hd.data(), D.hdst, 4 * H); D2H(hn.data(), D.hnext, 4 * H); D2H(head.data(), D.head, 4ull * ns);
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        size_t k = 0;
+        for (int st = 0; st < ns; st++) {
+            int d = 0;
+            for (int e = head[st]; e >= 0; e = hn[e]) {
+                if (h_edge_tok) h_edge_tok[k] = (int32_t)(uint32_t)hk[e];
+                if (h_edge_dst) h_edge_dst[k] = hd[e];
+                k++; d++;
+            }
+            if (h_deg) h_deg[st] = d;
+        }
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return SAMD_OK;
+}
+
+int samd_session_set_cache_length(samd_session_t *s, int32_t length, void *stream) {
+    if (!s || length < 0) return SAMD_E_INVALID;
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)s->dev.cache_length, length, 1, (hipStream_t)stream));
+    return SAMD_OK;
+}
+
+int samd_session_get_cache_length(samd_session_t *s, int32_t *h_out, void *stream) {
+    if (!s || !h_out) return SAMD_E_INVALID;
+    D2H(h_out, s->dev.cache_length, 4);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return SAMD_OK;
+}
+
+int samd_tree_buffers(const int32_t *d_parent, int32_t n, int32_t reverse_leaves, int32_t *d_position, uint64_t *d_mask,
+                      uint8_t *d_mask_bool, int32_t *d_retrieve, int32_t *d_shape, void *stream) {
+    if (!d_parent || n < 1 || n > SAMD_MAX_DRAFT) { samd_set_error("samd_tree_buffers: n must be in [1,64]"); return SAMD_E_INVALID; }
+    hipLaunchKernelGGL(k_tree_buffers, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, d_parent, n, reverse_leaves, d_position, d_mask,
+                       d_mask_bool, d_retrieve, d_shape);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+}  // extern "C"

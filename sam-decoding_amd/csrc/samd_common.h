@@ -1,0 +1,96 @@
+// samd_common.h -- shared host/device layouts of libsamd_hip (gfx950 only).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/samd_hip.h"
+
+#define SAMD_ABI_VERSION 1
+#define SAMD_INLINE_EDGES 5        // edges stored inside the 64-byte node
+#define SAMD_SPILL_HEAD 3          // spill block starts with top-k ranks 5,6,7 (-1 padded)
+
+// One automaton state = one 64-byte HBM line (one memory request per visited state).
+//   w0 = {link, length, aux, deg}            aux = cnt_endpos (KIND_COUNT) or min_endpos (KIND_ENDPOS)
+//   w1 = {e0.tok, e0.dst, e1.tok, e1.dst}    edges 0..4 in top-k order (count desc, ties in dict order;
+//   w2 = {e2.tok, e2.dst, e3.tok, e3.dst}    SO/sam/static_sam.py:140-146); empty slots = (-1,-1)
+//   w3 = {e4.tok, e4.dst, spill, reserved}   spill = index of this state's spill block (deg > 5) or -1
+// Spill block of a state with deg > 5:  [rank5, rank6, rank7 (padded (-1,-1))] followed by the
+// deg-5 edges of rank >= 5 sorted ascending by token (binary-searchable).
+struct __attribute__((aligned(64))) SamNode {
+    int32_t link, length, aux, deg;
+    int32_t e[2 * SAMD_INLINE_EDGES];
+    int32_t spill, reserved;
+};
+static_assert(sizeof(SamNode) == 64, "SamNode must be one 64-byte line");
+
+struct SamEdge { int32_t tok, dst; };
+
+// device view of a static automaton
+struct StaticDev {
+    const SamNode *nodes;
+    const int32_t *root_next;   // dense transition table of state 0: root_next[tok] = dst or -1
+    const SamEdge *spill;
+    const int32_t *text;        // KIND_ENDPOS: input_ids with the -1 sentinel at [0]
+    int32_t n_states, vocab, n_text, kind;
+};
+
+// ---- session (per request) -------------------------------------------------------------------
+// meta[] slots
+enum {
+    M_NSTATES = 0, M_NEDGES, M_NTEXT, M_LAST, M_MAXLEN, M_CUR_IDX, M_CUR_LEN, M_ST_IDX, M_ST_LEN, M_ERROR,
+    M_COUNT = 16
+};
+// dmeta[] slots (draft)
+enum { D_TYPE = 0, D_N, D_NLEAVES, D_MAXDEPTH, D_IDX_DYN, D_MATCH_DYN, D_IDX_ST, D_MATCH_ST, D_COUNT = 16 };
+// verdict[] slots
+enum { V_BEST = 0, V_ACCEPT, V_NEXT_NODE, V_NEXT_TOKEN, V_KV_START, V_IS_TREE, V_COUNT = 8 };
+// counters[] slots
+enum { C_STEPS = 0, C_TOKENS, C_SEQ_STEPS, C_TREE_STEPS, C_COUNT = 8 };
+
+#define SAMD_HEMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct SessionDev {
+    // dynamic automaton (SO/sam/dyn_sam.py:13-35): SoA state table + one open-addressing table whose
+    // slots ARE the edges: key=(state<<32|tok), dst, next = next edge of the same state in dict order
+    int32_t *link, *length, *minend, *head, *tail;
+    uint64_t *hkey;
+    int32_t *hdst, *hnext;
+    int32_t *text;              // input_ids, [0] = -1 sentinel; doubles as the committed-token history
+    int32_t *meta;              // M_*
+    // draft + verdict block
+    int32_t *tokens, *parent, *position;
+    uint64_t *mask;
+    int32_t *retrieve;          // [64][64]
+    int32_t *dmeta;             // D_*
+    int32_t *verdict;           // V_*
+    int32_t *acc_tokens, *kv_index;
+    int32_t *start_token, *cache_length;
+    int32_t *counters;
+    uint32_t hmask;
+    int32_t cap_states, cap_text, max_tokens;
+};
+
+struct samd_session {
+    SessionDev dev;
+    void *arena;
+    size_t arena_bytes;
+    int32_t max_tokens;
+};
+
+// host image + device image of a static automaton
+struct samd_static {
+    int32_t kind;
+    int64_t n_states, n_edges, n_spill, vocab, n_text;
+    // host image (may be released after upload in a later round; kept for export/save)
+    SamNode *h_nodes;
+    int32_t *h_root;
+    SamEdge *h_spill;
+    int32_t *h_text;
+    // device image
+    SamNode *d_nodes;
+    int32_t *d_root;
+    SamEdge *d_spill;
+    int32_t *d_text;
+    int uploaded;
+};
+
+void samd_set_error(const char *fmt, ...);

@@ -1,0 +1,511 @@
+// verify_kernels.hip -- gfx950 kernels of the verify side: row arg-max, KV-cache compaction,
+// tree-mask attention (MFMA), Token-Recycle table.  Reference functions: see include/samd_hip.h.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "samd_common.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { samd_set_error("%s: %s", #x, hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
+#define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct F16 { typedef _Float16 elem; typedef half8 vec8; };
+struct BF16 { typedef __bf16 elem; typedef bf16x8 vec8; };
+
+__device__ __forceinline__ float to_f32(_Float16 x) { return (float)x; }
+__device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
+__device__ __forceinline__ float to_f32(float x) { return x; }
+
+// ================================================================================================
+// torch.argmax(logits, -1): first maximum wins (SO/utils.py:86, :131)
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(1024) void k_argmax_rows(const T *__restrict__ logits, int rows, long long vocab, long long stride,
+                                                      const int *__restrict__ d_rows, int *__restrict__ out) {
+    const int row = blockIdx.x;
+    if (d_rows && row >= d_rows[0]) return;
+    if (row >= rows) return;
+    const T *x = logits + (size_t)row * stride;
+    float best = -INFINITY; long long bi = 0x7fffffffffffffffll;
+    constexpr int VEC = 16 / sizeof(T);
+    const bool vec_ok = ((((size_t)x) & 15) == 0);
+    const long long nvec = vec_ok ? vocab / VEC : 0;
+    for (long long c = threadIdx.x; c < nvec; c += blockDim.x) {
+        const uint4 raw = reinterpret_cast<const uint4 *>(x)[c];
+        const T *e = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) { const float v = to_f32(e[j]); if (v > best) { best = v; bi = c * VEC + j; } }
+    }
+    for (long long i = nvec * VEC + threadIdx.x; i < vocab; i += blockDim.x) {
+        const float v = to_f32(x[i]);
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+    // reduce (value desc, index asc)
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o); const long long oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __shared__ float sv[16]; __shared__ long long si[16];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int k = 1; k < nw; k++) if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        out[row] = (bi == 0x7fffffffffffffffll) ? 0 : (int)bi;     // all -inf / NaN row: index 0
+    }
+}
+
+// ================================================================================================
+// SamdStaticCache.select_indices (SO/cache.py:118-133): gather accepted rows, then scatter them to
+// [start, start+a).  One workgroup per (tensor, head): gather into LDS first (the reference's
+// index_select materialises before copy_), so overlapping source/destination rows are safe.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_kv_compact(void *const *__restrict__ tensors, const int *__restrict__ verdict,
+                                                    const int *__restrict__ kv_index, int n_heads, long long max_len, int row_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (!verdict[V_IS_TREE]) return;                       // sequence drafts keep their rows in place
+    const int a = verdict[V_ACCEPT], start = verdict[V_KV_START];
+    unsigned char *base = (unsigned char *)tensors[blockIdx.x / n_heads] + (size_t)(blockIdx.x % n_heads) * max_len * row_bytes;
+    const int chunks = row_bytes >> 4, total = a * chunks;
+    uint4 *lds = reinterpret_cast<uint4 *>(smem);
+    for (int c = threadIdx.x; c < total; c += blockDim.x) {
+        const int j = c / chunks, k = c - j * chunks;
+        const long long src = (long long)start + kv_index[j];
+        lds[c] = reinterpret_cast<const uint4 *>(base + (size_t)src * row_bytes)[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < total; c += blockDim.x) {
+        const int j = c / chunks, k = c - j * chunks;
+        if (kv_index[j] == j) continue;                    // already in place
+        reinterpret_cast<uint4 *>(base + (size_t)(start + j) * row_bytes)[k] = lds[c];
+    }
+}
+
+// ================================================================================================
+// tree-mask attention (SO/model_patch/llama.py:82-96 + SDPA).  One workgroup = one query head x one
+// KV split; 4 wavefronts x 16 query rows; 64-key tiles.  QK^T and PV on v_mfma_f32_16x16x32_{f16,bf16};
+// K fragments straight from HBM/L2 (row-major K is already the B-operand layout), V staged through LDS
+// transposed (key pairs packed per dword) so that PV's B fragments are 16-byte LDS reads; online softmax
+// in registers in the exp2 domain; partial (m, l, O) per split, merged by k_attn_combine.
+// ================================================================================================
+#define ATT_TILE 64
+#define ATT_SPLITS 8
+#define ATT_D 128
+#define VT_STRIDE (ATT_TILE + 8)      // halfs per Vt row: 144 B keeps 16-B alignment, spreads banks
+#define P_STRIDE (ATT_TILE + 8)
+
+template <typename TT> struct Mfma;
+template <> struct Mfma<F16> {
+    static __device__ __forceinline__ floatx4 run(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<BF16> {
+    static __device__ __forceinline__ floatx4 run(bf16x8 a, bf16x8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename TT>
+__global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
+                                                        const typename TT::elem *__restrict__ vc, float *__restrict__ ws,
+                                                        int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
+                                                        const unsigned long long *__restrict__ mask, const int *__restrict__ d_L,
+                                                        const int *__restrict__ d_n, float scale_log2) {
+    typedef typename TT::elem E;
+    typedef typename TT::vec8 V8;
+    __shared__ __attribute__((aligned(16))) E Vt[ATT_D * VT_STRIDE];
+    __shared__ __attribute__((aligned(16))) E Pw[4 * 16 * P_STRIDE];
+
+    const int h = blockIdx.x, split = blockIdx.y;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lg = l >> 4;
+    const int L = d_L[0];
+    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
+    const int total = L + n;
+    const int ntiles = (total + ATT_TILE - 1) / ATT_TILE;
+    const int tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
+    const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
+    const int kvh = h / (n_heads / n_kv_heads);
+    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
+    const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
+    const int row_base = 16 * w;
+    const bool active = row_base < n;
+
+    // Q fragments (A operand): row = row_base + lr, d = 32*kk + 8*lg .. +8
+    V8 qa[4];
+    {
+        const int qrow = row_base + lr;
+        const E *qp = q + ((size_t)qrow * n_heads + h) * ATT_D + 8 * lg;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (qrow < n_q_pad) raw = *reinterpret_cast<const uint4 *>(qp + 32 * kk);
+            qa[kk] = __builtin_bit_cast(V8, raw);
+        }
+    }
+    unsigned long long mrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const int row = row_base + 4 * lg + r; mrow[r] = row < n ? mask[row] : 0ull; }
+
+    float m_run[4], l_run[4];
+    floatx4 o[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) o[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    E *Pmine = Pw + w * 16 * P_STRIDE;
+
+    for (int t = t0; t < t1; t++) {
+        const int key0 = t * ATT_TILE;
+        __syncthreads();                                   // previous tile's Vt / Pw reads are done
+        // ---- stage V^T: thread handles key pair (2p, 2p+1) x one 8-wide d chunk, twice
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+            const int ka = key0 + 2 * p, kb = ka + 1;
+            uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+            if (ka < total) ra = *reinterpret_cast<const uint4 *>(vbase + (size_t)ka * ATT_D + d0);
+            if (kb < total) rb = *reinterpret_cast<const uint4 *>(vbase + (size_t)kb * ATT_D + d0);
+            const unsigned short *ea = reinterpret_cast<const unsigned short *>(&ra);
+            const unsigned short *eb = reinterpret_cast<const unsigned short *>(&rb);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<unsigned int *>(&Vt[(d0 + j) * VT_STRIDE + 2 * p]) = (unsigned int)ea[j] | ((unsigned int)eb[j] << 16);
+        }
+        // ---- S = Q K^T for this wave's 16 rows x 64 keys
+        floatx4 s[4];
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                int key = key0 + 16 * st + lr;
+                key = key < (int)max_len ? key : (int)max_len - 1;
+                const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
+                floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
+                    acc = Mfma<TT>::run(qa[kk], __builtin_bit_cast(V8, raw), acc);
+                }
+                s[st] = acc;
+            }
+            // ---- mask, online softmax (exp2 domain); lane holds rows 4*lg+r, key 16*st+lr
+            float tmax[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) tmax[r] = -INFINITY;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const int key = key0 + 16 * st + lr;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool ok = key < L || (key < total && ((mrow[r] >> (key - L)) & 1ull));
+                    const float v = ok ? s[st][r] * scale_log2 : -INFINITY;
+                    s[st][r] = v;
+                    tmax[r] = fmaxf(tmax[r], v);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = tmax[r];
+                v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
+                v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+                const float m_new = fmaxf(m_run[r], v);
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = exp2f(m_run[r] - m_use);          // m_run = -inf -> 0
+                float psum = 0.f;
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    const float p = exp2f(s[st][r] - m_use);
+                    psum += p;
+                    Pmine[(4 * lg + r) * P_STRIDE + 16 * st + lr] = (E)p;
+                }
+                psum += __shfl_xor(psum, 1); psum += __shfl_xor(psum, 2);
+                psum += __shfl_xor(psum, 4); psum += __shfl_xor(psum, 8);
+                l_run[r] = l_run[r] * alpha + psum;
+                m_run[r] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) o[dt][r] *= alpha;
+            }
+        }
+        __syncthreads();                                   // Vt staged, Pw written
+        if (active) {
+            // ---- O += P V : A = P[row=lr][keys 32*kc + 8*lg..+8], B = Vt[d = 16*dt + lr][same keys]
+            V8 pa[2];
+#pragma unroll
+            for (int kcx = 0; kcx < 2; kcx++)
+                pa[kcx] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4 *>(&Pmine[lr * P_STRIDE + 32 * kcx + 8 * lg]));
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++) {
+#pragma unroll
+                for (int kcx = 0; kcx < 2; kcx++) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(&Vt[(16 * dt + lr) * VT_STRIDE + 32 * kcx + 8 * lg]);
+                    o[dt] = Mfma<TT>::run(pa[kcx], __builtin_bit_cast(V8, raw), o[dt]);
+                }
+            }
+        }
+    }
+    // ---- partial result: ws[split][row][h][0..127] = O, [128] = m, [129] = l
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = row_base + 4 * lg + r;
+            float *dst = ws + (((size_t)split * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
+            if (row < n_q_pad) {
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) dst[16 * dt + lr] = o[dt][r];
+                if (lr == 0) { dst[ATT_D] = m_run[r]; dst[ATT_D + 1] = l_run[r]; }
+            }
+        }
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
+                                                      const int *__restrict__ d_n) {
+    const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
+    E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d;
+    if (row >= n) { *dst = (E)0.f; return; }
+    float M = -INFINITY;
+    for (int s = 0; s < ATT_SPLITS; s++) M = fmaxf(M, ws[(((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2) + ATT_D]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < ATT_SPLITS; s++) {
+        const float *p = ws + (((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
+        const float m = p[ATT_D];
+        if (m == -INFINITY) continue;
+        const float wgt = exp2f(m - M);
+        num += wgt * p[d]; den += wgt * p[ATT_D + 1];
+    }
+    *dst = (E)(den > 0.f ? num / den : 0.f);
+}
+
+// ================================================================================================
+// Token Recycle (S/tree_model/token_recycle/token_recycle.py:33-60)
+// ================================================================================================
+struct samd_recycle {
+    int32_t vocab, n_nodes, n_levels, tmp_rows;
+    int32_t *d_table;       // [vocab][8]
+    uint8_t *d_present;     // [vocab]
+    int32_t *d_tmp;         // [tmp_rows][8] top-8 of the rows of one update
+    int32_t *d_child_off, *d_children, *d_level_off, *d_level_nodes;
+};
+
+// logits.topk(8).indices per row: 8 selection rounds in (value desc, index asc) order
+template <typename T>
+__global__ __launch_bounds__(256) void k_topk8_rows(const T *__restrict__ logits, int rows, long long vocab, long long stride,
+                                                    const int *__restrict__ d_rows, int *__restrict__ out) {
+    const int row = blockIdx.x;
+    if ((d_rows && row >= d_rows[0]) || row >= rows) return;
+    const T *x = logits + (size_t)row * stride;
+    __shared__ float sv[4]; __shared__ long long si[4];
+    __shared__ float pv_s; __shared__ long long pi_s;
+    float pv = INFINITY; long long pi = -1;
+    for (int round = 0; round < 8; round++) {
+        float best = -INFINITY; long long bi = 0x7fffffffffffffffll;
+        for (long long i = threadIdx.x; i < vocab; i += blockDim.x) {
+            const float v = to_f32(x[i]);
+            const bool eligible = (v < pv) || (v == pv && i > pi);
+            if (eligible && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o); const long long oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; k++) if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+            out[(size_t)row * 8 + round] = bi == 0x7fffffffffffffffll ? 0 : (int)bi;
+            pv_s = best; pi_s = bi;
+        }
+        __syncthreads();
+        pv = pv_s; pi = pi_s;
+        __syncthreads();
+    }
+}
+
+// cache[token] = top-8, rows in order, later rows overwrite earlier ones (token_recycle.py:47-48)
+__global__ void k_recycle_scatter(const int *__restrict__ tokens, const int *__restrict__ topk, int rows, const int *__restrict__ d_rows,
+                                  int *__restrict__ table, uint8_t *__restrict__ present, int vocab) {
+    const int n = d_rows ? min(rows, d_rows[0]) : rows;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tokens[i];
+    if (t < 0 || t >= vocab) return;
+    for (int j = i + 1; j < n; j++) if (tokens[j] == t) return;        // a later row wins
+    for (int k = 0; k < 8; k++) table[(size_t)t * 8 + k] = topk[(size_t)i * 8 + k];
+    present[t] = 1;
+}
+
+// gen_draft (token_recycle.py:50-60): level-synchronous fill of the static tree, one lane per node
+__global__ __launch_bounds__(64) void k_recycle_draft(const int *__restrict__ table, const uint8_t *__restrict__ present, int vocab,
+                                                      const int *__restrict__ child_off, const int *__restrict__ children,
+                                                      const int *__restrict__ level_off, const int *__restrict__ level_nodes,
+                                                      int n_nodes, int n_levels, const int *__restrict__ start, int *__restrict__ out) {
+    __shared__ int tok[SAMD_MAX_DRAFT];
+    const int lane = threadIdx.x;
+    if (lane < n_nodes) tok[lane] = lane == 0 ? start[0] : 0;
+    __syncthreads();
+    for (int lv = 0; lv < n_levels; lv++) {
+        const int k = level_off[lv] + lane;
+        if (k < level_off[lv + 1]) {
+            const int node = level_nodes[k], t = tok[node];
+            if (t >= 0 && t < vocab && present[t])
+                for (int c = child_off[node]; c < child_off[node + 1]; c++) tok[children[c]] = table[(size_t)t * 8 + (c - child_off[node])];
+        }
+        __syncthreads();
+    }
+    if (lane < n_nodes) out[lane] = tok[lane];
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int samd_argmax_rows(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const int32_t *d_rows,
+                     int32_t *d_out, void *stream) {
+    if (!d_logits || !d_out || rows < 0 || vocab < 1 || row_stride < vocab) { samd_set_error("samd_argmax_rows: invalid argument"); return SAMD_E_INVALID; }
+    if (rows == 0) return SAMD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int esz = dtype == SAMD_F32 ? 4 : 2;
+    if ((row_stride * esz) % 16 != 0 && rows > 1) {
+        // rows after the first are not 16-byte aligned: the kernel falls back to scalar loads per row
+    }
+    switch (dtype) {
+    case SAMD_F16: hipLaunchKernelGGL(k_argmax_rows<_Float16>, dim3(rows), dim3(1024), 0, st, (const _Float16 *)d_logits, rows, (long long)vocab, (long long)row_stride, d_rows, d_out); break;
+    case SAMD_BF16: hipLaunchKernelGGL(k_argmax_rows<__bf16>, dim3(rows), dim3(1024), 0, st, (const __bf16 *)d_logits, rows, (long long)vocab, (long long)row_stride, d_rows, d_out); break;
+    case SAMD_F32: hipLaunchKernelGGL(k_argmax_rows<float>, dim3(rows), dim3(1024), 0, st, (const float *)d_logits, rows, (long long)vocab, (long long)row_stride, d_rows, d_out); break;
+    default: samd_set_error("samd_argmax_rows: bad dtype"); return SAMD_E_INVALID;
+    }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len,
+                    int32_t head_dim, int32_t elem_bytes, void *stream) {
+    if (!s || !d_tensors || n_tensors < 1 || n_heads < 1 || head_dim < 1 || (head_dim * elem_bytes) % 16 != 0) {
+        samd_set_error("samd_kv_compact: invalid argument (row bytes must be a multiple of 16)"); return SAMD_E_INVALID;
+    }
+    const int row_bytes = head_dim * elem_bytes;
+    const size_t lds = (size_t)SAMD_MAX_DRAFT * row_bytes;
+    if (lds > 64 * 1024) { samd_set_error("samd_kv_compact: row too large"); return SAMD_E_INVALID; }
+    hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, s->dev.verdict,
+                       s->dev.kv_index, n_heads, (long long)max_len, row_bytes);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int64_t samd_tree_attention_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim) {
+    return (int64_t)ATT_SPLITS * n_q_pad * n_heads * (head_dim + 2) * 4;
+}
+
+int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
+                        int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
+                        const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
+                        void *stream) {
+    if (!d_q || !d_k_cache || !d_v_cache || !d_out || !d_mask || !d_cache_length || !d_n || !d_workspace) { samd_set_error("samd_tree_attention: null pointer"); return SAMD_E_INVALID; }
+    if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 ||
+        (dtype != SAMD_F16 && dtype != SAMD_BF16) || workspace_bytes < samd_tree_attention_workspace(n_q_pad, n_heads, head_dim)) {
+        samd_set_error("samd_tree_attention: unsupported shape (head_dim must be 128, n_q_pad <= 64, f16/bf16) or workspace too small");
+        return SAMD_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const float scale_log2 = scale * 1.4426950408889634f;
+    float *ws = (float *)d_workspace;
+    if (dtype == SAMD_F16) {
+        hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
+                           (const _Float16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
+                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_n);
+    } else {
+        hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
+                           (const __bf16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
+                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_n);
+    }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_recycle_create(int32_t vocab, const int32_t *h_child_offsets, const int32_t *h_children, int32_t n_nodes, samd_recycle_t **out) {
+    if (!out || vocab < 1 || n_nodes < 1 || n_nodes > SAMD_MAX_DRAFT || !h_child_offsets) { samd_set_error("samd_recycle_create: invalid argument"); return SAMD_E_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { samd_set_error("no HIP device"); return SAMD_E_NODEVICE; }
+    // levels of the static tree (parents precede children in the reference's numbering)
+    std::vector<int> parent(n_nodes, -1), depth(n_nodes, 0);
+    const int n_child = h_child_offsets[n_nodes];
+    for (int i = 0; i < n_nodes; i++)
+        for (int c = h_child_offsets[i]; c < h_child_offsets[i + 1]; c++) {
+            const int ch = h_children[c];
+            if (ch <= i || ch >= n_nodes || (c - h_child_offsets[i]) >= SAMD_TOPK) { samd_set_error("samd_recycle_create: bad tree"); return SAMD_E_INVALID; }
+            parent[ch] = i;
+        }
+    int n_levels = 1;
+    for (int i = 1; i < n_nodes; i++) { depth[i] = parent[i] < 0 ? 0 : depth[parent[i]] + 1; n_levels = std::max(n_levels, depth[i] + 1); }
+    std::vector<int> level_off(n_levels + 1, 0), level_nodes(n_nodes);
+    for (int i = 0; i < n_nodes; i++) level_off[depth[i] + 1]++;
+    for (int lv = 0; lv < n_levels; lv++) level_off[lv + 1] += level_off[lv];
+    { std::vector<int> fill(level_off.begin(), level_off.end() - 1); for (int i = 0; i < n_nodes; i++) level_nodes[fill[depth[i]]++] = i; }
+
+    samd_recycle_t *t = (samd_recycle_t *)calloc(1, sizeof(samd_recycle_t));
+    t->vocab = vocab; t->n_nodes = n_nodes; t->n_levels = n_levels; t->tmp_rows = 16384;
+    bool ok = hipMalloc((void **)&t->d_table, (size_t)vocab * 8 * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&t->d_present, (size_t)vocab) == hipSuccess;
+    ok = ok && hipMalloc((void **)&t->d_tmp, (size_t)t->tmp_rows * 8 * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&t->d_child_off, (n_nodes + 1) * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&t->d_children, std::max(1, n_child) * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&t->d_level_off, (n_levels + 1) * 4) == hipSuccess;
+    ok = ok && hipMalloc((void **)&t->d_level_nodes, n_nodes * 4) == hipSuccess;
+    ok = ok && hipMemset(t->d_table, 0, (size_t)vocab * 8 * 4) == hipSuccess && hipMemset(t->d_present, 0, (size_t)vocab) == hipSuccess;
+    ok = ok && hipMemcpy(t->d_child_off, h_child_offsets, (n_nodes + 1) * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (n_child) ok = ok && hipMemcpy(t->d_children, h_children, n_child * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->d_level_off, level_off.data(), (n_levels + 1) * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(t->d_level_nodes, level_nodes.data(), n_nodes * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { samd_recycle_free(t); samd_set_error("samd_recycle_create: device allocation failed"); return SAMD_E_HIP; }
+    *out = t;
+    return SAMD_OK;
+}
+
+void samd_recycle_free(samd_recycle_t *t) {
+    if (!t) return;
+    void *ptrs[] = { t->d_table, t->d_present, t->d_tmp, t->d_child_off, t->d_children, t->d_level_off, t->d_level_nodes };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    free(t);
+}
+
+int samd_recycle_update(samd_recycle_t *t, const int32_t *d_tokens, const void *d_logits, int32_t dtype, int32_t n, const int32_t *d_n,
+                        int64_t vocab, int64_t row_stride, void *stream) {
+    if (!t || !d_tokens || !d_logits || n < 0 || n > t->tmp_rows || vocab < 8 || vocab > t->vocab) { samd_set_error("samd_recycle_update: invalid argument"); return SAMD_E_INVALID; }
+    if (n == 0) return SAMD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case SAMD_F16: hipLaunchKernelGGL(k_topk8_rows<_Float16>, dim3(n), dim3(256), 0, st, (const _Float16 *)d_logits, n, (long long)vocab, (long long)row_stride, d_n, t->d_tmp); break;
+    case SAMD_BF16: hipLaunchKernelGGL(k_topk8_rows<__bf16>, dim3(n), dim3(256), 0, st, (const __bf16 *)d_logits, n, (long long)vocab, (long long)row_stride, d_n, t->d_tmp); break;
+    case SAMD_F32: hipLaunchKernelGGL(k_topk8_rows<float>, dim3(n), dim3(256), 0, st, (const float *)d_logits, n, (long long)vocab, (long long)row_stride, d_n, t->d_tmp); break;
+    default: return SAMD_E_INVALID;
+    }
+    hipLaunchKernelGGL(k_recycle_scatter, dim3((n + 255) / 256), dim3(256), 0, st, d_tokens, t->d_tmp, n, d_n, t->d_table, t->d_present, t->vocab);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_recycle_draft(samd_recycle_t *t, const int32_t *d_start_token, int32_t *d_out, void *stream) {
+    if (!t || !d_start_token || !d_out) return SAMD_E_INVALID;
+    hipLaunchKernelGGL(k_recycle_draft, dim3(1), dim3(64), 0, (hipStream_t)stream, t->d_table, t->d_present, t->vocab, t->d_child_off,
+                       t->d_children, t->d_level_off, t->d_level_nodes, t->n_nodes, t->n_levels, d_start_token, d_out);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_recycle_export(samd_recycle_t *t, int32_t *h_table, uint8_t *h_present, void *stream) {
+    if (!t) return SAMD_E_INVALID;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (h_table) HIPCHK(hipMemcpy(h_table, t->d_table, (size_t)t->vocab * 8 * 4, hipMemcpyDeviceToHost));
+    if (h_present) HIPCHK(hipMemcpy(h_present, t->d_present, (size_t)t->vocab, hipMemcpyDeviceToHost));
+    return SAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,346 @@
+"""samd_hip -- ctypes binding of libsamd_hip.so (include/samd_hip.h), the gfx950 draft+verify hot path.
+
+There is NO CPU fallback: every op raises if the shared library is missing or if no MI355X is
+visible.  torch is used only for device memory, streams and dtypes.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsamd_hip.so")
+MAX_DRAFT = 64
+TOPK = 8
+KIND_COUNT, KIND_ENDPOS = 0, 1
+F16, BF16, F32 = 0, 1, 2
+
+_lib = None
+
+
+class SamdError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """samd_params_t"""
+    _fields_ = [("variant", C.c_int32), ("max_predicts", C.c_int32), ("alpha", C.c_double), ("K", C.c_int32),
+                ("len_bias", C.c_int32), ("n_predicts", C.c_int32), ("len_threshold", C.c_int32),
+                ("static_null", C.c_int32), ("reserved", C.c_int32)]
+
+
+class DraftHost(C.Structure):
+    """samd_draft_host_t"""
+    _fields_ = [("type", C.c_int32), ("n", C.c_int32), ("n_leaves", C.c_int32), ("max_depth", C.c_int32),
+                ("index_dyn", C.c_int32), ("match_dyn", C.c_int32), ("index_static", C.c_int32),
+                ("match_static", C.c_int32), ("tokens", C.c_int32 * MAX_DRAFT), ("parent", C.c_int32 * MAX_DRAFT),
+                ("position", C.c_int32 * MAX_DRAFT), ("mask", C.c_uint64 * MAX_DRAFT),
+                ("retrieve", C.c_int32 * (MAX_DRAFT * MAX_DRAFT))]
+
+
+class VerdictHost(C.Structure):
+    """samd_verdict_host_t"""
+    _fields_ = [("best", C.c_int32), ("accept", C.c_int32), ("next_node", C.c_int32), ("next_token", C.c_int32),
+                ("tokens", C.c_int32 * MAX_DRAFT), ("kv_index", C.c_int32 * MAX_DRAFT)]
+
+
+# every exported symbol of include/samd_hip.h with its signature; tests check this list against the header
+_VP, _I32, _I64, _F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_PROTOS = {
+    "samd_last_error": (C.c_char_p, []),
+    "samd_device_count": (C.c_int, []),
+    "samd_device_info": (C.c_int, [_VP]),
+    "samd_static_build": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _VP]),
+    "samd_static_from_tables": (C.c_int, [_I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
+    "samd_static_save": (C.c_int, [_VP, C.c_char_p]),
+    "samd_static_load": (C.c_int, [C.c_char_p, _VP]),
+    "samd_static_free": (None, [_VP]),
+    "samd_static_upload": (C.c_int, [_VP]),
+    "samd_static_info": (C.c_int, [_VP, _VP]),
+    "samd_static_export": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "samd_static_device_image": (C.c_int, [_VP, _VP, _VP]),
+    "samd_static_alloc_like": (C.c_int, [_VP, _VP]),
+    "samd_static_walk": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
+    "samd_static_walk_counted": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
+    "samd_session_create": (C.c_int, [_I32, _VP]),
+    "samd_session_free": (None, [_VP]),
+    "samd_session_reset": (C.c_int, [_VP, _VP]),
+    "samd_dyn_add_tokens": (C.c_int, [_VP, _VP, _I32, _VP, _VP]),
+    "samd_dyn_walk": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP]),
+    "samd_session_static_walk": (C.c_int, [_VP, _VP, _VP, _I32, _VP, _I32, _VP, _VP]),
+    "samd_session_export": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "samd_session_set_cursors": (C.c_int, [_VP, _I32, _I32, _I32, _I32, _VP]),
+    "samd_session_draft": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "samd_session_draft_seq": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
+    "samd_session_draft_tree": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
+    "samd_session_draft_fixed": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
+    "samd_session_set_draft": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
+    "samd_session_read_draft": (C.c_int, [_VP, _VP, _VP]),
+    "samd_session_device_views": (C.c_int, [_VP, _VP]),
+    "samd_tree_buffers": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "samd_argmax_rows": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),
+    "samd_session_accept": (C.c_int, [_VP, _VP, _VP]),
+    "samd_session_read_verdict": (C.c_int, [_VP, _VP, _VP]),
+    "samd_session_commit": (C.c_int, [_VP, _VP, _VP]),
+    "samd_session_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "samd_session_set_cache_length": (C.c_int, [_VP, _I32, _VP]),
+    "samd_session_get_cache_length": (C.c_int, [_VP, _VP, _VP]),
+    "samd_kv_compact": (C.c_int, [_VP, _VP, _I32, _I32, _I64, _I32, _I32, _VP]),
+    "samd_tree_attention_workspace": (_I64, [_I32, _I32, _I32]),
+    "samd_tree_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
+                                      _VP, _I64, _VP]),
+    "samd_recycle_create": (C.c_int, [_I32, _VP, _VP, _I32, _VP]),
+    "samd_recycle_free": (None, [_VP]),
+    "samd_recycle_update": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _I64, _I64, _VP]),
+    "samd_recycle_draft": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "samd_recycle_export": (C.c_int, [_VP, _VP, _VP, _VP]),
+}
+
+
+def lib():
+    """Load libsamd_hip.so (built by __graft_entry__.build()).  Fails loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SamdError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)          # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().samd_last_error()
+        raise SamdError(f"libsamd_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    if lib().samd_device_count() < 1:
+        raise SamdError("no MI355X / HIP device visible: the SAM-Decoding hot path has no CPU fallback")
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a):
+    """host numpy array or torch tensor or int -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(int(a))
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def torch_dtype_code(dtype):
+    import torch
+    return {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}[dtype]
+
+
+class StaticAutomaton:
+    """Handle of a corpus suffix automaton (samd_static_t): host image + HBM image."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    # ---- construction ------------------------------------------------------------------------
+    @classmethod
+    def build(cls, batch_tokens, eos_token, kind=KIND_COUNT):
+        """StaticSAM.build (samd_sam_only/sam/static_sam.py:31-40; samd/sam/static_sam.py:37-46)."""
+        if len(batch_tokens) == 0:
+            flat = np.zeros(0, np.int32)
+        else:
+            flat = np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in batch_tokens])
+        off = np.zeros(len(batch_tokens) + 1, np.int64)
+        off[1:] = np.cumsum([len(t) for t in batch_tokens])
+        return cls.build_flat(flat, off, eos_token, kind)
+
+    @classmethod
+    def build_flat(cls, tokens, doc_offsets, eos_token, kind=KIND_COUNT):
+        tokens = _np_i32(tokens)
+        doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+        h = C.c_void_p()
+        check(lib().samd_static_build(_ptr(tokens), _ptr(doc_offsets), len(doc_offsets) - 1, int(eos_token), kind, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_tables(cls, kind, link, length, aux, deg, edge_tok, edge_dst, text=None):
+        arrs = [_np_i32(x) for x in (link, length, aux, deg, edge_tok, edge_dst)]
+        t = _np_i32(text) if text is not None else None
+        h = C.c_void_p()
+        check(lib().samd_static_from_tables(kind, len(arrs[0]), *[_ptr(a) for a in arrs], _ptr(t), 0 if t is None else len(t),
+                                            C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        check(lib().samd_static_load(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    def save(self, path):
+        check(lib().samd_static_save(self._h, os.fsencode(path)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().samd_static_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- facts ---------------------------------------------------------------------------------
+    def info(self):
+        out = (C.c_int64 * 8)()
+        check(lib().samd_static_info(self._h, out))
+        keys = ("n_states", "n_edges", "n_spill", "vocab", "device_bytes", "kind", "n_text", "uploaded")
+        return dict(zip(keys, list(out)))
+
+    def export(self):
+        i = self.info()
+        n, ne = i["n_states"], i["n_edges"]
+        link, length, aux, deg = (np.empty(n, np.int32) for _ in range(4))
+        et, ed = np.empty(ne, np.int32), np.empty(ne, np.int32)
+        check(lib().samd_static_export(self._h, *[_ptr(a) for a in (link, length, aux, deg, et, ed)]))
+        return dict(link=link, length=length, aux=aux, deg=deg, edge_tok=et, edge_dst=ed)
+
+    def upload(self):
+        require_gpu()
+        check(lib().samd_static_upload(self._h))
+        return self
+
+    def device_image(self):
+        ptrs, nbytes = (C.c_void_p * 4)(), (C.c_int64 * 4)()
+        check(lib().samd_static_device_image(self._h, ptrs, nbytes))
+        return [(ptrs[i], nbytes[i]) for i in range(4)]
+
+    # ---- batched walk --------------------------------------------------------------------------
+    def walk(self, cursors, tokens, commit=True, trace=None, visited=None):
+        """cursors int32 [B,2] (cuda), tokens int32 [T,B] (cuda, time-major)."""
+        T, B = tokens.shape
+        if visited is not None:
+            check(lib().samd_static_walk_counted(self._h, _ptr(cursors), _ptr(tokens), B, T, int(commit), _ptr(visited),
+                                                 current_stream()))
+        else:
+            check(lib().samd_static_walk(self._h, _ptr(cursors), _ptr(tokens), B, T, int(commit), _ptr(trace), current_stream()))
+
+
+class Session:
+    """One request stream (samd_session_t): dynamic automaton + cursors + draft + verdict, all in HBM."""
+
+    def __init__(self, max_tokens):
+        require_gpu()
+        h = C.c_void_p()
+        check(lib().samd_session_create(int(max_tokens), C.byref(h)))
+        self._h = h
+        self.max_tokens = int(max_tokens)
+        self._views = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().samd_session_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def reset(self):
+        check(lib().samd_session_reset(self._h, current_stream()))
+
+    def add_tokens(self, d_tokens, n=None, d_n=None):
+        check(lib().samd_dyn_add_tokens(self._h, _ptr(d_tokens), d_tokens.numel() if n is None else n, _ptr(d_n), current_stream()))
+
+    def dyn_walk(self, d_tokens, n, commit, d_out=None):
+        check(lib().samd_dyn_walk(self._h, _ptr(d_tokens), n, int(commit), _ptr(d_out), current_stream()))
+
+    def static_walk(self, sam, d_tokens, n, commit, d_out=None, d_n=None):
+        check(lib().samd_session_static_walk(self._h, sam._h if sam is not None else None, _ptr(d_tokens), n, _ptr(d_n),
+                                             int(commit), _ptr(d_out), current_stream()))
+
+    def set_cursors(self, dyn_index, dyn_length, st_index, st_length):
+        check(lib().samd_session_set_cursors(self._h, dyn_index, dyn_length, st_index, st_length, current_stream()))
+
+    def draft(self, sam, params, d_start_token):
+        check(lib().samd_session_draft(self._h, sam._h if sam is not None else None, C.byref(params), _ptr(d_start_token),
+                                       current_stream()))
+
+    def draft_seq(self, params, index, match, start):
+        check(lib().samd_session_draft_seq(self._h, C.byref(params), index, match, start, current_stream()))
+
+    def draft_tree(self, sam, params, index, match, start):
+        check(lib().samd_session_draft_tree(self._h, sam._h, C.byref(params), index, match, start, current_stream()))
+
+    def draft_fixed(self, sam, params, source, index, start):
+        check(lib().samd_session_draft_fixed(self._h, sam._h if sam is not None else None, C.byref(params), source, index, start,
+                                             current_stream()))
+
+    def set_draft(self, d_tokens, d_parent, n, type_=1, reverse=False):
+        check(lib().samd_session_set_draft(self._h, _ptr(d_tokens), _ptr(d_parent), n, type_ | (256 if reverse else 0),
+                                           current_stream()))
+
+    def read_draft(self):
+        out = DraftHost()
+        check(lib().samd_session_read_draft(self._h, C.byref(out), current_stream()))
+        return out
+
+    def accept(self, d_node_argmax):
+        check(lib().samd_session_accept(self._h, _ptr(d_node_argmax), current_stream()))
+
+    def read_verdict(self):
+        out = VerdictHost()
+        check(lib().samd_session_read_verdict(self._h, C.byref(out), current_stream()))
+        return out
+
+    def commit(self, sam):
+        check(lib().samd_session_commit(self._h, sam._h if sam is not None else None, current_stream()))
+
+    def step(self, sam, params, d_node_argmax):
+        check(lib().samd_session_step(self._h, sam._h if sam is not None else None, C.byref(params), _ptr(d_node_argmax),
+                                      current_stream()))
+
+    def set_cache_length(self, length):
+        check(lib().samd_session_set_cache_length(self._h, int(length), current_stream()))
+
+    def get_cache_length(self):
+        out = C.c_int32()
+        check(lib().samd_session_get_cache_length(self._h, C.byref(out), current_stream()))
+        return out.value
+
+    def kv_compact(self, d_tensor_ptrs, n_tensors, n_heads, max_len, head_dim, elem_bytes):
+        check(lib().samd_kv_compact(self._h, _ptr(d_tensor_ptrs), n_tensors, n_heads, max_len, head_dim, elem_bytes, current_stream()))
+
+    def device_views(self):
+        """raw device pointers of the draft/verdict block (see include/samd_hip.h)."""
+        if self._views is None:
+            out = (C.c_void_p * 16)()
+            check(lib().samd_session_device_views(self._h, out))
+            names = ("tokens", "parent", "position", "mask", "retrieve", "dmeta", "verdict", "acc_tokens", "kv_index",
+                     "start_token", "cache_length", "history", "counters", "meta")
+            self._views = {k: out[i] for i, k in enumerate(names)}
+        return self._views
+
+    def export(self, with_edges=True):
+        info = (C.c_int64 * 10)()
+        check(lib().samd_session_export(self._h, info, None, None, None, None, None, None, None, current_stream()))
+        ns, ne, nt = info[0], info[1], info[2]
+        link, length, minend, deg = (np.empty(ns, np.int32) for _ in range(4))
+        et, ed, text = np.empty(ne, np.int32), np.empty(ne, np.int32), np.empty(nt, np.int32)
+        check(lib().samd_session_export(self._h, info, _ptr(link), _ptr(length), _ptr(minend),
+                                        _ptr(deg) if with_edges else None, _ptr(et) if with_edges else None,
+                                        _ptr(ed) if with_edges else None, _ptr(text), current_stream()))
+        keys = ("n_states", "n_edges", "n_text", "last", "max_length", "cur_index", "cur_length", "st_index", "st_length", "error")
+        out = dict(zip(keys, list(info)))
+        out.update(link=link, length=length, aux=minend, deg=deg, edge_tok=et, edge_dst=ed, text=text)
+        return out

@@ -1,0 +1,450 @@
+"""GPU parity of the suffix-automaton kernels (through the C ABI) against the CPU oracle and the
+golden fixtures produced by the reference.  Bit-exact: everything here is integer work."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import samd_hip
+from samd_hip import Params
+from oracle import sam_oracle as O
+from scripted_lm import ScriptedLM
+from util import markov_stream, split_edges, random_parents
+
+
+def dev(a, dtype=torch.int32):
+    return torch.as_tensor(np.asarray(a), dtype=dtype).cuda()
+
+
+def so_params(max_predicts=60, alpha=4.0, K=8, len_bias=0):
+    return Params(variant=0, max_predicts=max_predicts, alpha=alpha, K=K, len_bias=len_bias)
+
+
+def s_params(n_predicts=40, len_threshold=5, len_bias=5):
+    return Params(variant=1, max_predicts=64, alpha=4.0, K=8, len_bias=len_bias, n_predicts=n_predicts,
+                  len_threshold=len_threshold)
+
+
+def draft_tuple(d):
+    n, nl, md = d.n, d.n_leaves, d.max_depth
+    ret = np.asarray(d.retrieve[:nl * md]).reshape(nl, md).tolist()
+    mask = [[(d.mask[i] >> j) & 1 for j in range(n)] for i in range(n)]
+    return d.type, list(d.tokens[:n]), list(d.parent[:n]), list(d.position[:n]), mask, ret
+
+
+# --------------------------------------------------------------------------------------------------
+# static walk (batched, lane per stream)
+# --------------------------------------------------------------------------------------------------
+def test_static_walk_golden(golden):
+    for case in golden("sam_traces.json.gz")["static_so"]:
+        sam = samd_hip.StaticAutomaton.build(case["docs"], case["eos"], 0).upload()
+        q = case["query"]
+        cur = torch.zeros((1, 2), dtype=torch.int32, device="cuda")
+        trace = torch.zeros((len(q), 1, 2), dtype=torch.int32, device="cuda")
+        sam.walk(cur, dev(q).reshape(-1, 1), commit=True, trace=trace)
+        assert trace[:, 0].cpu().tolist() == case["walk"], case["name"]
+        assert cur[0].cpu().tolist() == case["walk"][-1]
+
+
+@pytest.mark.parametrize("vocab,B,T", [(6, 300, 40), (200, 1000, 64), (5000, 4096, 32)])
+def test_static_walk_batched_vs_oracle(vocab, B, T):
+    rng = np.random.default_rng(vocab)
+    docs = [markov_stream(rng, 300, vocab=vocab) for _ in range(30)] + [[i] for i in range(vocab)]
+    flat = np.concatenate([np.asarray(d) for d in docs[:30]])
+    prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    ora = O.StaticSAM.build(docs, 2)
+    toks = np.empty((T, B), np.int32)
+    for b in range(B):
+        p = int(rng.integers(0, len(flat) - T))
+        seq = flat[p:p + T].copy()
+        noise = rng.random(T) < 0.15
+        seq[noise] = rng.integers(0, vocab + 5, int(noise.sum()))       # incl. out-of-vocabulary ids
+        toks[:, b] = seq
+    cur = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    trace = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.walk(cur, dev(toks), commit=True, trace=trace)
+    cur2 = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    prod.walk(cur2, dev(toks), commit=True, visited=visited)
+    assert torch.equal(cur, cur2) and int(visited.item()) >= B * T
+    got = trace.cpu().numpy()
+    for b in range(0, B, max(1, B // 64)):
+        i, l = 0, 0
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[t, b]))
+            assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (b, t)
+    # lookup (commit=0) leaves the cursors alone
+    before = cur.clone()
+    prod.walk(cur, dev(toks), commit=False)
+    assert torch.equal(cur, before)
+
+
+def test_static_walk_empty_and_ragged():
+    prod = samd_hip.StaticAutomaton.build([[3, 4, 5, 3, 4, 6]], 2, 0).upload()
+    cur = torch.zeros((0, 2), dtype=torch.int32, device="cuda")
+    prod.walk(cur, torch.zeros((4, 0), dtype=torch.int32, device="cuda"))
+    cur = torch.zeros((3, 2), dtype=torch.int32, device="cuda")
+    prod.walk(cur, torch.zeros((0, 3), dtype=torch.int32, device="cuda"))
+    assert cur.abs().sum().item() == 0
+    # negative / huge token ids fall back to the root like an absent key
+    prod.walk(cur, dev([[3, -1, 10 ** 9], [4, 3, 3]]))
+    assert cur.cpu().tolist() == [[2, 2], [1, 1], [1, 1]]
+
+
+# --------------------------------------------------------------------------------------------------
+# dynamic automaton
+# --------------------------------------------------------------------------------------------------
+def check_dyn(sess, ora):
+    got, want = sess.export(), ora.export()
+    assert got["error"] == 0
+    for k in ("link", "length", "aux", "deg", "edge_tok", "edge_dst", "text"):       # edges in dict order
+        assert np.array_equal(got[k], want[k]), k
+    assert (got["cur_index"], got["cur_length"]) == ora.cursor()
+    assert (got["last"], got["max_length"]) == (ora.last, ora.max_length)
+
+
+def test_dyn_golden(golden):
+    for case in golden("sam_traces.json.gz")["dyn"]:
+        sess = samd_hip.Session(len(case["tokens"]) + 8)
+        ora = O.DynSAM()
+        toks, cuts = case["tokens"], case["cuts"]
+        out = torch.zeros(2, dtype=torch.int32, device="cuda")
+        for (a, b), cur, probes in zip(zip(cuts[:-1], cuts[1:]), case["cursors"], case["probes"]):
+            sess.add_tokens(dev(toks[a:b]))
+            ora.add_tokens(toks[a:b])
+            for t, pi, pl in probes:
+                sess.dyn_walk(dev([t]), 1, commit=False, d_out=out)
+                assert out.cpu().tolist() == [pi, pl]
+        check_dyn(sess, ora)
+        g = sess.export()
+        assert g["text"].tolist() == case["input_ids"]
+        assert g["link"].tolist() == case["table"]["link"] and g["aux"].tolist() == case["table"]["aux"]
+        assert [[list(e) for e in st] for st in split_edges(g)] == case["table"]["edges"]
+
+
+@pytest.mark.parametrize("vocab,n", [(3, 600), (5, 2048), (300, 2048), (32000, 1500)])
+def test_dyn_random_streams(vocab, n):
+    rng = np.random.default_rng(vocab + n)
+    toks = markov_stream(rng, n, vocab=max(vocab, 6)) if vocab > 5 else rng.integers(0, vocab, n).tolist()
+    sess = samd_hip.Session(n + 4)
+    ora = O.DynSAM()
+    pos = 0
+    while pos < n:
+        k = int(rng.integers(1, 64)) if pos else n // 2
+        sess.add_tokens(dev(toks[pos:pos + k]))
+        ora.add_tokens(toks[pos:pos + k])
+        pos += k
+    check_dyn(sess, ora)
+    # device-side count + reset
+    sess.reset()
+    ora.reset()
+    cnt = dev([100])
+    sess.add_tokens(dev(toks[:200]), n=200, d_n=cnt)
+    ora.add_tokens(toks[:100])
+    check_dyn(sess, ora)
+
+
+def test_dyn_capacity_is_reported_not_corrupted():
+    sess = samd_hip.Session(16)
+    sess.add_tokens(dev(list(range(3, 40))))
+    assert sess.export(with_edges=False)["error"] == -2
+
+
+# --------------------------------------------------------------------------------------------------
+# drafts + buffers
+# --------------------------------------------------------------------------------------------------
+def test_tree_buffers(golden):
+    g = golden("buffers.json.gz")
+    rng = np.random.default_rng(1)
+    cases = [(c["anc"], 0) for c in g["so"]]
+    cases += [(random_parents(rng, n, s), r) for n in (1, 5, 40, 64) for s in ("chain", "star", "bushy", "random") for r in (0, 1)]
+    for anc, rev in cases:
+        n = len(anc)
+        pos = torch.zeros(n, dtype=torch.int32, device="cuda")
+        mask = torch.zeros(n, dtype=torch.int64, device="cuda")
+        mb = torch.zeros((n, n), dtype=torch.uint8, device="cuda")
+        ret = torch.full((n * n,), -7, dtype=torch.int32, device="cuda")
+        shape = torch.zeros(2, dtype=torch.int32, device="cuda")
+        samd_hip.check(samd_hip.lib().samd_tree_buffers(samd_hip._ptr(dev(anc)), n, rev, samd_hip._ptr(pos), samd_hip._ptr(mask),
+                                                        samd_hip._ptr(mb), samd_hip._ptr(ret), samd_hip._ptr(shape),
+                                                        samd_hip.current_stream()))
+        want = O.gen_buffers(anc)
+        nl, md = shape.cpu().tolist()
+        assert pos.cpu().tolist() == want["tree_position_ids"][0].tolist()
+        assert mb.cpu().numpy().astype(bool).tolist() == want["tree_attn_mask"][0, 0].tolist()
+        m64 = mask.cpu().numpy().astype(np.uint64)
+        assert [[int(m64[i] >> np.uint64(j)) & 1 for j in range(n)] for i in range(n)] == want["tree_attn_mask"][0, 0].astype(int).tolist()
+        wr = want["tree_retrieve_indices"]
+        got = ret[:nl * md].reshape(nl, md).cpu().numpy()
+        assert got.tolist() == (wr[::-1] if rev else wr).tolist()
+    tr = g["token_recycle"][0]
+    want = O.tr_gen_buffers(tr["tree"])
+    assert want["tree_retrieve_indices"].tolist() == tr["retrieve"]
+
+
+def test_drafts_golden(golden):
+    g = golden("drafts.json.gz")
+    for case in g["dyn_so"]:
+        sess = samd_hip.Session(len(case["tokens"]) + 8)
+        sess.add_tokens(dev(case["tokens"]))
+        p = so_params(case["max_predicts"], case["alpha"])
+        for c in case["cases"]:
+            sess.draft_seq(p, c["index"], c["match"], c["start"])
+            ty, toks, par, pos, mask, ret = draft_tuple(sess.read_draft())
+            assert ty == 0 and toks == c["seq"] and pos == c["pos"][0]
+            assert par == [i - 1 for i in range(len(toks))] and ret == [list(range(len(toks)))]
+    for case in g["dyn_s"]:
+        sess = samd_hip.Session(len(case["tokens"]) + 8)
+        sess.add_tokens(dev(case["tokens"]))
+        p = s_params(case["n_predicts"])
+        for c in case["cases"]:
+            sess.draft_fixed(None, p, 0, c["index"], c["start"])
+            assert draft_tuple(sess.read_draft())[1] == c["seq"]
+    corp_s = {c["name"]: c for c in golden("sam_traces.json.gz")["static_s"]}
+    for case in g["static_s"]:
+        sam = samd_hip.StaticAutomaton.build(corp_s[case["name"]]["docs"], corp_s[case["name"]]["eos"], 1).upload()
+        sess = samd_hip.Session(64)
+        p = s_params(case["n_predicts"])
+        for c in case["cases"]:
+            sess.draft_fixed(sam, p, 1, c["index"], c["start"])
+            assert draft_tuple(sess.read_draft())[1] == c["seq"]
+    corp = {c["name"]: c for c in golden("sam_traces.json.gz")["static_so"]}
+    n_tree = 0
+    for case in g["tree"]:
+        sam = samd_hip.StaticAutomaton.build(corp[case["name"]]["docs"], corp[case["name"]]["eos"], 0).upload()
+        sess = samd_hip.Session(64)
+        p = so_params(case["max_predicts"], case["alpha"], case["K"])
+        for c in case["cases"]:
+            sess.draft_tree(sam, p, c["index"], c["match"], c["start"])
+            ty, toks, par, pos, mask, ret = draft_tuple(sess.read_draft())
+            assert ty == 1 and toks == c["tree"] and par == c["anc"], (case["name"], c)
+            want = O.gen_buffers(c["anc"])
+            assert ret == want["tree_retrieve_indices"].tolist() and pos == want["tree_position_ids"][0].tolist()
+            n_tree += 1
+    assert n_tree > 50
+
+
+def test_draft_model_golden_so(golden):
+    for case in golden("draft_model.json.gz")["so"]:
+        sam = samd_hip.StaticAutomaton.build(case["docs"], case["eos"], 0).upload()
+        sess = samd_hip.Session(512)
+        p = so_params(case["max_predicts"], case["alpha"], case["K"], case["len_bias"])
+        sess.add_tokens(dev(case["prompt"]))
+        sess.static_walk(sam, dev(case["prompt"]), len(case["prompt"]), commit=True)
+        for s in case["steps"]:
+            sess.draft(sam, p, dev([s["start"]]))
+            ty, toks, par, pos, mask, ret = draft_tuple(sess.read_draft())
+            assert ("sequence", "tree")[ty] == s["type"] and toks == s["tokens"]
+            if ty == 1:
+                assert [pos] == s["pos"] and ret == s["retrieve"] and mask == s["mask"]
+            acc = dev(s["accepted"])
+            sess.add_tokens(acc)
+            sess.static_walk(sam, acc, len(s["accepted"]), commit=True)
+            e = sess.export(with_edges=False)
+            assert [e["cur_index"], e["cur_length"], e["st_index"], e["st_length"]] == s["cursors"]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_draft_model_random_vs_oracle(seed):
+    """bigger automata, long drafts (max_predicts 60), ties in counts: product DraftModel.lookup == oracle."""
+    rng = np.random.default_rng(seed)
+    V = 64
+    docs = [markov_stream(rng, 400, vocab=V, succ=3, noise=0.03) for _ in range(40)] + [[i] for i in range(V)]
+    flat = [t for d in docs[:40] for t in d]
+    sam = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    st = O.StaticSAM.build(docs, 2)
+    od = O.DraftModel(60, 4.0, 8, int(seed), sam_static=st)
+    p = so_params(60, 4.0, 8, int(seed))
+    sess = samd_hip.Session(2048)
+    q = int(rng.integers(0, len(flat) - 600))
+    prompt = flat[q:q + 120] + flat[q + 30:q + 90]
+    od.reset(); od.update(prompt)
+    sess.add_tokens(dev(prompt)); sess.static_walk(sam, dev(prompt), len(prompt), commit=True)
+    kinds = [0, 0]
+    for step in range(120):
+        start = flat[q + 120 + step] if step % 5 else int(rng.integers(3, V))
+        ty, toks, anc = od.lookup_raw(start)
+        sess.draft(sam, p, dev([start]))
+        d = sess.read_draft()
+        assert (d.type, list(d.tokens[:d.n]), list(d.parent[:d.n])) == (ty, toks, anc), step
+        kinds[ty] += 1
+        a = int(rng.integers(1, min(5, len(toks)) + 1))
+        acc = toks[:a] if ty == 0 else [toks[0]] + [int(rng.integers(3, V)) for _ in range(a - 1)]
+        od.update(acc)
+        sess.add_tokens(dev(acc)); sess.static_walk(sam, dev(acc), a, commit=True)
+    assert min(kinds) > 5, kinds
+
+
+def test_draft_model_golden_s(golden):
+    tr_tree = golden("buffers.json.gz")["token_recycle"][0]["tree"]
+    off = np.zeros(len(tr_tree) + 1, np.int32); off[1:] = np.cumsum([len(c) for c in tr_tree])
+    ch = np.asarray([c for cs in tr_tree for c in cs], np.int32)
+    for case in golden("draft_model.json.gz")["s"]:
+        V = case["vocab"]
+        sam = samd_hip.StaticAutomaton.build(case["docs"], case["eos"], 1).upload() if case["use_static"] else None
+        sess = samd_hip.Session(512)
+        p = s_params(case["n_predicts"], case["len_threshold"], case["len_bias"])
+        h = samd_hip.C.c_void_p()
+        samd_hip.check(samd_hip.lib().samd_recycle_create(V, samd_hip._ptr(off), samd_hip._ptr(ch), len(tr_tree), samd_hip.C.byref(h)))
+        def tr_update(tokens, logits):
+            lg = torch.tensor(logits, dtype=torch.float32, device="cuda")
+            samd_hip.check(samd_hip.lib().samd_recycle_update(h, samd_hip._ptr(dev(tokens)), samd_hip._ptr(lg), samd_hip.F32, len(tokens),
+                                                              None, V, V, samd_hip.current_stream()))
+        pr = dev(case["prompt"])
+        sess.add_tokens(pr)
+        sess.static_walk(sam, pr, len(case["prompt"]), commit=True)
+        tr_update(case["prompt"], case["prompt_logits"])
+        for s in case["steps"]:
+            st = dev([s["start"]])
+            sess.draft(sam, p, st)
+            d = sess.read_draft()
+            if d.type == 2:
+                out = torch.zeros(len(tr_tree), dtype=torch.int32, device="cuda")
+                samd_hip.check(samd_hip.lib().samd_recycle_draft(h, samd_hip._ptr(st), samd_hip._ptr(out), samd_hip.current_stream()))
+                ty, toks = "tree", out.cpu().tolist()
+            else:
+                ty, toks = "sequence", list(d.tokens[:d.n])
+            assert ty == s["type"] and toks == s["tokens"]
+            acc = dev(s["accepted"])
+            sess.add_tokens(acc)
+            sess.static_walk(sam, acc, len(s["accepted"]), commit=True)
+            tr_update(toks, s["logits"])
+        samd_hip.lib().samd_recycle_free(h)
+
+
+def test_token_recycle_golden(golden):
+    for case in golden("token_recycle.json.gz"):
+        tree, V = case["tree"], case["vocab"]
+        off = np.zeros(len(tree) + 1, np.int32); off[1:] = np.cumsum([len(c) for c in tree])
+        ch = np.asarray([c for cs in tree for c in cs] or [0], np.int32)
+        h = samd_hip.C.c_void_p()
+        samd_hip.check(samd_hip.lib().samd_recycle_create(V, samd_hip._ptr(off), samd_hip._ptr(ch), len(tree), samd_hip.C.byref(h)))
+        ora = O.TokenRecycle(tree, V)
+        for r in case["rounds"]:
+            for dt in (torch.float32, torch.float16):
+                lg = torch.tensor(r["logits"], dtype=torch.float32, device="cuda").to(dt)
+                samd_hip.check(samd_hip.lib().samd_recycle_update(h, samd_hip._ptr(dev(r["tree_tokens"])), samd_hip._ptr(lg),
+                                                                  samd_hip.torch_dtype_code(dt), len(r["tree_tokens"]), None, V, V,
+                                                                  samd_hip.current_stream()))
+            ora.update(r["tree_tokens"], O.topk8_rows(np.asarray(r["logits"], np.float32)))
+            for start, draft in r["drafts"]:
+                out = torch.zeros(len(tree), dtype=torch.int32, device="cuda")
+                samd_hip.check(samd_hip.lib().samd_recycle_draft(h, samd_hip._ptr(dev([start])), samd_hip._ptr(out), samd_hip.current_stream()))
+                assert out.cpu().tolist() == draft
+            tab = np.zeros((V, 8), np.int32); pres = np.zeros(V, np.uint8)
+            samd_hip.check(samd_hip.lib().samd_recycle_export(h, samd_hip._ptr(tab), samd_hip._ptr(pres), samd_hip.current_stream()))
+            assert np.array_equal(pres, ora.present) and np.array_equal(tab[pres > 0], ora.table[ora.present > 0])
+        samd_hip.lib().samd_recycle_free(h)
+
+
+# --------------------------------------------------------------------------------------------------
+# posterior / accept
+# --------------------------------------------------------------------------------------------------
+def test_accept_golden(golden):
+    sess = samd_hip.Session(64)
+    for c in golden("posterior.json.gz"):
+        logits = torch.tensor(c["logits"], dtype=torch.float32, device="cuda")
+        n = len(c["tokens"])
+        am = torch.zeros(n, dtype=torch.int32, device="cuda")
+        samd_hip.check(samd_hip.lib().samd_argmax_rows(samd_hip._ptr(logits), samd_hip.F32, n, logits.shape[1], logits.shape[1], None,
+                                                       samd_hip._ptr(am), samd_hip.current_stream()))
+        assert am.cpu().tolist() == O.argmax_rows(np.asarray(c["logits"], np.float32)).tolist()
+        sess.set_draft(dev(c["tokens"]), dev(c["anc"]), n, type_=0 if c["type"] == "sequence" else 1)
+        sess.accept(am)
+        v = sess.read_verdict()
+        assert (v.best, v.accept) == (c["best"], c["accept"])
+        assert list(v.tokens[:v.accept]) == c["accepted_tokens"]
+        assert v.next_token == c["next_argmax"]
+        if c["type"] == "tree":
+            assert list(v.kv_index[:v.accept]) == c["accepted_indices"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,vocab", [(1, 32000), (60, 32000), (64, 128256), (7, 1003)])
+def test_argmax_rows(dtype, rows, vocab):
+    g = torch.Generator(device="cuda").manual_seed(rows * vocab)
+    x = torch.randn((rows, vocab), generator=g, device="cuda", dtype=torch.float32).to(dtype)
+    x[0, 5] = x[0, vocab - 1] = 100.0          # exact tie: first index wins
+    if rows > 1:
+        x[1, :] = 0.0                           # all equal -> 0
+    out = torch.full((rows,), -1, dtype=torch.int32, device="cuda")
+    samd_hip.check(samd_hip.lib().samd_argmax_rows(samd_hip._ptr(x), samd_hip.torch_dtype_code(dtype), rows, vocab, vocab, None,
+                                                   samd_hip._ptr(out), samd_hip.current_stream()))
+    want = O.argmax_rows(x.float().cpu().numpy())
+    assert out.cpu().tolist() == want.tolist()
+    assert out[0].item() == 5
+    # device-side row count
+    cnt = dev([max(1, rows // 2)])
+    out2 = torch.full((rows,), -1, dtype=torch.int32, device="cuda")
+    samd_hip.check(samd_hip.lib().samd_argmax_rows(samd_hip._ptr(x), samd_hip.torch_dtype_code(dtype), rows, vocab, vocab, samd_hip._ptr(cnt),
+                                                   samd_hip._ptr(out2), samd_hip.current_stream()))
+    k = max(1, rows // 2)
+    assert out2[:k].cpu().tolist() == want[:k].tolist() and (out2[k:] == -1).all()
+
+
+# --------------------------------------------------------------------------------------------------
+# whole loop: prefill + fused step kernel, scripted LM, vs the reference's recorded traces
+# --------------------------------------------------------------------------------------------------
+def run_device_loop(case, fused):
+    lm = ScriptedLM(case["target"], case["vocab"])
+    sam = samd_hip.StaticAutomaton.build(case["docs"], case["eos"], 0).upload()
+    sess = samd_hip.Session(case["max_cache_len"] + 64)
+    p = so_params(case["max_predicts"], case["alpha"], case["K"], case["len_bias"])
+    prompt = case["prompt"]
+    ids = list(prompt)
+    sess.reset()
+    pr = dev(prompt)
+    sess.add_tokens(pr)
+    sess.static_walk(sam, pr, len(prompt), commit=True)
+    start = int(np.argmax(lm.logits([], prompt, [i - 1 for i in range(len(prompt))])[-1]))
+    sess.draft(sam, p, dev([start]))
+    dt, ds, acc_list, trace = 0, 0, [], []
+    for _ in range(case["max_new_tokens"]):
+        if len(prompt) + dt + case["max_predicts"] >= case["max_cache_len"]:
+            break
+        d = sess.read_draft()
+        toks, anc = list(d.tokens[:d.n]), list(d.parent[:d.n])
+        logits = torch.from_numpy(lm.logits(ids, toks, anc)).cuda().half()
+        am = torch.zeros(d.n, dtype=torch.int32, device="cuda")
+        samd_hip.check(samd_hip.lib().samd_argmax_rows(samd_hip._ptr(logits), samd_hip.F16, d.n, logits.shape[1], logits.shape[1], None,
+                                                       samd_hip._ptr(am), samd_hip.current_stream()))
+        if fused:
+            sess.step(sam, p, am)
+        else:
+            sess.accept(am)
+            sess.commit(sam)
+            sess.draft(sam, p, samd_hip.C.c_void_p(sess.device_views()["start_token"]))
+        v = sess.read_verdict()
+        new = list(v.tokens[:v.accept])
+        full = list(new)
+        stop = False
+        if case["eos"] in new:
+            new = new[:new.index(case["eos"]) + 1]
+            stop = True
+        ids.extend(new)
+        ds += 1; dt += len(new); acc_list.append(len(new))
+        trace.append({"type": "sequence" if d.type == 0 else "tree", "tokens": toks, "anc": anc, "best": v.best, "accept": v.accept,
+                      "accepted": full, "kv_indices": None if d.type == 0 else list(v.kv_index[:v.accept]),
+                      "node_argmax": am.cpu().tolist()})
+        if stop or dt >= case["max_new_tokens"]:
+            break
+    e = sess.export(with_edges=False)
+    assert e["error"] == 0
+    return {"output_ids": ids[:len(prompt) + case["max_new_tokens"]], "decode_tokens": dt, "decode_steps": ds,
+            "accept_lengths": acc_list, "trace": trace}, e
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_loop_so_golden(golden, fused):
+    for case in golden("loop_so.json.gz"):
+        got, e = run_device_loop(case, fused)
+        for k in ("output_ids", "decode_tokens", "decode_steps", "accept_lengths"):
+            assert got[k] == case[k], k
+        for gt, wt in zip(got["trace"], case["trace"]):
+            assert gt == wt
+        assert got["output_ids"] == case["target"][:len(got["output_ids"])]      # lossless
+        # the dynamic automaton's text is exactly prompt + every committed (untruncated) token
+        committed = case["prompt"] + [t for st in case["trace"] for t in st["accepted"]]
+        assert e["n_text"] - 1 == len(committed)

@@ -1,0 +1,41 @@
+"""helpers shared by the parity tests (numpy only; no oracle / product imports at module level)."""
+import numpy as np
+
+
+def markov_stream(rng, n, vocab=200, succ=3, noise=0.05):
+    table = {}
+    out = [int(rng.integers(3, vocab)), int(rng.integers(3, vocab))]
+    w = np.array([1.0 / (i + 1) for i in range(succ)])
+    w = w / w.sum()
+    while len(out) < n:
+        key = (out[-2], out[-1])
+        if key not in table:
+            table[key] = rng.integers(3, vocab, succ).tolist()
+        if rng.random() < noise:
+            out.append(int(rng.integers(3, vocab)))
+        else:
+            out.append(int(table[key][rng.choice(succ, p=w)]))
+    return out
+
+
+def split_edges(tab):
+    """export dict -> per-state list of (tok,dst) in stored order"""
+    out, k = [], 0
+    for d in tab["deg"]:
+        out.append(list(zip(tab["edge_tok"][k:k + d].tolist(), tab["edge_dst"][k:k + d].tolist())))
+        k += d
+    return out
+
+
+def random_parents(rng, n, shape):
+    anc = [-1]
+    for i in range(1, n):
+        if shape == "chain":
+            anc.append(i - 1)
+        elif shape == "star":
+            anc.append(0)
+        elif shape == "bushy":
+            anc.append(int(rng.integers(max(0, i - 4), i)))
+        else:
+            anc.append(int(rng.integers(0, i)))
+    return anc
