@@ -246,6 +246,25 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                         const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- memory-bound glue of the verify forward (between the library GEMMs).  The arithmetic of the
+ * forward lives in HuggingFace transformers in the reference (third party, not vendored; call sites
+ * SO/samd_model.py:102-106 and :134-138); these follow LlamaDecoderLayer's operators and take every
+ * dynamic scalar from device memory so that one decode step is graph-capturable. ---- */
+/* hidden = embed_tokens(input_ids) */
+int samd_embed_rows(const int32_t *d_tokens, const void *d_table, void *d_out, int32_t rows, int32_t hidden, int32_t vocab,
+                    int32_t dtype, void *stream);
+/* LlamaRMSNorm; if d_delta != NULL first x += delta (residual add) and store x back */
+int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_out, int32_t rows, int32_t hidden, float eps,
+                 int32_t dtype, void *stream);
+/* rotary embedding of q,k at positions L + rel_pos[r] (SO/samd_model.py:127-132) and
+ * SamdStaticCache.update (SO/cache.py:103-115): K/V rows written at [L, L+n).  d_qkv [rows][(H+2Hkv)*D]. */
+int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                       const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
+                       int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
+                       void *stream);
+/* LlamaMLP activation: silu(gate) * up with gate|up concatenated per row */
+int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Token Recycle (S/tree_model/token_recycle/token_recycle.py:18-63)
  * ---------------------------------------------------------------------------------------------- */

@@ -1,0 +1,173 @@
+// lm_kernels.hip -- the memory-bound glue of the verify forward between the library GEMMs:
+// token embedding gather, RMSNorm (+ fused residual add), RoPE + KV-cache row write at a device-side
+// offset, SiLU*up.  They take every dynamic scalar (cache length L, draft size n, positions) from
+// device memory so that a whole decode step is capturable in one hipGraph without host round trips.
+// Reference semantics: HF LlamaDecoderLayer as driven by samd_sam_only/samd_model.py:134-138 with
+// SamdStaticCache.update (samd_sam_only/cache.py:103-115) writing K/V at [cache_length, +n).
+#include <hip/hip_runtime.h>
+#include "samd_common.h"
+
+#define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
+
+template <typename T> struct Vec8 { T v[8]; };
+
+template <typename T> __device__ __forceinline__ Vec8<T> ld8(const T *p) {
+    const uint4 raw = *reinterpret_cast<const uint4 *>(p);
+    return __builtin_bit_cast(Vec8<T>, raw);
+}
+template <typename T> __device__ __forceinline__ void st8(T *p, const Vec8<T> &x) {
+    *reinterpret_cast<uint4 *>(p) = __builtin_bit_cast(uint4, x);
+}
+
+__device__ __forceinline__ float block_sum(float v, float *smem) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if ((threadIdx.x & 63) == 0) smem[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < nw; k++) t += smem[k];
+    __syncthreads();
+    return t;
+}
+
+// out[r] = table[tokens[r]]
+template <typename T>
+__global__ __launch_bounds__(256) void k_embed_rows(const int *__restrict__ tokens, const T *__restrict__ table, T *__restrict__ out,
+                                                    int hidden, int vocab) {
+    const int r = blockIdx.x;
+    int t = tokens[r]; t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+    const T *src = table + (size_t)t * hidden;
+    T *dst = out + (size_t)r * hidden;
+    for (int c = threadIdx.x * 8; c < hidden; c += blockDim.x * 8) st8(dst + c, ld8(src + c));
+}
+
+// HF LlamaRMSNorm: out = w * (x * rsqrt(mean(x^2) + eps)).to(dtype); optional fused residual add:
+// x <- x + delta first (stored back), as LlamaDecoderLayer does between its two halves.
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void k_rmsnorm(T *__restrict__ x, const T *__restrict__ delta, const T *__restrict__ w,
+                                                 T *__restrict__ out, int hidden, float eps) {
+    __shared__ float red[4];
+    const size_t base = (size_t)blockIdx.x * hidden;
+    float ss = 0.f;
+    for (int c = threadIdx.x * 8; c < hidden; c += blockDim.x * 8) {
+        Vec8<T> a = ld8(x + base + c);
+        if (ADD) {
+            const Vec8<T> d = ld8(delta + base + c);
+#pragma unroll
+            for (int j = 0; j < 8; j++) a.v[j] = (T)((float)a.v[j] + (float)d.v[j]);
+            st8(x + base + c, a);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float f = (float)a.v[j]; ss += f * f; }
+    }
+    const float tot = block_sum(ss, red);
+    const float rs = rsqrtf(tot / (float)hidden + eps);
+    for (int c = threadIdx.x * 8; c < hidden; c += blockDim.x * 8) {
+        const Vec8<T> a = ld8(x + base + c), ww = ld8(w + c);
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const T h = (T)((float)a.v[j] * rs); o.v[j] = (T)((float)ww.v[j] * (float)h); }
+        st8(out + base + c, o);
+    }
+}
+
+// RoPE (HF rotate_half convention, cos/sin tables fp32 [max_pos][D/2]) on q and k, then
+//   q_out[r][h][:]            <- rotated q
+//   k_cache[kvh][L + r][:]    <- rotated k        (SamdStaticCache.update, cache.py:106-109)
+//   v_cache[kvh][L + r][:]    <- v
+// position of row r = L + rel_pos[r] (tree depth or sequence offset; samd_model.py:127-132).
+// grid = (rows, H + 2*Hkv), block = D/2 threads; rows >= *d_n are skipped.
+template <typename T>
+__global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel_pos, const int *__restrict__ d_L,
+                          const int *__restrict__ d_n, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                          T *__restrict__ q_out, T *__restrict__ k_cache, T *__restrict__ v_cache, int H, int Hkv, int D,
+                          long long max_len, int max_pos) {
+    const int r = blockIdx.x, hh = blockIdx.y, j = threadIdx.x, half = D >> 1;
+    if (r >= d_n[0]) return;
+    const int L = d_L[0];
+    const T *src = qkv + ((size_t)r * (H + 2 * Hkv) + hh) * D;
+    if (hh >= H + Hkv) {                                       // V: plain copy
+        T *dst = v_cache + ((size_t)(hh - H - Hkv) * max_len + L + r) * D;
+        dst[j] = src[j]; dst[j + half] = src[j + half];
+        return;
+    }
+    int pos = L + rel_pos[r]; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+    const float c = cos_t[(size_t)pos * half + j], s = sin_t[(size_t)pos * half + j];
+    const float x1 = (float)src[j], x2 = (float)src[j + half];
+    const T o1 = (T)(x1 * c - x2 * s), o2 = (T)(x2 * c + x1 * s);
+    T *dst = hh < H ? q_out + ((size_t)r * H + hh) * D : k_cache + ((size_t)(hh - H) * max_len + L + r) * D;
+    dst[j] = o1; dst[j + half] = o2;
+}
+
+// out = silu(gate) * up, gate|up concatenated per row: gu[r] = [gate(I) | up(I)]
+template <typename T>
+__global__ __launch_bounds__(256) void k_silu_mul(const T *__restrict__ gu, T *__restrict__ out, int inter) {
+    const size_t r = blockIdx.y;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (c >= inter) return;
+    const Vec8<T> g = ld8(gu + r * 2 * inter + c), u = ld8(gu + r * 2 * inter + inter + c);
+    Vec8<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float gf = (float)g.v[j];
+        const T s = (T)(gf / (1.f + __expf(-gf)));
+        o.v[j] = (T)((float)s * (float)u.v[j]);
+    }
+    st8(out + r * inter + c, o);
+}
+
+extern "C" {
+
+int samd_embed_rows(const int32_t *d_tokens, const void *d_table, void *d_out, int32_t rows, int32_t hidden, int32_t vocab,
+                    int32_t dtype, void *stream) {
+    if (!d_tokens || !d_table || !d_out || rows < 1 || hidden % 8 != 0) { samd_set_error("samd_embed_rows: invalid argument"); return SAMD_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_embed_rows<_Float16>, dim3(rows), dim3(256), 0, st, d_tokens, (const _Float16 *)d_table, (_Float16 *)d_out, hidden, vocab);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_embed_rows<__bf16>, dim3(rows), dim3(256), 0, st, d_tokens, (const __bf16 *)d_table, (__bf16 *)d_out, hidden, vocab);
+    else { samd_set_error("samd_embed_rows: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_out, int32_t rows, int32_t hidden, float eps,
+                 int32_t dtype, void *stream) {
+    if (!d_x || !d_weight || !d_out || rows < 1 || hidden % 8 != 0) { samd_set_error("samd_rmsnorm: invalid argument"); return SAMD_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAMD_F16) {
+        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<_Float16, true>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)d_delta, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps);
+        else hipLaunchKernelGGL((k_rmsnorm<_Float16, false>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)nullptr, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps);
+    } else if (dtype == SAMD_BF16) {
+        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<__bf16, true>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)d_delta, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps);
+        else hipLaunchKernelGGL((k_rmsnorm<__bf16, false>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)nullptr, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps);
+    } else { samd_set_error("samd_rmsnorm: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                       const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
+                       int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
+                       void *stream) {
+    if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || !d_cos || !d_sin || !d_q_out || !d_k_cache || !d_v_cache || rows < 1 ||
+        head_dim % 2 != 0 || head_dim > 2048) { samd_set_error("samd_rope_kv_write: invalid argument"); return SAMD_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(rows, n_heads + 2 * n_kv_heads), block(head_dim / 2);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos);
+    else { samd_set_error("samd_rope_kv_write: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, void *stream) {
+    if (!d_gate_up || !d_out || rows < 1 || inter % 8 != 0) { samd_set_error("samd_silu_mul: invalid argument"); return SAMD_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((inter / 8 + 255) / 256, rows), block(256);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_silu_mul<_Float16>, grid, block, 0, st, (const _Float16 *)d_gate_up, (_Float16 *)d_out, inter);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_silu_mul<__bf16>, grid, block, 0, st, (const __bf16 *)d_gate_up, (__bf16 *)d_out, inter);
+    else { samd_set_error("samd_silu_mul: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+}  // extern "C"

@@ -221,8 +221,9 @@ int samd_device_info(int64_t out[4]) {
 
 int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
                      int32_t commit, int32_t *d_trace, void *stream) {
-    if (!sam || !sam->uploaded || !d_cursors || !d_tokens || B < 0 || T < 0) { samd_set_error("samd_static_walk: invalid argument"); return SAMD_E_INVALID; }
-    if (B == 0 || T == 0) return SAMD_OK;
+    if (!sam || !sam->uploaded || B < 0 || T < 0) { samd_set_error("samd_static_walk: invalid argument"); return SAMD_E_INVALID; }
+    if (B == 0 || T == 0) return SAMD_OK;                 // empty batch / no tokens: nothing to do
+    if (!d_cursors || !d_tokens) { samd_set_error("samd_static_walk: null pointer"); return SAMD_E_INVALID; }
     const int threads = 256, blocks = (B + threads - 1) / threads;
     hipLaunchKernelGGL(k_static_walk, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, static_view(sam), d_cursors, d_tokens,
                        B, T, commit, d_trace, (unsigned long long *)nullptr);

@@ -89,6 +89,10 @@ _PROTOS = {
     "samd_tree_attention_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_tree_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
                                       _VP, _I64, _VP]),
+    "samd_embed_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "samd_rmsnorm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _VP]),
+    "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
+    "samd_silu_mul": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_recycle_create": (C.c_int, [_I32, _VP, _VP, _I32, _VP]),
     "samd_recycle_free": (None, [_VP]),
     "samd_recycle_update": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _I64, _I64, _VP]),
@@ -132,6 +136,8 @@ def _ptr(a):
     """host numpy array or torch tensor or int -> void*"""
     if a is None:
         return None
+    if isinstance(a, C.c_void_p):
+        return a
     if isinstance(a, np.ndarray):
         return a.ctypes.data_as(C.c_void_p)
     if hasattr(a, "data_ptr"):

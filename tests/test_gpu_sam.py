@@ -234,7 +234,8 @@ def test_draft_model_golden_so(golden):
         sess.add_tokens(dev(case["prompt"]))
         sess.static_walk(sam, dev(case["prompt"]), len(case["prompt"]), commit=True)
         for s in case["steps"]:
-            sess.draft(sam, p, dev([s["start"]]))
+            d_start = dev([s["start"]])
+            sess.draft(sam, p, d_start)
             ty, toks, par, pos, mask, ret = draft_tuple(sess.read_draft())
             assert ("sequence", "tree")[ty] == s["type"] and toks == s["tokens"]
             if ty == 1:
@@ -258,22 +259,37 @@ def test_draft_model_random_vs_oracle(seed):
     od = O.DraftModel(60, 4.0, 8, int(seed), sam_static=st)
     p = so_params(60, 4.0, 8, int(seed))
     sess = samd_hip.Session(2048)
-    q = int(rng.integers(0, len(flat) - 600))
+    q = int(rng.integers(0, len(flat) - 1200))
     prompt = flat[q:q + 120] + flat[q + 30:q + 90]
     od.reset(); od.update(prompt)
-    sess.add_tokens(dev(prompt)); sess.static_walk(sam, dev(prompt), len(prompt), commit=True)
-    kinds = [0, 0]
+    d_prompt = dev(prompt)
+    sess.add_tokens(d_prompt); sess.static_walk(sam, d_prompt, len(prompt), commit=True)
+    # the "true" text that gets committed: fresh corpus spans (static matches) and prompt repeats (dyn matches)
+    text = []
+    while len(text) < 700:
+        if rng.random() < 0.6:
+            r = int(rng.integers(0, len(flat) - 80)); text += flat[r:r + int(rng.integers(8, 60))]
+        else:
+            r = int(rng.integers(0, len(prompt) - 20)); text += prompt[r:r + int(rng.integers(4, 20))]
+        if rng.random() < 0.3:
+            text += rng.integers(3, V, 2).tolist()
+    kinds, pos = [0, 0], 0
     for step in range(120):
-        start = flat[q + 120 + step] if step % 5 else int(rng.integers(3, V))
+        start = text[pos]
         ty, toks, anc = od.lookup_raw(start)
-        sess.draft(sam, p, dev([start]))
+        d_start = dev([start])
+        sess.draft(sam, p, d_start)
         d = sess.read_draft()
         assert (d.type, list(d.tokens[:d.n]), list(d.parent[:d.n])) == (ty, toks, anc), step
+        want = O.gen_buffers(anc)
+        assert np.asarray(d.retrieve[:d.n_leaves * d.max_depth]).reshape(d.n_leaves, d.max_depth).tolist() == want["tree_retrieve_indices"].tolist()
         kinds[ty] += 1
-        a = int(rng.integers(1, min(5, len(toks)) + 1))
-        acc = toks[:a] if ty == 0 else [toks[0]] + [int(rng.integers(3, V)) for _ in range(a - 1)]
+        a = int(rng.integers(1, 6))
+        acc = text[pos:pos + a]
+        pos += a
         od.update(acc)
-        sess.add_tokens(dev(acc)); sess.static_walk(sam, dev(acc), a, commit=True)
+        d_acc = dev(acc)
+        sess.add_tokens(d_acc); sess.static_walk(sam, d_acc, a, commit=True)
     assert min(kinds) > 5, kinds
 
 
@@ -399,7 +415,8 @@ def run_device_loop(case, fused):
     sess.add_tokens(pr)
     sess.static_walk(sam, pr, len(prompt), commit=True)
     start = int(np.argmax(lm.logits([], prompt, [i - 1 for i in range(len(prompt))])[-1]))
-    sess.draft(sam, p, dev([start]))
+    d_start = dev([start])
+    sess.draft(sam, p, d_start)
     dt, ds, acc_list, trace = 0, 0, [], []
     for _ in range(case["max_new_tokens"]):
         if len(prompt) + dt + case["max_predicts"] >= case["max_cache_len"]:
@@ -415,7 +432,7 @@ def run_device_loop(case, fused):
         else:
             sess.accept(am)
             sess.commit(sam)
-            sess.draft(sam, p, samd_hip.C.c_void_p(sess.device_views()["start_token"]))
+            sess.draft(sam, p, sess.device_views()["start_token"])
         v = sess.read_verdict()
         new = list(v.tokens[:v.accept])
         full = list(new)

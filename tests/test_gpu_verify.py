@@ -99,9 +99,10 @@ def test_tree_attention(dtype, tol, H, Hkv, L, n, shape):
     ws_bytes = samd_hip.lib().samd_tree_attention_workspace(n_pad, H, D)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
     scale = 1.0 / math.sqrt(D)
+    d_L, d_n = dev([L]), dev([n])              # device-side scalars (kept alive across the launch)
     samd_hip.check(samd_hip.lib().samd_tree_attention(samd_hip._ptr(q), samd_hip._ptr(k_cache), samd_hip._ptr(v_cache), samd_hip._ptr(out),
                                                       samd_hip.torch_dtype_code(dtype), n_pad, H, Hkv, D, max_len, samd_hip._ptr(mask),
-                                                      samd_hip._ptr(dev([L])), samd_hip._ptr(dev([n])), scale, samd_hip._ptr(ws), ws_bytes,
+                                                      samd_hip._ptr(d_L), samd_hip._ptr(d_n), scale, samd_hip._ptr(ws), ws_bytes,
                                                       samd_hip.current_stream()))
     want = reference_attention(q, k_cache, v_cache, L, n, mask_rows, scale)
     got = out[:n].float()
