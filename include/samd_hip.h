@@ -34,6 +34,16 @@ extern "C" {
 #define SAMD_MAX_DRAFT 64     /* a draft (sequence or tree) holds at most 64 nodes: one wavefront, one u64 mask row */
 #define SAMD_TOPK 8           /* SO/sam/static_sam.py:137 keeps 8 successors per state */
 
+/* per-step report block (int32 words) copied to the host by samd_session_report_async:
+ * what SamdModel.decode/update_state/generate read back per step (SO/samd_model.py:158-174, :216-235) */
+#define SAMD_REP_DMETA 0      /* [16] type, n, n_leaves, max_depth, index_dyn, match_dyn, index_static, match_static, ... */
+#define SAMD_REP_VERDICT 16   /* [8]  best, accept, next_node, next_token, kv_start, is_tree */
+#define SAMD_REP_TOKENS 24    /* [64] candidate_tokens[best][:accept] */
+#define SAMD_REP_KVINDEX 88   /* [64] retrieve[best][:accept] */
+#define SAMD_REP_COUNTERS 152 /* [8]  steps, tokens, sequence steps, tree steps */
+#define SAMD_REP_META 160     /* [16] n_states, n_edges, n_text, last, max_length, cursors, error flag */
+#define SAMD_REPORT_INTS 176
+
 /* automaton flavours */
 #define SAMD_KIND_COUNT 0     /* samd_sam_only StaticSAM: cnt_endpos + top-k (SO/sam/static_sam.py:24-29) */
 #define SAMD_KIND_ENDPOS 1    /* samd StaticSAM / both DynSAMs: min_endpos + input_ids (S/sam/static_sam.py:10-15) */
@@ -163,6 +173,10 @@ int samd_session_export(samd_session_t *s, int64_t out_info[10], int32_t *h_link
 int samd_session_set_cursors(samd_session_t *s, int32_t dyn_index, int32_t dyn_length, int32_t st_index,
                              int32_t st_length, void *stream);
 
+/* seed the first lookup: start_token <- *d_src (the arg-max of the last prompt position, SO/samd_model.py:110
+ * feeding SO/utils.py:86); device-to-device, no host round trip */
+int samd_session_set_start_token(samd_session_t *s, const int32_t *d_src, void *stream);
+
 /* DraftModel.lookup  -- SO/draft.py:50-59 (variant 0) / S/draft.py:52-63 (variant 1):
  * both lookups, len_bias, the dyn-vs-static rule, then
  *   sequence: DynSAM.gen_draft (SO/sam/dyn_sam.py:116-121; S/sam/dyn_sam.py:99-113 with to_anc; S/sam/static_sam.py:119-125)
@@ -185,6 +199,14 @@ int samd_session_draft_fixed(samd_session_t *s, const samd_static_t *sam, const 
 int samd_session_set_draft(samd_session_t *s, const int32_t *d_tokens, const int32_t *d_parent, int32_t n, int32_t type,
                            void *stream);
 int samd_session_read_draft(samd_session_t *s, samd_draft_host_t *out, void *stream);
+/* like samd_session_set_draft, but takes effect only when the session's last lookup deferred to the tree
+ * model (draft type 2: S/draft.py:63) -- lets the Token-Recycle / EAGLE draft be installed without a host
+ * round trip.  reverse_leaves as in samd_tree_buffers. */
+int samd_session_set_draft_if_deferred(samd_session_t *s, const int32_t *d_tokens, const int32_t *d_parent, int32_t n,
+                                       int32_t reverse_leaves, void *stream);
+/* enqueue one D2H copy of the SAMD_REPORT_INTS-word report block into h_dst (pinned host memory for a
+ * truly asynchronous copy); no synchronisation -- the caller waits on the stream / an event. */
+int samd_session_report_async(samd_session_t *s, int32_t *h_dst, void *stream);
 
 /* device view of the session's draft/verdict block (fixed layout, see samd_session_block_t in DESIGN.md):
  * out[0]=tokens int32[64] out[1]=parent int32[64] out[2]=position int32[64] out[3]=mask u64[64]
@@ -229,6 +251,11 @@ int samd_session_step(samd_session_t *s, const samd_static_t *sam, const samd_pa
 int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len,
                     int32_t head_dim, int32_t elem_bytes, void *stream);
 
+/* the same compaction with host-known start/accept and a device index vector: the stand-alone form of
+ * SamdStaticCache.select_indices(indices, accept_length) -- SO/cache.py:118-133 */
+int samd_kv_compact_indices(void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len, int32_t head_dim,
+                            int32_t elem_bytes, int32_t start, const int32_t *d_indices, int32_t accept, void *stream);
+
 /* SamdStaticCache.reset / set_length  -- SO/cache.py:89-94: the committed KV length lives in the session
  * (device scalar) so that accept, compaction and attention chain without host round trips. */
 int samd_session_set_cache_length(samd_session_t *s, int32_t length, void *stream);
@@ -264,6 +291,14 @@ int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_
                        void *stream);
 /* LlamaMLP activation: silu(gate) * up with gate|up concatenated per row */
 int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, void *stream);
+
+/* ---- scripted verifier (tests, smoke and bench only): replaces the LM arg-max of every draft node by
+ * the next token of a target stream while the node's context (committed history + root->node path) is a
+ * prefix of it, otherwise by a hash of the context's last three tokens -- the device twin of
+ * tests/scripted_lm.py, so that acceptance statistics are reproducible without model weights.
+ * d_target int32[n_target]; d_out int32[64]. */
+int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_target, int32_t vocab, int32_t *d_out,
+                         void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token Recycle (S/tree_model/token_recycle/token_recycle.py:18-63)

@@ -64,6 +64,7 @@ struct StepArgs {
     int index, match, start, source, type, reverse;
     int c0, c1, c2, c3;         // OP_SET_CURSORS
     int have_static;
+    int only_if_deferred;       // OP_SET_DRAFT: install only when the last lookup returned type 2
 };
 
 __device__ __forceinline__ void load_draft(const SessionDev &D, StepShared &sh, int &type, int &n, int &nl, int &md) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         int nl, mxd; build_buffers(sh, n, 0, nl, mxd);
         store_draft(D, sh, 0, n, nl, mxd, A.index, 0, A.index, 0, 0);
     }
-    if (A.ops & OP_SET_DRAFT) {
+    if ((A.ops & OP_SET_DRAFT) && !(A.only_if_deferred && D.dmeta[D_TYPE] != 2)) {
         if (lane < A.n) { sh.tokens[lane] = A.tokens[lane]; sh.parent[lane] = A.parents[lane]; }
         __syncthreads();
         int nl, mxd; build_buffers(sh, A.n, A.reverse, nl, mxd);
@@ -192,6 +193,42 @@ __global__ __launch_bounds__(64) void k_tree_buffers(const int32_t *parent, int 
     }
     if (retrieve) for (int k = i; k < nl * md; k += WAVE) { const unsigned char v = sh.path[k / md][k % md]; retrieve[k] = v == PATH_PAD ? -1 : (int)v; }
     if (shape && i == 0) { shape[0] = nl; shape[1] = md; }
+}
+
+// scripted verifier (tests / smoke / bench): device twin of tests/scripted_lm.py next_token().
+// ctx(i) = committed history + tokens on the root->i path; arg-max(i) = target[len(ctx)] while ctx is a
+// prefix of target, else 3 + hash(last three ctx tokens) % (V-3).
+__global__ __launch_bounds__(64) void k_scripted_argmax(SessionDev D, const int32_t *__restrict__ target, int n_target, int vocab,
+                                                        int32_t *__restrict__ out) {
+    __shared__ int tok[SAMD_MAX_DRAFT], par[SAMD_MAX_DRAFT];
+    const int i = lane_id();
+    const int n = D.dmeta[D_N];
+    const int nc = D.meta[M_NTEXT] - 1;                       // committed tokens (text[0] is the sentinel)
+    const int32_t *hist = D.text + 1;
+    if (i < n) { tok[i] = D.tokens[i]; par[i] = D.parent[i]; }
+    __syncthreads();
+    // is the committed history a prefix of target?
+    int bad = 0;
+    for (int k = i; k < nc; k += WAVE) bad |= (k >= n_target || hist[k] != target[k]);
+    const bool hist_ok = __ballot(bad != 0) == 0ull;
+    int res = 0;
+    if (i < n) {
+        int path[SAMD_MAX_DRAFT]; int d = 0;
+        for (int j = i; j != -1; j = par[j]) path[d++] = tok[j];   // leaf -> root
+        bool ok = hist_ok;
+        for (int k = 0; k < d && ok; k++) { const int pos = nc + k; ok = pos < n_target && path[d - 1 - k] == target[pos]; }
+        const int len = nc + d;
+        if (ok && len < n_target) res = target[len];
+        else {
+            long long h = 1469598103ll;
+            for (int k = (len >= 3 ? len - 3 : 0); k < len; k++) {
+                const int t = k < nc ? hist[k] : path[d - 1 - (k - nc)];
+                h = (h * 1000003ll + t + 7) % 2147483647ll;
+            }
+            res = 3 + (int)(h % (vocab - 3));
+        }
+    }
+    out[i] = res;
 }
 
 // ================================================================================================
@@ -256,23 +293,25 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
     D.hmask = H - 1;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    // report block: dmeta | verdict | acc_tokens | kv_index | counters | meta are contiguous so that one
+    // D2H copy (samd_session_report_async) hands the host everything it polls per step
     const size_t o_link = carve(4ull * D.cap_states), o_len = carve(4ull * D.cap_states), o_me = carve(4ull * D.cap_states),
                  o_head = carve(4ull * D.cap_states), o_tail = carve(4ull * D.cap_states), o_hk = carve(8ull * H),
-                 o_hd = carve(4ull * H), o_hn = carve(4ull * H), o_text = carve(4ull * D.cap_text), o_meta = carve(4 * M_COUNT),
+                 o_hd = carve(4ull * H), o_hn = carve(4ull * H), o_text = carve(4ull * D.cap_text),
                  o_tok = carve(4 * 64), o_par = carve(4 * 64), o_pos = carve(4 * 64), o_mask = carve(8 * 64), o_ret = carve(4 * 64 * 64),
-                 o_dm = carve(4 * D_COUNT), o_ver = carve(4 * V_COUNT), o_acc = carve(4 * 64), o_kv = carve(4 * 64),
-                 o_st = carve(4), o_cl = carve(4), o_cnt = carve(4 * C_COUNT);
+                 o_rep = carve(4 * SAMD_REPORT_INTS), o_st = carve(4), o_cl = carve(4);
     s->arena_bytes = off;
     if (hipMalloc(&s->arena, off) != hipSuccess) { free(s); samd_set_error("hipMalloc(session arena) failed"); return SAMD_E_HIP; }
     char *base = (char *)s->arena;
     D.link = (int32_t *)(base + o_link); D.length = (int32_t *)(base + o_len); D.minend = (int32_t *)(base + o_me);
     D.head = (int32_t *)(base + o_head); D.tail = (int32_t *)(base + o_tail); D.hkey = (uint64_t *)(base + o_hk);
     D.hdst = (int32_t *)(base + o_hd); D.hnext = (int32_t *)(base + o_hn); D.text = (int32_t *)(base + o_text);
-    D.meta = (int32_t *)(base + o_meta); D.tokens = (int32_t *)(base + o_tok); D.parent = (int32_t *)(base + o_par);
+    D.tokens = (int32_t *)(base + o_tok); D.parent = (int32_t *)(base + o_par);
     D.position = (int32_t *)(base + o_pos); D.mask = (uint64_t *)(base + o_mask); D.retrieve = (int32_t *)(base + o_ret);
-    D.dmeta = (int32_t *)(base + o_dm); D.verdict = (int32_t *)(base + o_ver); D.acc_tokens = (int32_t *)(base + o_acc);
-    D.kv_index = (int32_t *)(base + o_kv); D.start_token = (int32_t *)(base + o_st); D.cache_length = (int32_t *)(base + o_cl);
-    D.counters = (int32_t *)(base + o_cnt);
+    int32_t *rep = (int32_t *)(base + o_rep);
+    D.dmeta = rep + SAMD_REP_DMETA; D.verdict = rep + SAMD_REP_VERDICT; D.acc_tokens = rep + SAMD_REP_TOKENS;
+    D.kv_index = rep + SAMD_REP_KVINDEX; D.counters = rep + SAMD_REP_COUNTERS; D.meta = rep + SAMD_REP_META;
+    D.start_token = (int32_t *)(base + o_st); D.cache_length = (int32_t *)(base + o_cl);
     if (hipMemset(s->arena, 0, off) != hipSuccess) { (void)hipFree(s->arena); free(s); return SAMD_E_HIP; }
     *out = s;
     int rc = samd_session_reset(s, nullptr);
@@ -361,6 +400,26 @@ int samd_session_set_draft(samd_session_t *s, const int32_t *d_tokens, const int
     StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_SET_DRAFT; A.tokens = d_tokens; A.parents = d_parent; A.n = n;
     A.type = type & 0xff; A.reverse = (type >> 8) & 1;
     return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_session_set_draft_if_deferred(samd_session_t *s, const int32_t *d_tokens, const int32_t *d_parent, int32_t n,
+                                       int32_t reverse_leaves, void *stream) {
+    if (!d_tokens || !d_parent || n < 1 || n > SAMD_MAX_DRAFT) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_SET_DRAFT; A.tokens = d_tokens; A.parents = d_parent; A.n = n;
+    A.type = 1; A.reverse = reverse_leaves ? 1 : 0; A.only_if_deferred = 1;
+    return launch_session(s, nullptr, nullptr, A, stream);
+}
+
+int samd_session_set_start_token(samd_session_t *s, const int32_t *d_src, void *stream) {
+    if (!s || !d_src) return SAMD_E_INVALID;
+    HIPCHK(hipMemcpyAsync(s->dev.start_token, d_src, 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SAMD_OK;
+}
+
+int samd_session_report_async(samd_session_t *s, int32_t *h_dst, void *stream) {
+    if (!s || !h_dst) return SAMD_E_INVALID;
+    HIPCHK(hipMemcpyAsync(h_dst, s->dev.dmeta, 4 * SAMD_REPORT_INTS, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SAMD_OK;
 }
 
 int samd_session_accept(samd_session_t *s, const int32_t *d_node_argmax, void *stream) {
@@ -458,6 +517,13 @@ int samd_session_get_cache_length(samd_session_t *s, int32_t *h_out, void *strea
     if (!s || !h_out) return SAMD_E_INVALID;
     D2H(h_out, s->dev.cache_length, 4);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return SAMD_OK;
+}
+
+int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_target, int32_t vocab, int32_t *d_out, void *stream) {
+    if (!s || !d_target || !d_out || n_target < 0 || vocab < 4) return SAMD_E_INVALID;
+    hipLaunchKernelGGL(k_scripted_argmax, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, s->dev, d_target, n_target, vocab, d_out);
+    LAUNCHCHK();
     return SAMD_OK;
 }
 

@@ -67,10 +67,14 @@ __global__ __launch_bounds__(1024) void k_argmax_rows(const T *__restrict__ logi
 // index_select materialises before copy_), so overlapping source/destination rows are safe.
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_kv_compact(void *const *__restrict__ tensors, const int *__restrict__ verdict,
-                                                    const int *__restrict__ kv_index, int n_heads, long long max_len, int row_bytes) {
+                                                    const int *__restrict__ kv_index, int n_heads, long long max_len, int row_bytes,
+                                                    int h_start, int h_accept) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (!verdict[V_IS_TREE]) return;                       // sequence drafts keep their rows in place
-    const int a = verdict[V_ACCEPT], start = verdict[V_KV_START];
+    int a = h_accept, start = h_start;
+    if (verdict) {                                         // device-side verdict of the fused step
+        if (!verdict[V_IS_TREE]) return;                   // sequence drafts keep their rows in place
+        a = verdict[V_ACCEPT]; start = verdict[V_KV_START];
+    }
     unsigned char *base = (unsigned char *)tensors[blockIdx.x / n_heads] + (size_t)(blockIdx.x % n_heads) * max_len * row_bytes;
     const int chunks = row_bytes >> 4, total = a * chunks;
     uint4 *lds = reinterpret_cast<uint4 *>(smem);
@@ -393,7 +397,23 @@ int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors
     const size_t lds = (size_t)SAMD_MAX_DRAFT * row_bytes;
     if (lds > 64 * 1024) { samd_set_error("samd_kv_compact: row too large"); return SAMD_E_INVALID; }
     hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, s->dev.verdict,
-                       s->dev.kv_index, n_heads, (long long)max_len, row_bytes);
+                       s->dev.kv_index, n_heads, (long long)max_len, row_bytes, 0, 0);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_kv_compact_indices(void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len, int32_t head_dim,
+                            int32_t elem_bytes, int32_t start, const int32_t *d_indices, int32_t accept, void *stream) {
+    if (!d_tensors || !d_indices || n_tensors < 1 || n_heads < 1 || head_dim < 1 || (head_dim * elem_bytes) % 16 != 0 || start < 0 ||
+        accept < 0 || accept > SAMD_MAX_DRAFT || start + accept > max_len) {
+        samd_set_error("samd_kv_compact_indices: invalid argument"); return SAMD_E_INVALID;
+    }
+    if (accept == 0) return SAMD_OK;
+    const int row_bytes = head_dim * elem_bytes;
+    const size_t lds = (size_t)SAMD_MAX_DRAFT * row_bytes;
+    if (lds > 64 * 1024) { samd_set_error("samd_kv_compact_indices: row too large"); return SAMD_E_INVALID; }
+    hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, (const int *)nullptr,
+                       d_indices, n_heads, (long long)max_len, row_bytes, start, accept);
     LAUNCHCHK();
     return SAMD_OK;
 }

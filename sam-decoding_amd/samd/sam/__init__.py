@@ -1,0 +1,3 @@
+from .dyn_sam import DynSAM
+from .static_sam import StaticSAM, NullStaticSAM
+from .utils import build_sam, dump_sam, load_sam

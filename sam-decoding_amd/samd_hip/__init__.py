@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsamd_hip.so")
 MAX_DRAFT = 64
 TOPK = 8
+# report block layout (include/samd_hip.h SAMD_REP_*)
+REP_DMETA, REP_VERDICT, REP_TOKENS, REP_KVINDEX, REP_COUNTERS, REP_META, REPORT_INTS = 0, 16, 24, 88, 152, 160, 176
 KIND_COUNT, KIND_ENDPOS = 0, 1
 F16, BF16, F32 = 0, 1, 2
 
@@ -76,6 +78,10 @@ _PROTOS = {
     "samd_session_draft_fixed": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_session_set_draft": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
     "samd_session_read_draft": (C.c_int, [_VP, _VP, _VP]),
+    "samd_session_set_draft_if_deferred": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP]),
+    "samd_session_report_async": (C.c_int, [_VP, _VP, _VP]),
+    "samd_session_set_start_token": (C.c_int, [_VP, _VP, _VP]),
+    "samd_scripted_argmax": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP]),
     "samd_session_device_views": (C.c_int, [_VP, _VP]),
     "samd_tree_buffers": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_argmax_rows": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),
@@ -86,6 +92,7 @@ _PROTOS = {
     "samd_session_set_cache_length": (C.c_int, [_VP, _I32, _VP]),
     "samd_session_get_cache_length": (C.c_int, [_VP, _VP, _VP]),
     "samd_kv_compact": (C.c_int, [_VP, _VP, _I32, _I32, _I64, _I32, _I32, _VP]),
+    "samd_kv_compact_indices": (C.c_int, [_VP, _I32, _I32, _I64, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_tree_attention_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_tree_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
                                       _VP, _I64, _VP]),
@@ -296,6 +303,19 @@ class Session:
         check(lib().samd_session_set_draft(self._h, _ptr(d_tokens), _ptr(d_parent), n, type_ | (256 if reverse else 0),
                                            current_stream()))
 
+    def set_draft_if_deferred(self, d_tokens, d_parent, n, reverse=False):
+        check(lib().samd_session_set_draft_if_deferred(self._h, _ptr(d_tokens), _ptr(d_parent), n, int(reverse), current_stream()))
+
+    def set_start_token(self, d_src):
+        check(lib().samd_session_set_start_token(self._h, _ptr(d_src), current_stream()))
+
+    def report_async(self, h_pinned):
+        """enqueue the D2H copy of the per-step report block into a pinned int32[REPORT_INTS] tensor."""
+        check(lib().samd_session_report_async(self._h, _ptr(h_pinned), current_stream()))
+
+    def scripted_argmax(self, d_target, n_target, vocab, d_out):
+        check(lib().samd_scripted_argmax(self._h, _ptr(d_target), n_target, vocab, _ptr(d_out), current_stream()))
+
     def read_draft(self):
         out = DraftHost()
         check(lib().samd_session_read_draft(self._h, C.byref(out), current_stream()))
@@ -350,3 +370,38 @@ class Session:
         out = dict(zip(keys, list(info)))
         out.update(link=link, length=length, aux=minend, deg=deg, edge_tok=et, edge_dst=ed, text=text)
         return out
+
+
+class TokenRecycleTable:
+    """samd_recycle_t: the [V, 8] successor table of Token Recycle (samd/tree_model/token_recycle/token_recycle.py:18-63)
+    plus the static draft tree given as child lists."""
+
+    def __init__(self, vocab, tree):
+        require_gpu()
+        off = np.zeros(len(tree) + 1, np.int32)
+        off[1:] = np.cumsum([len(c) for c in tree])
+        ch = _np_i32([c for cs in tree for c in cs] or [0])
+        h = C.c_void_p()
+        check(lib().samd_recycle_create(int(vocab), _ptr(off), _ptr(ch), len(tree), C.byref(h)))
+        self._h, self.vocab, self.n_nodes = h, int(vocab), len(tree)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().samd_recycle_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def update(self, d_tokens, d_logits, dtype_code, n, vocab, row_stride, d_n=None):
+        check(lib().samd_recycle_update(self._h, _ptr(d_tokens), _ptr(d_logits), dtype_code, n, _ptr(d_n), vocab, row_stride,
+                                        current_stream()))
+
+    def draft(self, d_start_token, d_out):
+        check(lib().samd_recycle_draft(self._h, _ptr(d_start_token), _ptr(d_out), current_stream()))
+
+    def export(self):
+        table = np.empty((self.vocab, 8), np.int32)
+        present = np.empty(self.vocab, np.uint8)
+        check(lib().samd_recycle_export(self._h, _ptr(table), _ptr(present), current_stream()))
+        return table, present

@@ -1,0 +1,203 @@
+"""DecodeEngine -- one request stream of SAM-Decoding on one MI355X.
+
+What SamdModel.prefill / decode / update_state do between two LM forwards in the reference
+(samd_sam_only/samd_model.py:96-174; samd/samd_model.py:101-211) -- arg-max, draft lookup, tree buffers, greedy
+posterior, SAM update, KV compaction -- is here a fixed sequence of kernels on one stream with no host round trip:
+
+    verify forward (R rows) -> row arg-max -> [Token-Recycle update] -> k_session{accept, commit, lookup, draft, buffers}
+    -> [Token-Recycle draft install] -> KV compaction -> report copy (D2H, pinned)
+
+The sequence is captured once per row bucket R into a hipGraph; the host replays it and reads the 704-byte report
+(accepted tokens, next draft size) to apply the reference's stopping rules.
+"""
+import numpy as np
+import torch
+
+from . import (F32, MAX_DRAFT, REP_COUNTERS, REP_DMETA, REP_KVINDEX, REP_META, REP_TOKENS, REP_VERDICT, REPORT_INTS,
+               Params, SamdError, Session, StaticAutomaton, TokenRecycleTable, _ptr, check, current_stream, lib,
+               require_gpu, torch_dtype_code)
+
+
+class StepReport:
+    """host view of one report block (include/samd_hip.h SAMD_REP_*)."""
+    __slots__ = ("type", "n", "n_leaves", "max_depth", "match_dyn", "match_static", "best", "accept", "next_token", "is_tree",
+                 "tokens", "kv_index", "steps", "error")
+
+    def __init__(self, r):
+        d, v = r[REP_DMETA:REP_DMETA + 16], r[REP_VERDICT:REP_VERDICT + 8]
+        self.type, self.n, self.n_leaves, self.max_depth = int(d[0]), int(d[1]), int(d[2]), int(d[3])
+        self.match_dyn, self.match_static = int(d[5]), int(d[7])
+        self.best, self.accept, self.next_token, self.is_tree = int(v[0]), int(v[1]), int(v[3]), int(v[5])
+        self.tokens = r[REP_TOKENS:REP_TOKENS + self.accept].tolist()
+        self.kv_index = r[REP_KVINDEX:REP_KVINDEX + self.accept].tolist()
+        self.steps = int(r[REP_COUNTERS])
+        self.error = int(r[REP_META + 9])
+
+
+class ScriptedVerifier:
+    """Stand-in for the LM forward in tests, smoke() and bench.py's acceptance model: the arg-max of every draft node
+    comes from a target stream (samd_scripted_argmax, the device twin of tests/scripted_lm.py).  It exercises every
+    non-LM kernel of the step with reproducible accept lengths; it is not a CPU fallback of anything."""
+
+    def __init__(self, target, vocab, device="cuda", with_logits=False):
+        require_gpu()
+        self.vocab, self.device = int(vocab), torch.device(device)
+        self.host_target = [int(t) for t in target]
+        self.target = torch.tensor(self.host_target, dtype=torch.int32, device=self.device)
+        self.argmax = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
+        self.with_logits = with_logits
+        self.logits = torch.zeros((MAX_DRAFT, self.vocab), dtype=torch.float32, device=self.device) if with_logits else None
+        self._base = ((torch.arange(self.vocab, device=self.device, dtype=torch.int64) * 37)) if with_logits else None
+        self.dtype = torch.float32
+
+    def next_token(self, ctx):
+        k = len(ctx)
+        if k < len(self.host_target) and list(ctx) == self.host_target[:k]:
+            return self.host_target[k]
+        h = 1469598103
+        for t in ctx[-3:]:
+            h = (h * 1000003 + t + 7) % 2147483647
+        return 3 + h % (self.vocab - 3)
+
+    def _rows(self, n_rows):
+        """tie-free logits rows whose arg-max is self.argmax (same construction as tests/scripted_lm.py row())."""
+        nt = self.argmax[:n_rows].to(torch.int64)
+        v = self.vocab
+        r = ((self._base[None, :] + 11 * nt[:, None]) % v).to(torch.float32) / float(v)
+        idx = torch.arange(n_rows, device=self.device)
+        r[idx, nt] += 8.0
+        r[idx, (nt * 7 + 1) % v] += 3.0
+        self.logits[:n_rows] = r
+
+    def prefill(self, session, input_ids, on_chunk=None):
+        ids = [int(t) for t in input_ids.reshape(-1).tolist()]
+        n = len(ids)
+        session.set_cache_length(n)
+        if on_chunk is not None:
+            if not self.with_logits:
+                raise SamdError("ScriptedVerifier(with_logits=True) is required for Token Recycle")
+            for c0 in range(0, n, MAX_DRAFT):
+                m = min(MAX_DRAFT, n - c0)
+                am = [self.next_token(ids[:c0 + i + 1]) for i in range(m)]
+                self.argmax[:m] = torch.tensor(am, dtype=torch.int32, device=self.device)
+                self._rows(m)
+                on_chunk(torch.tensor(ids[c0:c0 + m] + [0] * (MAX_DRAFT - m), dtype=torch.int32, device=self.device), self.logits, m)
+        first = torch.tensor([self.next_token(ids)], dtype=torch.int32, device=self.device)
+        session.set_start_token(first)
+        self._keep = first
+        if not self.with_logits:
+            return None
+        self.argmax[:1] = first
+        self._rows(1)
+        return self.logits[0].clone()
+
+    def forward_tokens(self, session, tokens, relpos, mask_rows, n, L):
+        """granular verify: the session already holds this draft (DraftModel.lookup installed it)."""
+        if not self.with_logits:
+            raise SamdError("ScriptedVerifier(with_logits=True) is required for the granular decode()")
+        session.set_cache_length(L)
+        self.verify(session, MAX_DRAFT)
+        return self.logits[:n].clone()
+
+    def verify(self, session, R):
+        session.scripted_argmax(self.target, len(self.host_target), self.vocab, self.argmax)
+        if self.with_logits:
+            self._rows(MAX_DRAFT)
+        return dict(argmax=self.argmax, logits=self.logits)
+
+    def compact(self, session):
+        pass
+
+    def bucket(self, n):
+        return MAX_DRAFT
+
+
+class DecodeEngine:
+    def __init__(self, verifier, session: Session, static: StaticAutomaton, params: Params, recycle: TokenRecycleTable = None,
+                 recycle_parent=None, use_graphs=True):
+        require_gpu()
+        self.verifier, self.session, self.static, self.params = verifier, session, static, params
+        self.recycle = recycle
+        self.device = torch.device("cuda")
+        if recycle is not None:
+            self.tr_parent = torch.tensor(recycle_parent, dtype=torch.int32, device=self.device)
+            self.tr_tokens = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
+        self.report_buf = torch.zeros(REPORT_INTS, dtype=torch.int32).pin_memory()
+        self._report_np = self.report_buf.numpy()
+        self.use_graphs = use_graphs
+        self._graphs = {}
+        self._views = session.device_views()
+        self._n_ptr = self._views["dmeta"] + 4
+        self.timing = None
+
+    # ---- pieces ---------------------------------------------------------------------------------------
+    def _recycle_update(self, d_tokens, logits, n_rows, d_n):
+        dt = F32 if logits.dtype == torch.float32 else torch_dtype_code(logits.dtype)
+        self.recycle.update(d_tokens, logits, dt, n_rows, logits.shape[1], logits.stride(0), d_n)
+
+    def _install_tree(self):
+        """samd/draft.py:63: when the lookup deferred to the tree model, fill and install its draft."""
+        self.recycle.draft(self._views["start_token"], self.tr_tokens)
+        self.session.set_draft_if_deferred(self.tr_tokens, self.tr_parent, self.recycle.n_nodes, reverse=True)
+
+    def _enqueue_step(self, R):
+        b = self.verifier.verify(self.session, R)
+        if self.recycle is not None:
+            import ctypes as C
+            self._recycle_update(self._views["tokens"], b["logits"], min(R, MAX_DRAFT), C.c_void_p(self._n_ptr))
+        self.session.step(self.static, self.params, b["argmax"])
+        if self.recycle is not None:
+            self._install_tree()
+        self.verifier.compact(self.session)
+        self.session.report_async(self.report_buf)
+
+    # ---- public ---------------------------------------------------------------------------------------
+    def start(self, input_ids):
+        """DraftModel.reset + SamdModel.prefill (SO/samd_model.py:96-114) + the first lookup of the decode loop."""
+        s = self.session
+        s.reset()
+        on_chunk = None
+        if self.recycle is not None:
+            on_chunk = lambda toks, logits, n: self._recycle_update(toks, logits, n, None)
+        ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
+        self.verifier.prefill(s, ids, on_chunk)
+        s.add_tokens(ids)                                    # DraftModel.update(prompt): dyn add_tokens ...
+        s.static_walk(self.static, ids, ids.numel(), commit=True)     # ... and static transfer_tokens (SO/draft.py:62-67)
+        s.draft(self.static, self.params, self._views["start_token"])
+        if self.recycle is not None:
+            self._install_tree()
+        s.report_async(self.report_buf)
+        torch.cuda.current_stream().synchronize()
+        return StepReport(self._report_np)
+
+    def step(self, n_next):
+        """one decode step on the current draft of n_next nodes; returns the report after it."""
+        R = self.verifier.bucket(n_next)
+        if not self.use_graphs:
+            self._enqueue_step(R)
+        else:
+            g = self._graphs.get(R)
+            if g is None:
+                g = self._capture(R)
+            g.replay()
+        torch.cuda.current_stream().synchronize()
+        return StepReport(self._report_np)
+
+    def _capture(self, R):
+        """capture the step for row bucket R.  The warm-up run executes a real step (it advances the request by one
+        step exactly like a replay would), so capture happens on a side copy of nothing: we snapshot nothing and
+        instead capture without running -- hipGraph capture records launches without executing them."""
+        stream = torch.cuda.current_stream()
+        g = torch.cuda.CUDAGraph()
+        # library handles (hipBLASLt workspaces) must exist before capture: warm the GEMMs of this bucket on scratch
+        self._warm(R)
+        stream.synchronize()
+        with torch.cuda.graph(g, stream=stream if stream != torch.cuda.default_stream() else None):
+            self._enqueue_step(R)
+        self._graphs[R] = g
+        return g
+
+    def _warm(self, R):
+        v = self.verifier
+        if hasattr(v, "warm"):
+            v.warm(R)

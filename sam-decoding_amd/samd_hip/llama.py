@@ -1,0 +1,267 @@
+"""LlamaRunner -- the verify forward of SAM-Decoding on MI355X.
+
+The reference runs HuggingFace `LlamaForCausalLM` with two monkey patches (samd_sam_only/model_patch/llama.py:35-109,
+:112-202) and a static KV cache (samd_sam_only/cache.py:37-133).  Here the decoder loop is our own: library GEMMs
+(torch.mm -> hipBLASLt) between hand-written gfx950 kernels (embedding gather, RMSNorm+residual, RoPE + KV write at a
+device-side offset, tree-mask attention, SiLU*up, row arg-max).  Every dynamic scalar of a decode step -- cache length
+L, draft size n, tree depths, tree mask -- is read from device memory (the session's draft block), so one step is a
+fixed launch sequence that is captured once per row bucket into a hipGraph.
+
+There is no CPU path: constructing a runner without a GPU raises.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import (F16, BF16, MAX_DRAFT, SamdError, Session, _ptr, check, current_stream, lib, require_gpu,
+               torch_dtype_code)
+
+
+def _cfg_get(cfg, name, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+class LlamaShape:
+    """the architecture numbers the runner needs (subset of transformers.LlamaConfig)."""
+
+    def __init__(self, cfg):
+        self.hidden = int(_cfg_get(cfg, "hidden_size"))
+        self.inter = int(_cfg_get(cfg, "intermediate_size"))
+        self.layers = int(_cfg_get(cfg, "num_hidden_layers"))
+        self.heads = int(_cfg_get(cfg, "num_attention_heads"))
+        kv = _cfg_get(cfg, "num_key_value_heads")
+        self.kv_heads = int(kv) if kv is not None else self.heads
+        hd = _cfg_get(cfg, "head_dim")
+        self.head_dim = int(hd) if hd else self.hidden // self.heads
+        self.vocab = int(_cfg_get(cfg, "vocab_size"))
+        self.eps = float(_cfg_get(cfg, "rms_norm_eps", 1e-6))
+        self.max_pos = int(_cfg_get(cfg, "max_position_embeddings", 2048))
+        rp = _cfg_get(cfg, "rope_parameters") or _cfg_get(cfg, "rope_scaling") or {}
+        theta = _cfg_get(cfg, "rope_theta")
+        if theta is None and isinstance(rp, dict):
+            theta = rp.get("rope_theta")
+        self.rope_theta = float(theta if theta is not None else 10000.0)
+        self.rope_scaling = dict(rp) if isinstance(rp, dict) else {}
+        if self.head_dim != 128:
+            raise SamdError("the gfx950 tree-attention kernel is specialised for head_dim 128 (Vicuna-7B / Llama-3-8B)")
+
+    def inv_freq(self):
+        """rotary inverse frequencies incl. the 'llama3' scaling rule (what HF's ROPE_INIT_FUNCTIONS computes)."""
+        d = self.head_dim
+        inv = 1.0 / (self.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float64) / d))
+        rs = self.rope_scaling
+        kind = rs.get("rope_type", rs.get("type", "default")) if rs else "default"
+        if kind == "llama3":
+            factor, lo, hi = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
+            old = rs["original_max_position_embeddings"]
+            wavelen = 2 * math.pi / inv
+            scaled = torch.where(wavelen > old / lo, inv / factor, inv)
+            smooth = (old / wavelen - lo) / (hi - lo)
+            mid = (1 - smooth) * inv / factor + smooth * inv
+            is_mid = (wavelen <= old / lo) & (wavelen >= old / hi)
+            inv = torch.where(is_mid, mid, scaled)
+        elif kind == "linear":
+            inv = inv / rs["factor"]
+        elif kind not in ("default", None):
+            raise SamdError(f"unsupported rope scaling '{kind}'")
+        return inv
+
+
+class LlamaRunner:
+    """Own decoder loop over Llama weights resident in HBM.  One instance = one model replica on one GPU."""
+
+    BUCKETS = (1, 8, 16, 32, 64)
+
+    def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None):
+        require_gpu()
+        self.shape, self.dtype, self.device = shape, dtype, torch.device(device)
+        self.dt = torch_dtype_code(dtype)
+        if self.dt not in (F16, BF16):
+            raise SamdError("LlamaRunner computes in fp16 or bf16")
+        self.max_len = int(max_cache_len)
+        s = shape
+        self.w = weights
+        # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
+        self.bind_cache(kv if kv is not None else
+                        torch.zeros((s.layers, 2, s.kv_heads, self.max_len, s.head_dim), dtype=dtype, device=self.device))
+        # rotary tables, fp32 [max_pos][D/2]
+        max_pos = max(s.max_pos, self.max_len)
+        ang = torch.outer(torch.arange(max_pos, dtype=torch.float64), s.inv_freq())
+        self.cos = ang.cos().float().to(self.device).contiguous()
+        self.sin = ang.sin().float().to(self.device).contiguous()
+        self.rope_rows = max_pos
+        self.scale = 1.0 / math.sqrt(s.head_dim)
+        self._buf = {}
+        self._graphs = {}
+        # prefill staging (chunks of MAX_DRAFT rows with a causal chain mask)
+        self.pf_tokens = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
+        self.pf_relpos = torch.arange(MAX_DRAFT, dtype=torch.int32, device=self.device)
+        rows = [(1 << (i + 1)) - 1 for i in range(MAX_DRAFT)]
+        self.pf_mask = torch.tensor([r - (1 << 64) if r >= (1 << 63) else r for r in rows], dtype=torch.int64, device=self.device)
+        self.pf_n = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def bind_cache(self, storage):
+        """use `storage` [layers, 2, H_kv, max_len, D] (e.g. SamdStaticCache.storage) as the KV cache."""
+        s = self.shape
+        if tuple(storage.shape) != (s.layers, 2, s.kv_heads, self.max_len, s.head_dim) or storage.dtype != self.dtype:
+            raise SamdError(f"KV storage shape/dtype mismatch: {tuple(storage.shape)} {storage.dtype}")
+        self.kv = storage
+        self.kv_ptrs = torch.tensor([storage[l, j].data_ptr() for j in (0, 1) for l in range(s.layers)],
+                                    dtype=torch.int64, device=self.device)
+        self._graphs_dirty = True
+
+    # ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_hf(cls, lm, max_cache_len, dtype=None, device="cuda", **kw):
+        """weights of a transformers LlamaForCausalLM (what the reference passes as `lm`)."""
+        dtype = dtype or next(lm.parameters()).dtype
+        shape = LlamaShape(lm.config)
+        dev = torch.device(device)
+
+        def get(t):
+            return t.detach().to(device=dev, dtype=dtype).contiguous()
+        m = lm.model
+        layers = []
+        for lyr in m.layers:
+            a, f = lyr.self_attn, lyr.mlp
+            for lin in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, f.gate_proj, f.up_proj, f.down_proj):
+                if getattr(lin, "bias", None) is not None:
+                    raise SamdError("LlamaRunner: projection biases are not supported")
+            layers.append(dict(
+                wqkv=get(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)),
+                wo=get(a.o_proj.weight),
+                wgu=get(torch.cat([f.gate_proj.weight, f.up_proj.weight], dim=0)),
+                wdown=get(f.down_proj.weight),
+                ln1=get(lyr.input_layernorm.weight), ln2=get(lyr.post_attention_layernorm.weight)))
+        weights = dict(embed=get(m.embed_tokens.weight), layers=layers, norm=get(m.norm.weight), lm_head=get(lm.lm_head.weight))
+        return cls(shape, weights, max_cache_len, dtype, device, **kw)
+
+    @classmethod
+    def random_init(cls, cfg, max_cache_len, dtype=torch.float16, device="cuda", seed=0, std=0.02, **kw):
+        """random-init weights of the given architecture, created directly in HBM (no checkpoint on the box)."""
+        require_gpu()
+        shape = LlamaShape(cfg)
+        g = torch.Generator(device=device).manual_seed(seed)
+
+        def rnd(*size):
+            return (torch.randn(size, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+        s = shape
+        qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
+        layers = [dict(wqkv=rnd(qkv_out, s.hidden), wo=rnd(s.hidden, s.heads * s.head_dim), wgu=rnd(2 * s.inter, s.hidden),
+                       wdown=rnd(s.hidden, s.inter), ln1=torch.ones(s.hidden, dtype=dtype, device=device),
+                       ln2=torch.ones(s.hidden, dtype=dtype, device=device)) for _ in range(s.layers)]
+        weights = dict(embed=rnd(s.vocab, s.hidden), layers=layers, norm=torch.ones(s.hidden, dtype=dtype, device=device),
+                       lm_head=rnd(s.vocab, s.hidden))
+        return cls(shape, weights, max_cache_len, dtype, device, **kw)
+
+    def weight_bytes(self):
+        """bytes of weights one decode step streams from HBM (the embedding table is only gathered)."""
+        n = self.w["lm_head"].numel() + self.w["norm"].numel()
+        for l in self.w["layers"]:
+            n += sum(t.numel() for t in l.values())
+        return n * self.w["lm_head"].element_size()
+
+    # ------------------------------------------------------------------------------------------------
+    def _buffers(self, R):
+        if R not in self._buf:
+            s, dt, dev = self.shape, self.dtype, self.device
+            z = lambda *sz: torch.zeros(sz, dtype=dt, device=dev)
+            ws_bytes = lib().samd_tree_attention_workspace(R, s.heads, s.head_dim)
+            self._buf[R] = dict(x=z(R, s.hidden), h=z(R, s.hidden), qkv=z(R, (s.heads + 2 * s.kv_heads) * s.head_dim),
+                                q=z(R, s.heads, s.head_dim), attn=z(R, s.heads, s.head_dim), o=z(R, s.hidden),
+                                gu=z(R, 2 * s.inter), act=z(R, s.inter), d=z(R, s.hidden), logits=z(R, s.vocab),
+                                argmax=torch.zeros(MAX_DRAFT, dtype=torch.int32, device=dev),
+                                ws=torch.zeros(ws_bytes, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes)
+        return self._buf[R]
+
+    def bucket(self, n):
+        for b in self.BUCKETS:
+            if n <= b:
+                return b
+        raise SamdError(f"draft of {n} nodes exceeds {MAX_DRAFT}")
+
+    def forward_rows(self, R, d_tokens, d_relpos, d_mask, d_L, d_n):
+        """one forward over R rows; all of d_* are device pointers (ints / tensors).  Returns the buffers of bucket R
+        (logits [R, V], argmax int32[64] with rows < n valid)."""
+        L, s, b, dt, st = lib(), self.shape, self._buffers(R), self.dt, current_stream()
+        check(L.samd_embed_rows(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(b["x"]), R, s.hidden, s.vocab, dt, st))
+        delta = None
+        for li, w in enumerate(self.w["layers"]):
+            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, st))
+            torch.mm(b["h"], w["wqkv"].t(), out=b["qkv"])
+            check(L.samd_rope_kv_write(_ptr(b["qkv"]), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
+                                       _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
+                                       s.head_dim, self.max_len, self.rope_rows, dt, st))
+            check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
+                                        s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                                        _ptr(b["ws"]), b["ws_bytes"], st))
+            torch.mm(b["attn"].view(R, -1), w["wo"].t(), out=b["o"])
+            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(b["o"]), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, st))
+            torch.mm(b["h"], w["wgu"].t(), out=b["gu"])
+            check(L.samd_silu_mul(_ptr(b["gu"]), _ptr(b["act"]), R, s.inter, dt, st))
+            torch.mm(b["act"], w["wdown"].t(), out=b["d"])
+            delta = b["d"]
+        check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, st))
+        torch.mm(b["h"], self.w["lm_head"].t(), out=b["logits"])
+        check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
+        return b
+
+    # ------------------------------------------------------------------------------------------------
+    def prefill(self, session: Session, input_ids, on_chunk=None):
+        """SamdModel.prefill's LM part (SO/samd_model.py:96-114): the prompt goes through the same kernels in chunks of
+        64 rows with a causal chain mask; K/V land at [0, N).  Leaves cache_length = N in the session and the arg-max of
+        the last prompt position in session.start_token.  on_chunk(tokens int32[64], logits [64,V], n) is called per
+        chunk (Token Recycle learns from the prompt logits: S/samd_model.py:117-122)."""
+        ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
+        N = ids.numel()
+        if N < 1 or N > self.max_len:
+            raise SamdError(f"prompt of {N} tokens does not fit max_cache_len {self.max_len}")
+        v = session.device_views()
+        b = None
+        for c0 in range(0, N, MAX_DRAFT):
+            n = min(MAX_DRAFT, N - c0)
+            self.pf_tokens.zero_()
+            self.pf_tokens[:n] = ids[c0:c0 + n]
+            self.pf_n.fill_(n)
+            session.set_cache_length(c0)
+            b = self.forward_rows(MAX_DRAFT, self.pf_tokens, self.pf_relpos, self.pf_mask, v["cache_length"], self.pf_n)
+            if on_chunk is not None:
+                on_chunk(self.pf_tokens, b["logits"], n)
+        session.set_cache_length(N)
+        session.set_start_token(b["argmax"][(N - 1) % MAX_DRAFT:])
+        return b["logits"][(N - 1) % MAX_DRAFT]
+
+    def warm(self, R):
+        """run the launch sequence of bucket R once with n = 0 rows (no K/V row is written, every query row is
+        masked): creates the GEMM library's handles/workspaces before hipGraph capture without touching the request."""
+        self.pf_n.zero_()
+        scratch_L = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.forward_rows(R, self.pf_tokens, self.pf_relpos, self.pf_mask, scratch_L, self.pf_n)
+        torch.cuda.current_stream().synchronize()
+
+    def forward_tokens(self, session: Session, tokens, relpos, mask_rows, n, L):
+        """granular verify (SamdModel.decode): explicit draft tokens / relative positions / u64 mask rows -> logits [n, V]."""
+        R = self.bucket(n)
+        tok = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
+        tok[:n] = tokens.reshape(-1)[:n].to(torch.int32)
+        rel = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
+        rel[:n] = relpos.reshape(-1)[:n].to(torch.int32)
+        d_n = torch.tensor([n], dtype=torch.int32, device=self.device)
+        session.set_cache_length(L)
+        b = self.forward_rows(R, tok, rel, mask_rows, session.device_views()["cache_length"], d_n)
+        torch.cuda.current_stream().synchronize()
+        return b["logits"][:n]
+
+    def verify(self, session: Session, R):
+        """SamdModel.decode's LM call (SO/samd_model.py:134-138) on the session's current draft."""
+        v = session.device_views()
+        n_ptr = C.c_void_p(v["dmeta"] + 4)          # dmeta[D_N]
+        return self.forward_rows(R, v["tokens"], v["position"], v["mask"], v["cache_length"], n_ptr)
+
+    def compact(self, session: Session):
+        """SamdStaticCache.select_indices (SO/cache.py:118-133) for all 2 x layers tensors in one launch."""
+        s = self.shape
+        session.kv_compact(self.kv_ptrs, 2 * s.layers, s.kv_heads, self.max_len, s.head_dim, self.kv.element_size())

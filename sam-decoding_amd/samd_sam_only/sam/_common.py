@@ -1,0 +1,52 @@
+"""helpers shared by the DynSAM / StaticSAM facades (both variants)."""
+import numpy as np
+import torch
+
+import samd_hip
+
+
+def dev_i32(values, device="cuda"):
+    return torch.as_tensor(np.asarray(values, dtype=np.int32)).to(device)
+
+
+def so_params(max_predicts=60, alpha=4.0, K=8, len_bias=0):
+    p = samd_hip.Params()
+    p.variant, p.max_predicts, p.alpha, p.K, p.len_bias = 0, int(max_predicts), float(alpha), int(K), int(len_bias)
+    p.n_predicts, p.len_threshold, p.static_null = 0, 0, 0
+    return p
+
+
+def s_params(n_predicts=40, len_threshold=5, len_bias=5, static_null=False):
+    p = samd_hip.Params()
+    p.variant, p.max_predicts, p.alpha, p.K = 1, 0, 0.0, 0
+    p.len_bias, p.n_predicts, p.len_threshold, p.static_null = int(len_bias), int(n_predicts), int(len_threshold), int(static_null)
+    return p
+
+
+def tree_buffers_from_draft(d, device):
+    """DraftHost -> the tensors gen_buffers returns (samd_sam_only/sam/static_sam.py:164-180): bool mask [1,1,n,n],
+    int64 depths [1,n], int64 retrieve [leaves, max_depth] padded with -1."""
+    n = d.n
+    rows = np.frombuffer(d.mask, dtype=np.uint64, count=n)
+    bits = ((rows[:, None] >> np.arange(n, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+    pos = np.asarray(d.position[:n], dtype=np.int64)
+    ret = np.asarray(d.retrieve[:d.n_leaves * d.max_depth], dtype=np.int64).reshape(d.n_leaves, d.max_depth)
+    return {
+        "tree_attn_mask": torch.from_numpy(bits.reshape(1, 1, n, n)).to(device),
+        "tree_position_ids": torch.from_numpy(pos.reshape(1, n)).to(device),
+        "tree_retrieve_indices": torch.from_numpy(ret.copy()).to(device),
+    }
+
+
+class CursorOwner:
+    """a facade that may own a private Session (stand-alone use) or share the DraftModel's."""
+    _session = None
+    _own_capacity = 4096
+
+    def _sess(self):
+        if self._session is None:
+            self._session = samd_hip.Session(self._own_capacity)
+        return self._session
+
+    def _bind(self, session):
+        self._session = session

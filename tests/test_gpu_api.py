@@ -1,0 +1,186 @@
+"""GPU parity of the drop-in API layer (samd_sam_only / samd packages): the reference's own classes and call
+sequence (SamdConfig -> DraftModel -> SamdModel.generate) must reproduce, integer for integer, the traces recorded
+from the imported reference (tests/golden/loop_so.json.gz, loop_s.json.gz; generator: tests/golden/make_golden.py).
+The LM is the scripted verifier (device twin of tests/scripted_lm.py), so every accepted token, step count and
+accept length is exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import samd_hip
+from samd_hip.engine import ScriptedVerifier
+
+
+def so_model(case, with_logits=False, use_graphs=True):
+    import samd_sam_only as SO
+    cfg = SO.SamdConfig(max_predicts=case["max_predicts"], alpha=case["alpha"], K=case["K"], len_bias=case["len_bias"])
+    sam = SO.build_sam(case["docs"], case["eos"])
+    draft = SO.DraftModel(cfg, sam_static=sam, device="cuda")
+    lm = ScriptedVerifier(case["target"], case["vocab"], with_logits=with_logits)
+    model = SO.SamdModel(cfg, lm, draft, case["eos"], torch.float16, "cuda")
+    return SO, model
+
+
+@pytest.mark.parametrize("use_graphs", [True, False])
+def test_generate_so_matches_reference_trace(golden, use_graphs):
+    for case in golden("loop_so.json.gz"):
+        SO, model = so_model(case)
+        gcfg = SO.SamdGenerationConfig(max_new_tokens=case["max_new_tokens"], max_cache_len=case["max_cache_len"])
+        ids = torch.tensor([case["prompt"]], dtype=torch.long, device="cuda")
+        for rep in range(2):                     # second call: draft.reset() + cache reuse
+            model.set_cache(gcfg)
+            model.engine.use_graphs = use_graphs
+            out = model.generate(ids, generation_config=gcfg)
+            assert out.output_ids == [case["output_ids"]]
+            assert out.decode_tokens == case["decode_tokens"]
+            assert out.decode_steps == case["decode_steps"]
+            assert out.accepet_length_per_step == case["accept_lengths"]
+        kinds = [t["type"] for t in case["trace"]]
+        assert model.lookup_stats["sequence"][0] == 2 * kinds.count("sequence")
+        assert model.lookup_stats["tree"][0] == 2 * kinds.count("tree")
+
+
+def test_granular_decode_so_matches_reference_trace(golden):
+    """prefill()/decode()/update_state() with the reference's intermediate tensors."""
+    for case in golden("loop_so.json.gz")[:3]:
+        SO, model = so_model(case, with_logits=True)
+        gcfg = SO.SamdGenerationConfig(max_new_tokens=case["max_new_tokens"], max_cache_len=case["max_cache_len"])
+        ids = torch.tensor([case["prompt"]], dtype=torch.long, device="cuda")
+        model.gen_config = gcfg
+        steps = list(model._run_granular(ids, gcfg, gcfg.max_new_tokens))
+        got = list(case["prompt"])
+        for new_ids, _ in steps:
+            got.extend(new_ids)
+        assert got[:len(case["prompt"]) + case["max_new_tokens"]] == case["output_ids"]
+        assert [len(s[0]) for s in steps] == case["accept_lengths"]
+
+
+def test_draft_model_api_so(golden):
+    """DraftModel.lookup/update return the reference's tuples (type, tokens, buffers)."""
+    import samd_sam_only as SO
+    case = golden("loop_so.json.gz")[1]
+    cfg = SO.SamdConfig(max_predicts=case["max_predicts"], alpha=case["alpha"], K=case["K"], len_bias=case["len_bias"])
+    draft = SO.DraftModel(cfg, sam_static=SO.build_sam(case["docs"], case["eos"]), device="cuda")
+    draft.reset()
+    draft.update(tokens=torch.tensor(case["prompt"]))
+    from oracle import sam_oracle as O
+    for st in case["trace"]:
+        ty, tokens, buf = draft.lookup(st["tokens"][0])
+        assert ty.value == st["type"] and tokens == st["tokens"]
+        if st["type"] == "sequence":
+            assert buf["seq_position_ids"].tolist() == [list(range(len(tokens)))]
+        else:
+            want = O.gen_buffers(st["anc"])
+            assert buf["tree_attn_mask"].cpu().numpy().tolist() == want["tree_attn_mask"].tolist()
+            assert buf["tree_position_ids"].cpu().numpy().tolist() == want["tree_position_ids"].tolist()
+            assert buf["tree_retrieve_indices"].cpu().numpy().tolist() == want["tree_retrieve_indices"].tolist()
+        draft.update(tokens=torch.tensor(st["accepted"]))
+
+
+def s_model(case):
+    import samd as S
+    cfg = S.SamdConfig(n_predicts=case["n_predicts"], len_threshold=case["len_threshold"], len_bias=case["len_bias"],
+                       tree_method="token_recycle", tree=case["tree"])
+    st = S.build_sam(case["docs"], case["eos"]) if case["use_static"] else None
+    lm = ScriptedVerifier(case["target"], case["vocab"], with_logits=True)
+    draft = S.DraftModel(cfg, sam_static=st, lm=lm, device="cuda")
+    model = S.SamdModel(cfg, lm, draft, case["eos"], torch.float16, "cuda")
+    return S, model
+
+
+@pytest.mark.parametrize("use_graphs", [True, False])
+def test_generate_s_matches_reference_trace(golden, use_graphs):
+    for case in golden("loop_s.json.gz"):
+        S, model = s_model(case)
+        gcfg = S.SamdGenerationConfig(max_new_tokens=case["max_new_tokens"], max_cache_len=case["max_cache_len"])
+        model.set_cache(gcfg)
+        model.engine.use_graphs = use_graphs
+        out = model.generate(torch.tensor([case["prompt"]], dtype=torch.long, device="cuda"), generation_config=gcfg)
+        assert out.output_ids == [case["output_ids"]]
+        assert out.decode_steps == case["decode_steps"]
+        assert out.accepet_length_per_step == case["accept_lengths"]
+
+
+def test_granular_decode_s_matches_reference_trace(golden):
+    case = golden("loop_s.json.gz")[0]
+    S, model = s_model(case)
+    gcfg = S.SamdGenerationConfig(max_new_tokens=case["max_new_tokens"], max_cache_len=case["max_cache_len"])
+    model.gen_config = gcfg
+    steps = list(model._run_granular(torch.tensor([case["prompt"]], dtype=torch.long, device="cuda"), gcfg, gcfg.max_new_tokens))
+    got = list(case["prompt"])
+    for new_ids, _ in steps:
+        got.extend(new_ids)
+    assert got[:len(case["prompt"]) + case["max_new_tokens"]] == case["output_ids"]
+    assert [len(s[0]) for s in steps] == case["accept_lengths"]
+
+
+def test_sam_facades_roundtrip(tmp_path, golden):
+    """StaticSAM / DynSAM stand-alone API + dump_sam/load_sam."""
+    import samd_sam_only as SO
+    from samd_sam_only.sam import DynSAM, StaticSAM
+    from oracle import sam_oracle as O
+    rng = np.random.default_rng(5)
+    docs = [rng.integers(3, 40, 60).tolist() for _ in range(6)] + [[i] for i in range(40)]
+    sam = SO.build_sam(docs, 2)
+    ora = O.StaticSAM.build(docs, 2)
+    path = str(tmp_path / "s.sam")
+    SO.dump_sam(path, sam)
+    sam2 = SO.load_sam(path)
+    stream = rng.integers(3, 40, 50).tolist()
+    for s in (sam, sam2):
+        s.reset()
+        ora.reset()
+        for t in stream:
+            assert s.lookup(t) == ora.lookup(t)
+            s.transfer_tokens([t]); ora.transfer_tokens([t])
+            assert (s.cur_index, s.cur_length) == ora.cursor()
+    i, l = ora.cursor()
+    if l > 0:
+        sam.max_predicts = ora.max_predicts = 20
+        tree, buf = sam.gen_draft(i, l, stream[-1])
+        otree, oanc = ora.gen_draft_tree(i, l, stream[-1])
+        assert tree == otree
+        assert buf["tree_retrieve_indices"].cpu().numpy().tolist() == O.gen_buffers(oanc)["tree_retrieve_indices"].tolist()
+    dyn, odyn = DynSAM(max_predicts=12, alpha=2.0), O.DynSAM(max_predicts=12, alpha=2.0)
+    dyn.reset()
+    text = (stream[:20] + stream[5:18]) * 2
+    dyn.add_tokens(text); odyn.add_tokens(text)
+    assert dyn.input_ids == odyn.export()["text"].tolist()
+    assert (dyn.cur_index, dyn.cur_length) == odyn.cursor()
+    for t in stream[:10]:
+        assert dyn.lookup(t) == odyn.lookup(t)
+    i, l = odyn.lookup(stream[7])
+    assert dyn.gen_draft(i, l, stream[7])[0] == odyn.gen_draft(i, l, stream[7])
+    st = dyn.states
+    e = odyn.export()
+    assert [s.link for s in st] == e["link"].tolist() and [s.min_endpos for s in st] == e["aux"].tolist()
+
+
+def test_cache_select_indices():
+    from samd_sam_only.cache import SamdStaticCache
+    cfg = dict(num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2, hidden_size=512, max_position_embeddings=128)
+    cache = SamdStaticCache(cfg, batch_size=1, max_cache_len=96, device="cuda", dtype=torch.float16, hf_device_map={})
+    g = torch.Generator(device="cuda").manual_seed(0)
+    k0 = torch.randn((1, 2, 10, 128), generator=g, device="cuda").half()
+    for l in range(3):
+        kk, vv = cache.update(k0 + l, k0 - l, l)
+        assert kk.shape == (1, 2, 10, 128)
+    cache.set_length()
+    assert cache.get_seq_length() == 10
+    k1 = torch.randn((1, 2, 7, 128), generator=g, device="cuda").half()
+    for l in range(3):
+        cache.update(k1 + l, k1 - l, l)
+    idx = torch.tensor([0, 2, 5], device="cuda")
+    cache.select_indices(idx, 3)
+    assert cache.cache_length == 13
+    for l in range(3):
+        assert torch.equal(cache.key_cache[l][0, :, 10:13], (k1 + l)[0][:, [0, 2, 5]])
+        assert torch.equal(cache.value_cache[l][0, :, 10:13], (k1 - l)[0][:, [0, 2, 5]])
+        assert torch.equal(cache.key_cache[l][0, :, :10], (k0 + l)[0])
+    cache.select_indices(None, 2)
+    assert cache.cache_length == 15
+    cache.reset()
+    assert cache.get_seq_length() == 0
