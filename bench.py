@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""bench.py -- SAM-Decoding draft+verify hot path on MI355X, BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+Workload (config.workload): BASELINE.json configs[1] -- samd_sam_only on a Vicuna-7B-shaped fp16 Llama, bs=1,
+max_predicts 60 / alpha 4 / len_bias 0 (scripts/inference_samd_sam_only.sh:17-19 of the reference).  There are no
+weights, no Spec-Bench and no SAM pickle on the GPU box, so every input is synthetic and seeded:
+random-init weights of the Vicuna-7B architecture, a sparse order-2 Markov corpus for the static automaton, requests =
+512-token prompts made of copied corpus spans / noise / an in-prompt repeat with 512-token continuations of the same
+process.  The verify forward runs in full every step; its per-node arg-max is then replaced by the request's
+continuation stream (samd_hip.engine.ScriptedAcceptance) so that accept lengths are those of a model that actually
+continues the text -- `--acceptance natural` keeps the random-init model's own arg-max instead.
+
+One "step" = one draft+verify decode step (one hipGraph replay + a 704-byte report read-back).  The timed region is
+exactly K steps (request turnover -- reset, prefill, prompt ingestion -- included when it falls inside), bracketed by
+barrier + synchronize; value = accepted tokens of all ranks / max-over-ranks time.  Requests are independent, so N GPUs
+= N replicas on disjoint request shards with no data-path collective ("scaling": "weak").
+
+Extra objects in the JSON line: `roofline` = the SAM traversal kernel (k_static_walk) in batched-streams form, HIP
+events around the launches, algorithmic bytes = 16 B x visited states; `cpu_baseline` = the C
+oracle (oracle/, a port of the reference's Python SAM path) on this box's host cores over a bounded sample of the same
+request streams; plus the autoregressive baseline, step-time breakdown and verify-forward bandwidth of the same run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "sam-decoding_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+VOCAB, EOS = 32000, 2
+VICUNA_7B = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=32,
+                 vocab_size=VOCAB, max_position_embeddings=2048, rms_norm_eps=1e-6, rope_theta=10000.0)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ---------------------------------------------------------------------------------------------------------------------
+def _succ(a, b, c, vocab):
+    """the c-th successor of context (a, b) in the sparse order-2 Markov source (a fixed hash)."""
+    h = (a.astype(np.uint64) * np.uint64(1000003) + b.astype(np.uint64) * np.uint64(10007) + c.astype(np.uint64) * np.uint64(7919)
+         + np.uint64(12345)) & np.uint64(0x7FFFFFFF)
+    h = (h * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    return (np.uint64(3) + h % np.uint64(vocab - 3)).astype(np.int32)
+
+
+def synth_corpus(n_tokens, vocab=VOCAB, seed=0, doc_len=256):
+    """documents of `doc_len` tokens from the Markov source (4 successors per context, Zipf weights, 2 % noise),
+    followed by every vocabulary id as a one-token document (tools/gen_sam_alpaca_sam_only.py:43-44)."""
+    rng = np.random.default_rng(seed)
+    n_docs = max(1, n_tokens // doc_len)
+    w = np.array([1.0 / (i + 1) for i in range(4)])
+    w /= w.sum()
+    docs = np.empty((n_docs, doc_len), np.int32)
+    docs[:, :2] = rng.integers(3, vocab, (n_docs, 2))
+    choice = rng.choice(4, size=(n_docs, doc_len), p=w)
+    noise = rng.random((n_docs, doc_len)) < 0.02
+    noise_tok = rng.integers(3, vocab, (n_docs, doc_len)).astype(np.int32)
+    for i in range(2, doc_len):                       # vectorised over documents
+        t = _succ(docs[:, i - 2], docs[:, i - 1], choice[:, i], vocab)
+        docs[:, i] = np.where(noise[:, i], noise_tok[:, i], t)
+    flat = np.concatenate([docs.reshape(-1), np.arange(vocab, dtype=np.int32)])
+    off = np.concatenate([np.arange(n_docs + 1, dtype=np.int64) * doc_len, n_docs * doc_len + 1 + np.arange(vocab, dtype=np.int64)])
+    return flat, off, docs
+
+
+def synth_request(rng, docs, vocab=VOCAB, prompt_len=512, total_len=2048):
+    """prompt + continuation: alternating copied corpus spans (geometric, mean 16), fresh noise (mean 4) and repeats of
+    earlier text of the same request (mean 12)."""
+    out = []
+    n_docs, doc_len = docs.shape
+    while len(out) < total_len:
+        r = rng.random()
+        if r < 0.55:
+            ln = int(rng.geometric(1 / 16.0))
+            d, s = int(rng.integers(0, n_docs)), int(rng.integers(0, doc_len - 1))
+            out.extend(docs[d, s:s + ln].tolist())
+        elif r < 0.80 and len(out) > 32:
+            ln = int(rng.geometric(1 / 12.0))
+            s = int(rng.integers(0, len(out) - 8))
+            out.extend(out[s:s + ln])
+        else:
+            out.extend(rng.integers(3, vocab, int(rng.geometric(1 / 4.0))).tolist())
+    out = [t if t != EOS else 3 for t in out[:total_len]]
+    return out[:prompt_len], out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def hip_time_ms(fn, iters):
+    """average duration of fn() in ms, HIP events on the stream fn launches on (torch's current stream)."""
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def walk_roofline(sam, docs, rng, B, T, iters):
+    """the SAM traversal kernel in batched-streams form: B independent cursors x T tokens per launch."""
+    import torch
+    n_docs, doc_len = docs.shape
+    # token streams: copied corpus spans with 10 % noise, time-major [T, B]
+    d = rng.integers(0, n_docs, B)
+    s = rng.integers(0, doc_len - T, B)
+    toks = docs[d[None, :], (s[None, :] + np.arange(T)[:, None])]
+    noise = rng.random((T, B)) < 0.10
+    toks = np.where(noise, rng.integers(3, VOCAB, (T, B)), toks).astype(np.int32)
+    d_toks = torch.from_numpy(np.ascontiguousarray(toks)).cuda()
+    cursors = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    sam.walk(cursors, d_toks, commit=False, visited=visited)
+    torch.cuda.synchronize()
+    n_visited = int(visited.item())
+    ms = hip_time_ms(lambda: sam.walk(cursors, d_toks, commit=False), iters)
+    alg_bytes = 16.0 * n_visited
+    gbps = alg_bytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="k_static_walk", achieved=round(gbps, 2), peak=HBM_PEAK_GBPS, unit="GB/s",
+                frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=None, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
+                visited_states=n_visited, alg_bytes_per_launch=int(alg_bytes), transitions_per_s=round(B * T / (ms * 1e-3), 1),
+                line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2)), toks
+
+
+def cpu_baseline(flat, off, requests, cfg, toks_walk, budget_s=12.0):
+    """the C oracle (single thread, like the reference's Python) on the same request streams: per step
+    lookup -> draft(+buffers) -> greedy accept against the continuation -> update; and the batched walk's CPU twin."""
+    from oracle import sam_oracle as O
+    t0 = time.perf_counter()
+    n_build = min(len(off) - 1, 4096 + VOCAB)           # bounded corpus sample for the CPU automaton
+    keep = np.r_[0:4096, len(off) - 1 - VOCAB:len(off) - 1] if len(off) - 1 > n_build else np.arange(len(off) - 1)
+    docs_list = [flat[off[i]:off[i + 1]].tolist() for i in keep]
+    st = O.StaticSAM.build(docs_list, EOS)
+    build_s = time.perf_counter() - t0
+    dm = O.DraftModel(cfg["max_predicts"], cfg["alpha"], cfg["K"], cfg["len_bias"], sam_static=st)
+    spent, steps, tokens = 0.0, 0, 0
+    for prompt, target in requests:
+        dm.reset()
+        t = time.perf_counter()
+        dm.update(prompt)
+        spent += time.perf_counter() - t
+        pos = len(prompt)
+        while pos < len(prompt) + 512 and pos + 70 < len(target) and spent < budget_s:
+            t = time.perf_counter()
+            ty, tok, anc = dm.lookup_raw(target[pos])
+            if ty == 1:
+                O.gen_buffers(anc)
+            spent += time.perf_counter() - t
+            # scripted greedy verdict: longest root->node path that follows the continuation
+            depth = [0] * len(tok)
+            ok = [True] * len(tok)
+            best = 0
+            for i in range(1, len(tok)):
+                depth[i] = depth[anc[i]] + 1
+                ok[i] = ok[anc[i]] and tok[i] == target[pos + depth[i]]
+                if ok[i] and depth[i] > depth[best]:
+                    best = i
+            acc = target[pos:pos + depth[best] + 1]
+            t = time.perf_counter()
+            dm.update(acc)
+            spent += time.perf_counter() - t
+            pos += len(acc)
+            steps += 1
+            tokens += len(acc)
+        if spent >= budget_s:
+            break
+    # CPU twin of the batched walk (transitions/s, one thread)
+    T, B = toks_walk.shape
+    nb = min(B, 4096)
+    t = time.perf_counter()
+    for b in range(nb):
+        st.reset()
+        st.transfer_tokens(toks_walk[:, b])
+    walk_s = time.perf_counter() - t
+    return dict(value=round(tokens / max(spent, 1e-9), 1), unit="tokens/s", cores=1, kind="port",
+                sample=f"oracle/sam_oracle.c DraftModel loop (lookup+draft+buffers+update, no LM forward) over {steps} steps of the "
+                       f"same request streams, static automaton from {len(docs_list)} documents ({build_s:.1f} s build); "
+                       f"walk twin: {nb} streams x {T} tokens",
+                steps=steps, us_per_step=round(spent / max(steps, 1) * 1e6, 2), host_cores_available=os.cpu_count(),
+                walk_transitions_per_s=round(nb * T / max(walk_s, 1e-9), 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--corpus-tokens", type=int, default=1 << 22)
+    ap.add_argument("--acceptance", choices=["scripted", "natural"], default="scripted")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the result is then not a benchmark)")
+    ap.add_argument("--walk-streams", type=int, default=1 << 20)
+    ap.add_argument("--walk-tokens", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import samd_hip
+    import samd_sam_only as SO
+    from samd_hip.engine import ScriptedAcceptance
+    from samd_hip.llama import LlamaRunner
+    from samd_hip import parallel
+
+    t_setup = time.perf_counter()
+    cfg = dict(max_predicts=60, alpha=4.0, K=8, len_bias=0)
+    flat, off, docs = synth_corpus(args.corpus_tokens)
+    # rank 0 builds the automaton; the other ranks receive the flat image over RCCL (north_star: shared static SAM broadcast)
+    auto = samd_hip.StaticAutomaton.build_flat(flat, off, EOS, samd_hip.KIND_COUNT) if rank == 0 else None
+    build_s = time.perf_counter() - t_setup
+    auto = parallel.broadcast_static(auto, src=0) if world > 1 else auto.upload()
+    sam_info = auto.info()
+    sam = SO.sam.StaticSAM._from_automaton(auto)
+
+    mcfg = dict(VICUNA_7B)
+    if args.layers:
+        mcfg["num_hidden_layers"] = args.layers
+    max_len = mcfg["max_position_embeddings"]
+    runner = LlamaRunner.random_init(mcfg, max_len, torch.float16, seed=0)
+    lm = ScriptedAcceptance(runner, VOCAB, max_len) if args.acceptance == "scripted" else runner
+
+    samd_cfg = SO.SamdConfig(**cfg)
+    model = SO.SamdModel(samd_cfg, lm, SO.DraftModel(samd_cfg, sam_static=sam, device="cuda"), EOS, torch.float16, "cuda")
+    gcfg = SO.SamdGenerationConfig(max_new_tokens=512, max_cache_len=max_len)
+    model.set_cache(gcfg)
+    model.engine.use_graphs = not args.no_graphs
+
+    rng = np.random.default_rng(1000 + rank)           # disjoint request shards per rank
+
+    def requests():
+        while True:
+            prompt, target = synth_request(rng, docs)
+            if args.acceptance == "scripted":
+                lm.set_target(target)
+            yield prompt, target
+
+    req_log = []
+
+    def steps_forever():
+        for prompt, target in requests():
+            req_log.append((prompt, target))
+            ids = torch.tensor([prompt], dtype=torch.long, device="cuda")
+            for new_ids, rep in model._run(ids, gcfg, gcfg.max_new_tokens):
+                yield len(new_ids)
+
+    it = steps_forever()
+    for _ in range(args.warmup):
+        next(it)
+    for v in model.lookup_stats.values():
+        v[0] = v[1] = 0
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    tokens = 0
+    for _ in range(args.steps):
+        tokens += next(it)
+    fence()
+    dt = time.perf_counter() - t0
+    stats = {k: list(v) for k, v in model.lookup_stats.items()}
+
+    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tok_all = torch.tensor([tokens], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tok_all, op=dist.ReduceOp.SUM)
+    dt_max, tokens_total = float(t_all.item()), float(tok_all.item())
+
+    out = None
+    if rank == 0:
+        # ---- same-run context numbers (rank 0, outside the timed region) --------------------------------------------
+        eng = model.engine
+        sess = eng.session
+        breakdown = {}
+        for R in sorted(eng._graphs):
+            g_full = eng._graphs[R]
+            eng.start(torch.tensor([req_log[-1][0]], dtype=torch.long, device="cuda"))   # rewind: replays advance the request
+            ms_full = hip_time_ms(g_full.replay, 10)
+            gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf):
+                lm.verify(sess, R)
+            ms_fwd = hip_time_ms(gf.replay, 10)
+            breakdown[str(R)] = dict(step_ms=round(ms_full, 4), lm_forward_ms=round(ms_fwd, 4),
+                                     overhead_frac=round((ms_full - ms_fwd) / ms_full, 4),
+                                     weight_gbps=round(runner.weight_bytes() / (ms_fwd * 1e-3) / 1e9, 1))
+        # autoregressive baseline: same kernels, max_predicts = 1 (the reference's cli_baseline.py does exactly this)
+        ar_cfg = SO.SamdConfig(max_predicts=1, alpha=4.0, K=8, len_bias=0)
+        ar = SO.SamdModel(ar_cfg, lm, SO.DraftModel(ar_cfg, device="cuda"), EOS, torch.float16, "cuda")
+        ar.set_cache(gcfg)
+        prompt, target = req_log[0]
+        if args.acceptance == "scripted":
+            lm.set_target(target)
+        ar_it = ar._run(torch.tensor([prompt], dtype=torch.long, device="cuda"), gcfg, 96)
+        for _ in range(16):
+            next(ar_it)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        ar_tokens = sum(len(next(ar_it)[0]) for _ in range(64))
+        torch.cuda.synchronize()
+        ar_tps = ar_tokens / (time.perf_counter() - ta)
+
+        roof, toks_walk = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20)
+        cpu = None if args.no_cpu_baseline else cpu_baseline(flat, off, req_log[:4], cfg, toks_walk)
+
+        n_steps = sum(v[0] for v in stats.values())
+        n_tok = sum(v[1] for v in stats.values())
+        value = tokens_total / dt_max
+        out = {
+            "metric": "tokens/sec (+ mean accepted tokens), Vicuna-7B bs=1, samd_sam_only draft+verify",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic: random-init Vicuna-7B-shaped weights (seed 0), seeded Markov corpus + request streams; "
+                                    + ("LM arg-max replaced after the full forward by each request's continuation stream"
+                                       if args.acceptance == "scripted" else "the random-init model's own arg-max"),
+            "config": {"workload": "BASELINE.json configs[1]: samd_sam_only, Vicuna-7B-v1.3 shape fp16, bs=1, max_predicts 60, alpha 4, "
+                                   "len_bias 0, K 8; prompts 512 tokens, max_new_tokens 512, max_cache_len 2048",
+                       "layers": mcfg["num_hidden_layers"], "corpus_tokens": int(args.corpus_tokens),
+                       "static_sam_states": int(sam_info["n_states"]), "static_sam_bytes": int(sam_info["device_bytes"]),
+                       "acceptance": args.acceptance, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
+                       "hipgraphs": not args.no_graphs},
+            "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
+            "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
+            "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
+            "step_breakdown_by_rows": breakdown,
+            "roofline": roof, "cpu_baseline": cpu,
+            "setup": {"static_build_s": round(build_s, 2), "host": f"{os.cpu_count()} cores"},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,12 @@ int samd_static_export(const samd_static_t *sam, int32_t *h_link, int32_t *h_len
 /* device pointers of the HBM image, for callers that broadcast it with RCCL (multi-GPU request
  * parallelism): out[0]=nodes, out[1]=root table, out[2]=spill edges, out[3]=text; bytes in out_bytes[]. */
 int samd_static_device_image(const samd_static_t *sam, void *out_ptrs[4], int64_t out_bytes[4]);
+/* host pointers of the flat image (same four regions), for a host-side broadcast (gloo) or custom I/O */
+int samd_static_host_image(const samd_static_t *sam, void *out_ptrs[4], int64_t out_bytes[4]);
+/* rebuild a handle from the four regions received from another rank: host copy (then samd_static_upload) ... */
+int samd_static_from_host_image(const int64_t info[8], const void *const h_ptrs[4], samd_static_t **out);
+/* ... or adopt device buffers the caller owns (e.g. torch tensors filled by an RCCL broadcast); the handle borrows them */
+int samd_static_adopt_device(const int64_t info[8], void *const d_ptrs[4], samd_static_t **out);
 /* create an un-filled device image of the same shape on this rank (to receive a broadcast) */
 int samd_static_alloc_like(const int64_t info[8], samd_static_t **out);
 

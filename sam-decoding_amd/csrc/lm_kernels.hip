@@ -85,6 +85,7 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
     const int r = blockIdx.x, hh = blockIdx.y, j = threadIdx.x, half = D >> 1;
     if (r >= d_n[0]) return;
     const int L = d_L[0];
+    if (L + r >= max_len) return;                              // never write past the cache (the host guard breaks earlier)
     const T *src = qkv + ((size_t)r * (H + 2 * Hkv) + hh) * D;
     if (hh >= H + Hkv) {                                       // V: plain copy
         T *dst = v_cache + ((size_t)(hh - H - Hkv) * max_len + L + r) * D;

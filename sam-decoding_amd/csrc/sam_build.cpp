@@ -223,10 +223,12 @@ int samd_static_from_tables(int32_t kind, int64_t n_states, const int32_t *h_lin
 void samd_static_free(samd_static_t *s) {
     if (!s) return;
     free(s->h_nodes); free(s->h_root); free(s->h_spill); free(s->h_text);
-    if (s->d_nodes) (void)hipFree(s->d_nodes);
-    if (s->d_root) (void)hipFree(s->d_root);
-    if (s->d_spill) (void)hipFree(s->d_spill);
-    if (s->d_text) (void)hipFree(s->d_text);
+    if (!s->borrowed) {
+        if (s->d_nodes) (void)hipFree(s->d_nodes);
+        if (s->d_root) (void)hipFree(s->d_root);
+        if (s->d_spill) (void)hipFree(s->d_spill);
+        if (s->d_text) (void)hipFree(s->d_text);
+    }
     free(s);
 }
 
@@ -339,6 +341,46 @@ int samd_static_device_image(const samd_static_t *s, void *out_ptrs[4], int64_t 
     out_ptrs[1] = s->d_root; out_bytes[1] = s->vocab * 4;
     out_ptrs[2] = s->d_spill; out_bytes[2] = s->n_spill * 8;
     out_ptrs[3] = s->d_text; out_bytes[3] = s->n_text * 4;
+    return SAMD_OK;
+}
+
+int samd_static_host_image(const samd_static_t *s, void *out_ptrs[4], int64_t out_bytes[4]) {
+    if (!s || !s->h_nodes || !out_ptrs || !out_bytes) { samd_set_error("samd_static_host_image: no host image"); return SAMD_E_INVALID; }
+    out_ptrs[0] = s->h_nodes; out_bytes[0] = s->n_states * (int64_t)sizeof(SamNode);
+    out_ptrs[1] = s->h_root; out_bytes[1] = s->vocab * 4;
+    out_ptrs[2] = s->h_spill; out_bytes[2] = s->n_spill * 8;
+    out_ptrs[3] = s->h_text; out_bytes[3] = s->n_text * 4;
+    return SAMD_OK;
+}
+
+static samd_static_t *shell_from_info(const int64_t info[8]) {
+    samd_static_t *s = (samd_static_t *)calloc(1, sizeof(samd_static_t));
+    s->n_states = info[0]; s->n_edges = info[1]; s->n_spill = info[2]; s->vocab = info[3];
+    s->kind = (int32_t)info[5]; s->n_text = info[6];
+    return s;
+}
+
+int samd_static_from_host_image(const int64_t info[8], const void *const h_ptrs[4], samd_static_t **out) {
+    if (!info || !h_ptrs || !out || info[0] < 1 || !h_ptrs[0]) { samd_set_error("samd_static_from_host_image: invalid argument"); return SAMD_E_INVALID; }
+    samd_static_t *s = shell_from_info(info);
+    if (posix_memalign((void **)&s->h_nodes, 64, (size_t)s->n_states * sizeof(SamNode))) { free(s); return SAMD_E_CAPACITY; }
+    s->h_root = (int32_t *)malloc(std::max<int64_t>(1, s->vocab) * 4);
+    s->h_spill = (SamEdge *)malloc(std::max<int64_t>(1, s->n_spill) * 8);
+    s->h_text = (int32_t *)malloc(std::max<int64_t>(1, s->n_text) * 4);
+    memcpy(s->h_nodes, h_ptrs[0], (size_t)s->n_states * sizeof(SamNode));
+    if (s->vocab && h_ptrs[1]) memcpy(s->h_root, h_ptrs[1], (size_t)s->vocab * 4);
+    if (s->n_spill && h_ptrs[2]) memcpy(s->h_spill, h_ptrs[2], (size_t)s->n_spill * 8);
+    if (s->n_text && h_ptrs[3]) memcpy(s->h_text, h_ptrs[3], (size_t)s->n_text * 4);
+    *out = s;
+    return SAMD_OK;
+}
+
+int samd_static_adopt_device(const int64_t info[8], void *const d_ptrs[4], samd_static_t **out) {
+    if (!info || !d_ptrs || !out || info[0] < 1 || !d_ptrs[0]) { samd_set_error("samd_static_adopt_device: invalid argument"); return SAMD_E_INVALID; }
+    samd_static_t *s = shell_from_info(info);
+    s->d_nodes = (SamNode *)d_ptrs[0]; s->d_root = (int32_t *)d_ptrs[1]; s->d_spill = (SamEdge *)d_ptrs[2]; s->d_text = (int32_t *)d_ptrs[3];
+    s->uploaded = 1; s->borrowed = 1;
+    *out = s;
     return SAMD_OK;
 }
 

@@ -91,6 +91,7 @@ struct samd_static {
     SamEdge *d_spill;
     int32_t *d_text;
     int uploaded;
+    int borrowed;               // device image owned by the caller (samd_static_adopt_device)
 };
 
 void samd_set_error(const char *fmt, ...);

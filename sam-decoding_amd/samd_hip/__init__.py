@@ -62,6 +62,9 @@ _PROTOS = {
     "samd_static_export": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_static_device_image": (C.c_int, [_VP, _VP, _VP]),
     "samd_static_alloc_like": (C.c_int, [_VP, _VP]),
+    "samd_static_host_image": (C.c_int, [_VP, _VP, _VP]),
+    "samd_static_from_host_image": (C.c_int, [_VP, _VP, _VP]),
+    "samd_static_adopt_device": (C.c_int, [_VP, _VP, _VP]),
     "samd_static_walk": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "samd_static_walk_counted": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "samd_session_create": (C.c_int, [_I32, _VP]),
@@ -238,6 +241,41 @@ class StaticAutomaton:
         ptrs, nbytes = (C.c_void_p * 4)(), (C.c_int64 * 4)()
         check(lib().samd_static_device_image(self._h, ptrs, nbytes))
         return [(ptrs[i], nbytes[i]) for i in range(4)]
+
+    def host_image(self):
+        """numpy uint8 views of the four host regions (nodes, root table, spill edges, text)."""
+        ptrs, nbytes = (C.c_void_p * 4)(), (C.c_int64 * 4)()
+        check(lib().samd_static_host_image(self._h, ptrs, nbytes))
+        out = []
+        for i in range(4):
+            n = int(nbytes[i])
+            out.append(np.ctypeslib.as_array((C.c_uint8 * n).from_address(ptrs[i])) if n else np.zeros(0, np.uint8))
+        return out
+
+    def info_array(self):
+        out = (C.c_int64 * 8)()
+        check(lib().samd_static_info(self._h, out))
+        return np.array(list(out), dtype=np.int64)
+
+    @classmethod
+    def from_host_image(cls, info, regions):
+        arr = (C.c_int64 * 8)(*[int(x) for x in info])
+        regs = [np.ascontiguousarray(r, dtype=np.uint8) for r in regions]
+        ptrs = (C.c_void_p * 4)(*[r.ctypes.data if r.size else None for r in regs])
+        h = C.c_void_p()
+        check(lib().samd_static_from_host_image(arr, ptrs, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def adopt_device(cls, info, tensors):
+        """wrap four device tensors (kept alive by the returned object) as the HBM image."""
+        arr = (C.c_int64 * 8)(*[int(x) for x in info])
+        ptrs = (C.c_void_p * 4)(*[t.data_ptr() if t.numel() else None for t in tensors])
+        h = C.c_void_p()
+        check(lib().samd_static_adopt_device(arr, ptrs, C.byref(h)))
+        obj = cls(h)
+        obj._keep = list(tensors)
+        return obj
 
     # ---- batched walk --------------------------------------------------------------------------
     def walk(self, cursors, tokens, commit=True, trace=None, visited=None):

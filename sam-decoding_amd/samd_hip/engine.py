@@ -112,6 +112,45 @@ class ScriptedVerifier:
         return MAX_DRAFT
 
 
+class ScriptedAcceptance:
+    """bench.py's acceptance model: the FULL verify forward of `runner` runs (every kernel, every weight byte), then the
+    per-node arg-max is replaced by the next token of a seeded target stream (samd_scripted_argmax).  Without model
+    weights or Spec-Bench on the box this is what gives the run realistic, reproducible accept lengths; a random-init
+    LM on its own decodes degenerate loops.  The target buffer has a fixed address and length so the step stays one
+    hipGraph across requests."""
+
+    def __init__(self, runner, vocab, target_len):
+        self.runner, self.vocab, self.target_len = runner, int(vocab), int(target_len)
+        self.target = torch.zeros(self.target_len, dtype=torch.int32, device=runner.device)
+        self.pf_mask = runner.pf_mask
+        self._prompt_len = 0
+
+    def set_target(self, target):
+        t = torch.as_tensor(np.asarray(target, dtype=np.int32))[:self.target_len]
+        self.target.zero_()
+        self.target[:t.numel()] = t.to(self.target.device)
+
+    def prefill(self, session, input_ids, on_chunk=None):
+        last = self.runner.prefill(session, input_ids, on_chunk)
+        n = input_ids.numel()
+        session.set_start_token(self.target[n:n + 1])          # the scripted LM's continuation of the prompt
+        return last
+
+    def verify(self, session, R):
+        b = self.runner.verify(session, R)
+        session.scripted_argmax(self.target, self.target_len, self.vocab, b["argmax"])
+        return b
+
+    def compact(self, session):
+        self.runner.compact(session)
+
+    def bucket(self, n):
+        return self.runner.bucket(n)
+
+    def warm(self, R):
+        self.runner.warm(R)
+
+
 class DecodeEngine:
     def __init__(self, verifier, session: Session, static: StaticAutomaton, params: Params, recycle: TokenRecycleTable = None,
                  recycle_parent=None, use_graphs=True):

@@ -1,0 +1,76 @@
+"""Request-level data parallelism over the GPUs of one node.
+
+The reference's only parallelism is Ray actors that each run the whole model on a contiguous chunk of the question
+list and append to a shared jsonl (evaluation/eval_vicuna.py:39-68, :233-258).  Here: one process per GPU
+(torch.distributed; backend "nccl" = RCCL over xGMI), the static automaton's flat image is broadcast once from rank 0,
+every rank decodes its own request shard with its own dynamic automaton and KV cache, and the padded results are
+all-gathered at the end.  Nothing on the per-step path communicates.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import StaticAutomaton
+
+
+def shard_bounds(n_items, world, rank):
+    """contiguous chunks as eval_vicuna.py:50-65: chunk = n // world per worker, the remainder goes to the last one
+    (the reference spawns one extra tail task; a fixed world folds it into the last rank)."""
+    chunk = n_items // world
+    lo = rank * chunk
+    hi = n_items if rank == world - 1 else lo + chunk
+    return lo, hi
+
+
+def broadcast_static(auto, src=0, device=None):
+    """rank `src` passes its built StaticAutomaton, the others pass None; every rank returns an uploaded automaton.
+    With a CUDA device the four image regions travel GPU-to-GPU (RCCL) into torch-owned buffers that the handle
+    adopts; on CPU (gloo, tests) the host image is broadcast and rebuilt."""
+    rank = dist.get_rank()
+    use_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
+    info = torch.zeros(8, dtype=torch.int64, device=dev)
+    if rank == src:
+        info.copy_(torch.from_numpy(auto.info_array()))
+    dist.broadcast(info, src)
+    info_h = info.cpu().numpy()
+    sizes = [int(info_h[0]) * 64, int(info_h[3]) * 4, int(info_h[2]) * 8, int(info_h[6]) * 4]
+    regions = []
+    host = auto.host_image() if rank == src else None
+    for i, nbytes in enumerate(sizes):
+        if rank == src:
+            t = torch.from_numpy(host[i]).to(dev) if nbytes else torch.zeros(0, dtype=torch.uint8, device=dev)
+        else:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        if nbytes:
+            dist.broadcast(t, src)
+        regions.append(t)
+    if use_gpu:
+        return StaticAutomaton.adopt_device(info_h, regions)
+    out = StaticAutomaton.from_host_image(info_h, [r.numpy() for r in regions])
+    return out
+
+
+def gather_results(rows, pad=-1, device=None):
+    """all-gather of ragged int rows (one per local request: output ids, or [new_tokens, steps, ...] stats) ->
+    list over ranks of lists of rows.  Padded to the global max length, lengths travel alongside."""
+    world = dist.get_world_size()
+    use_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
+    n_local = torch.tensor([len(rows), max([len(r) for r in rows], default=0)], dtype=torch.int64, device=dev)
+    dims = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(dims, n_local)
+    n_max = max(int(d[0]) for d in dims)
+    l_max = max(int(d[1]) for d in dims)
+    buf = torch.full((n_max, l_max + 1), pad, dtype=torch.int64, device=dev)
+    for i, r in enumerate(rows):
+        buf[i, 0] = len(r)
+        if len(r):
+            buf[i, 1:1 + len(r)] = torch.as_tensor(np.asarray(r, dtype=np.int64)).to(dev)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    res = []
+    for w in range(world):
+        o = out[w].cpu().numpy()
+        res.append([o[i, 1:1 + o[i, 0]].tolist() for i in range(int(dims[w][0]))])
+    return res
