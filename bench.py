@@ -108,7 +108,7 @@ def hip_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def walk_roofline(sam, docs, rng, B, T, iters):
+def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
     """the SAM traversal kernel in batched-streams form: B independent cursors x T tokens per launch."""
     import torch
     n_docs, doc_len = docs.shape
@@ -127,8 +127,18 @@ def walk_roofline(sam, docs, rng, B, T, iters):
     ms = hip_time_ms(lambda: sam.walk(cursors, d_toks, commit=False), iters)
     alg_bytes = 16.0 * n_visited
     gbps = alg_bytes / (ms * 1e-3) / 1e9
+    # HBM traffic per launch from the PMC passes of the same kernel and configuration (collected separately with
+    # rocprofv3 --pmc, scripts/pmc_walk.sh; profiles/walk_pmc.json) -- null when the configuration differs
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "walk_pmc.json")))
+        c = pmc["config"]
+        if (c["corpus_tokens"], c["streams"], c["tokens_per_stream"]) == (sam_tokens, B, T):
+            traffic = int(pmc["fetch_bytes_per_launch"] * pmc["fetch_size_correction"] + pmc["write_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     return dict(bound="hbm", kernel="k_static_walk", achieved=round(gbps, 2), peak=HBM_PEAK_GBPS, unit="GB/s",
-                frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=None, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
+                frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=traffic, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
                 visited_states=n_visited, alg_bytes_per_launch=int(alg_bytes), transitions_per_s=round(B * T / (ms * 1e-3), 1),
                 line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2)), toks
 
@@ -325,7 +335,7 @@ def main():
         torch.cuda.synchronize()
         ar_tps = ar_tokens / (time.perf_counter() - ta)
 
-        roof, toks_walk = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20)
+        roof, toks_walk = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20, args.corpus_tokens)
         cpu = None if args.no_cpu_baseline else cpu_baseline(flat, off, req_log[:4], cfg, toks_walk)
 
         n_steps = sum(v[0] for v in stats.values())

@@ -135,7 +135,7 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
     int64_t n_edges = 0, n_spill = 0;
     int32_t max_root_tok = -1;
     for (int64_t i = 0; i < n_states; i++) {
-        if (deg[i] > SAMD_INLINE_EDGES) n_spill += SAMD_SPILL_HEAD + deg[i] - SAMD_INLINE_EDGES;
+        if (deg[i] > SAMD_INLINE_EDGES) n_spill += SAMD_SPILL_HEAD + samd_spill_slots(deg[i]);
         n_edges += deg[i];
     }
     for (int32_t j = 0; j < deg[0]; j++) max_root_tok = std::max(max_root_tok, edge_tok[j]);
@@ -153,8 +153,10 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
     for (int64_t i = 0; i < n_states; i++) {
         const int32_t d = deg[i];
         SamNode &nd = s->h_nodes[i];
-        nd.link = link[i]; nd.length = length[i]; nd.aux = aux[i]; nd.deg = d; nd.spill = -1; nd.reserved = 0;
-        for (int j = 0; j < 2 * SAMD_INLINE_EDGES; j++) nd.e[j] = -1;
+        if (length[i] < 0 || length[i] >= SAMD_SINGLE) { samd_static_free(s); samd_set_error("state length out of range"); return SAMD_E_CAPACITY; }
+        nd.link = link[i]; nd.length = length[i] | (d <= 1 ? SAMD_SINGLE : 0); nd.aux = aux[i]; nd.deg = d; nd.spill = -1; nd.reserved = 0;
+        int32_t *words = reinterpret_cast<int32_t *>(&nd);
+        for (int j = 0; j < SAMD_INLINE_EDGES; j++) { words[SAMD_EDGE_WORD(j)] = -1; words[SAMD_EDGE_WORD(j) + 1] = -1; }
         row.resize(d);
         for (int32_t j = 0; j < d; j++) {
             int32_t dst = edge_dst[ebase + j];
@@ -168,16 +170,22 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
         std::partial_sort(row.begin(), row.begin() + top, row.end(), [](const Ranked &a, const Ranked &b) {
             return a.key != b.key ? a.key > b.key : a.order < b.order;
         });
-        for (int32_t j = 0; j < std::min<int32_t>(d, SAMD_INLINE_EDGES); j++) { nd.e[2 * j] = row[j].tok; nd.e[2 * j + 1] = row[j].dst; }
+        for (int32_t j = 0; j < std::min<int32_t>(d, SAMD_INLINE_EDGES); j++) { words[SAMD_EDGE_WORD(j)] = row[j].tok; words[SAMD_EDGE_WORD(j) + 1] = row[j].dst; }
         if (d > SAMD_INLINE_EDGES) {
             nd.spill = (int32_t)sp;
             for (int32_t j = 0; j < SAMD_SPILL_HEAD; j++) {
                 int32_t r = SAMD_INLINE_EDGES + j;
                 s->h_spill[sp + j] = r < d ? SamEdge{ row[r].tok, row[r].dst } : SamEdge{ -1, -1 };
             }
-            std::sort(row.begin() + SAMD_INLINE_EDGES, row.end(), [](const Ranked &a, const Ranked &b) { return a.tok < b.tok; });
-            for (int32_t j = SAMD_INLINE_EDGES; j < d; j++) s->h_spill[sp + SAMD_SPILL_HEAD + j - SAMD_INLINE_EDGES] = { row[j].tok, row[j].dst };
-            sp += SAMD_SPILL_HEAD + d - SAMD_INLINE_EDGES;
+            const uint32_t m = samd_spill_slots(d);
+            SamEdge *tab = s->h_spill + sp + SAMD_SPILL_HEAD;
+            for (uint32_t j = 0; j < m; j++) tab[j] = SamEdge{ -1, -1 };
+            for (int32_t j = SAMD_INLINE_EDGES; j < d; j++) {
+                uint32_t h = samd_spill_hash(row[j].tok, m);
+                while (tab[h].tok != -1) h = (h + 1) & (m - 1);
+                tab[h] = SamEdge{ row[j].tok, row[j].dst };
+            }
+            sp += SAMD_SPILL_HEAD + m;
         }
         ebase += d;
     }
@@ -247,22 +255,29 @@ int samd_static_export(const samd_static_t *s, int32_t *h_link, int32_t *h_lengt
     for (int64_t i = 0; i < s->n_states; i++) {
         const SamNode &nd = s->h_nodes[i];
         if (h_link) h_link[i] = nd.link;
-        if (h_length) h_length[i] = nd.length;
+        if (h_length) h_length[i] = nd.length & ~SAMD_SINGLE;
         if (h_aux) h_aux[i] = nd.aux;
         if (h_deg) h_deg[i] = nd.deg;
         if (!h_edge_tok || !h_edge_dst) continue;
         const int32_t d = nd.deg;
-        for (int32_t j = 0; j < std::min<int32_t>(d, SAMD_INLINE_EDGES); j++) { h_edge_tok[k] = nd.e[2 * j]; h_edge_dst[k] = nd.e[2 * j + 1]; k++; }
+        const int32_t *words = reinterpret_cast<const int32_t *>(&nd);
+        for (int32_t j = 0; j < std::min<int32_t>(d, SAMD_INLINE_EDGES); j++) { h_edge_tok[k] = words[SAMD_EDGE_WORD(j)]; h_edge_dst[k] = words[SAMD_EDGE_WORD(j) + 1]; k++; }
         if (d > SAMD_INLINE_EDGES) {
             const SamEdge *sp = s->h_spill + nd.spill;
             int32_t nhead = std::min<int32_t>(d, SAMD_TOPK) - SAMD_INLINE_EDGES;
             for (int32_t j = 0; j < nhead; j++) { h_edge_tok[k] = sp[j].tok; h_edge_dst[k] = sp[j].dst; k++; }
-            for (int32_t j = 0; j < d - SAMD_INLINE_EDGES; j++) {
+            // the hashed remainder, ascending by token (the order the export contract promises)
+            std::vector<SamEdge> rest;
+            const uint32_t m = samd_spill_slots(d);
+            for (uint32_t j = 0; j < m; j++) {
                 const SamEdge &e = sp[SAMD_SPILL_HEAD + j];
+                if (e.tok == -1) continue;
                 bool in_head = false;
                 for (int32_t h = 0; h < nhead; h++) in_head |= (sp[h].tok == e.tok);
-                if (!in_head) { h_edge_tok[k] = e.tok; h_edge_dst[k] = e.dst; k++; }
+                if (!in_head) rest.push_back(e);
             }
+            std::sort(rest.begin(), rest.end(), [](const SamEdge &a, const SamEdge &b) { return a.tok < b.tok; });
+            for (const SamEdge &e : rest) { h_edge_tok[k] = e.tok; h_edge_dst[k] = e.dst; k++; }
         }
     }
     return SAMD_OK;

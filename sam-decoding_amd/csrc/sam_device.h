@@ -23,31 +23,21 @@ __device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMI
 // static automaton: one longest-suffix-match transition
 // reference: transfer_state, samd_sam_only/sam/static_sam.py:98-107 (== samd/sam/static_sam.py:81-90)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int spill_search(const SamEdge *tail, int count, int tok) {
-    int lo = 0, hi = count;                       // lower_bound over edges sorted by token
-    while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        int t = tail[mid].tok;
-        if (t < tok) lo = mid + 1; else hi = mid;
+__device__ __forceinline__ int spill_search(const SamEdge *tab, int deg, int tok) {
+    const uint32_t m = samd_spill_slots(deg);       // open addressing, load factor <= 1/2 (samd_common.h)
+    uint32_t h = samd_spill_hash(tok, m);
+    for (uint32_t probes = 0; probes < m; probes++) {
+        const SamEdge e = tab[h];
+        if (e.tok == tok) return e.dst;
+        if (e.tok == -1) return -1;
+        h = (h + 1) & (m - 1);
     }
-    if (lo < count) { SamEdge e = tail[lo]; if (e.tok == tok) return e.dst; }
     return -1;
 }
 
-__device__ __forceinline__ int node_find(const StaticDev &S, const int4 &w0, const int4 &w1, const int4 &w2,
-                                         const int4 &w3, int tok) {
-    int nx = -1;
-    nx = (w1.x == tok) ? w1.y : nx;
-    nx = (w1.z == tok) ? w1.w : nx;
-    nx = (w2.x == tok) ? w2.y : nx;
-    nx = (w2.z == tok) ? w2.w : nx;
-    nx = (w3.x == tok) ? w3.y : nx;
-    if (nx < 0 && w0.w > SAMD_INLINE_EDGES)
-        nx = spill_search(S.spill + w3.z + SAMD_SPILL_HEAD, w0.w - SAMD_INLINE_EDGES, tok);
-    return nx;
-}
-
-// returns the number of states visited (for the bytes-per-visit accounting of the bench)
+// returns the number of states visited (for the bytes-per-visit accounting of the bench).
+// Common case = ONE 16-byte load per visited state (w0: link, length, most frequent successor); the rest of the
+// 64-byte node is read only when that successor is not the token and the state has more edges.
 __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &len, int tok) {
     int visited = 0;
     bool hopped = false;
@@ -60,9 +50,18 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
             return visited;
         }
         const int4 *np = reinterpret_cast<const int4 *>(S.nodes + idx);
-        const int4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-        if (hopped) len = w0.y;                    // length <- states[link].length (static_sam.py:101)
-        int nx = node_find(S, w0, w1, w2, w3, tok);
+        const int4 w0 = np[0];
+        if (hopped) len = w0.y & ~SAMD_SINGLE;     // length <- states[link].length (static_sam.py:101)
+        int nx = (w0.z == tok) ? w0.w : -1;
+        if (nx < 0 && !(w0.y & SAMD_SINGLE)) {
+            const int4 w1 = np[1], w2 = np[2], w3 = np[3];
+            nx = (w1.z == tok) ? w1.w : nx;
+            nx = (w2.x == tok) ? w2.y : nx;
+            nx = (w2.z == tok) ? w2.w : nx;
+            nx = (w3.x == tok) ? w3.y : nx;
+            if (nx < 0 && w1.y > SAMD_INLINE_EDGES)
+                nx = spill_search(S.spill + w3.z + SAMD_SPILL_HEAD, w1.y, tok);
+        }
         if (nx >= 0) { idx = nx; len += 1; return visited; }
         idx = w0.x; hopped = true;
         if (idx == 0) len = 0;
@@ -314,17 +313,17 @@ __device__ __forceinline__ int tree_draft(StepShared &sh, const StaticDev &S, in
         if (m == n) break;
         // expand: the first min(K, 8, deg) successors in top-k order, one lane each
         const int4 *np = reinterpret_cast<const int4 *>(S.nodes + sh.pop_idx);
-        const int4 w0 = np[0];
-        int kk = w0.w < SAMD_TOPK ? w0.w : SAMD_TOPK; kk = kk < K ? kk : K;
+        const int4 w1 = np[1];                                      // {aux = cnt_endpos, deg, e1}
+        int kk = w1.y < SAMD_TOPK ? w1.y : SAMD_TOPK; kk = kk < K ? kk : K;
         if (lane < kk) {
             int tk, ds;
-            if (lane < SAMD_INLINE_EDGES) { const int *e = reinterpret_cast<const int *>(np) + 4 + 2 * lane; tk = e[0]; ds = e[1]; }
+            if (lane < SAMD_INLINE_EDGES) { const int *e = reinterpret_cast<const int *>(np) + SAMD_EDGE_WORD(lane); tk = e[0]; ds = e[1]; }
             else { const int sp = reinterpret_cast<const int *>(np)[14]; const SamEdge ed = S.spill[sp + lane - SAMD_INLINE_EDGES]; tk = ed.tok; ds = ed.dst; }
             sh.c_tok[lane] = tk; sh.c_dst[lane] = ds; sh.c_cnt[lane] = S.nodes[ds].aux;
         }
         __syncthreads();
         if (lane == 0) {
-            const double cnt_sum = (double)w0.z, pp = sh.pop_prob;
+            const double cnt_sum = (double)w1.x, pp = sh.pop_prob;
             const int dep = sh.pop_dep + 1;
             for (int j = 0; j < kk; j++) {
                 const double n_prob = (double)sh.c_cnt[j] / cnt_sum;      // Python int / int

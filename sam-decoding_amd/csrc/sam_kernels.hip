@@ -19,7 +19,13 @@ static inline StaticDev static_view(const samd_static_t *s) {
 }
 
 // ================================================================================================
-// batched walk: one lane per cursor, T tokens each (time-major token matrix => coalesced token loads)
+// batched walk: one lane per cursor, T tokens each (time-major token matrix => coalesced token loads).
+// Per visited state the lane issues ONE 16-byte load in the common case (st_transfer; node word 0 holds the suffix
+// link, the length and the most frequent successor) and high-degree states resolve through a hashed spill block, so
+// the launch generates ~1 HBM request per visited state (profiles/r01_walk_pmc.md: TCC_EA0_RDREQ == visited states)
+// and runs at the memory system's request rate (~48 G requests/s on MI355X, scripts/hbm_probe.hip).  A flattened
+// one-visit-per-iteration state machine with LDS-staged tokens and a lane-quad variant (4 lanes x 16 B per node) were
+// measured and are not faster once the kernel is request-bound; the simple nesting stays.
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__restrict__ cursors,
                                                      const int32_t *__restrict__ tokens, int B, int T, int commit,
@@ -31,7 +37,7 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
         int idx = c.x, len = c.y;
         int tok = tokens[b];
         for (int t = 0; t < T; t++) {
-            const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;   // prefetch the next token
+            const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;
             visited += st_transfer(S, idx, len, tok);
             if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(idx, len);
             tok = nxt;

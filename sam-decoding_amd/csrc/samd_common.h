@@ -4,25 +4,51 @@
 #include <stddef.h>
 #include "../../include/samd_hip.h"
 
-#define SAMD_ABI_VERSION 1
+#define SAMD_ABI_VERSION 2
 #define SAMD_INLINE_EDGES 5        // edges stored inside the 64-byte node
 #define SAMD_SPILL_HEAD 3          // spill block starts with top-k ranks 5,6,7 (-1 padded)
 
-// One automaton state = one 64-byte HBM line (one memory request per visited state).
-//   w0 = {link, length, aux, deg}            aux = cnt_endpos (KIND_COUNT) or min_endpos (KIND_ENDPOS)
-//   w1 = {e0.tok, e0.dst, e1.tok, e1.dst}    edges 0..4 in top-k order (count desc, ties in dict order;
-//   w2 = {e2.tok, e2.dst, e3.tok, e3.dst}    SO/sam/static_sam.py:140-146); empty slots = (-1,-1)
-//   w3 = {e4.tok, e4.dst, spill, reserved}   spill = index of this state's spill block (deg > 5) or -1
-// Spill block of a state with deg > 5:  [rank5, rank6, rank7 (padded (-1,-1))] followed by the
-// deg-5 edges of rank >= 5 sorted ascending by token (binary-searchable).
+// One automaton state = one 64-byte HBM line.  Measured on MI355X (scripts/hbm_probe.hip, profiles/r01_hbm_probe.md):
+// the memory system retires ~48 G requests/s whatever their size; a lane that reads its whole 64-byte node with four
+// dwordx4 loads generates 1.5 requests per node (1.28 TB/s), a lane that reads ONE dwordx4 of it generates exactly one
+// (47 G nodes/s).  So the first 16 bytes hold everything the common transition needs -- suffix link, length and the
+// MOST FREQUENT successor (rank 0 of the top-k order) -- and the other three words are touched only when that misses:
+//   w0 = {link, length | SAMD_SINGLE (deg <= 1), e0.tok, e0.dst}
+//   w1 = {aux, deg, e1.tok, e1.dst}          aux = cnt_endpos (KIND_COUNT) or min_endpos (KIND_ENDPOS)
+//   w2 = {e2.tok, e2.dst, e3.tok, e3.dst}    edges 0..4 in top-k order (count desc, ties in dict order;
+//   w3 = {e4.tok, e4.dst, spill, reserved}   SO/sam/static_sam.py:140-146); empty slots = (-1,-1)
+// spill = index of this state's spill block (deg > 5) or -1.  Spill block of a state with deg > 5:
+// [rank5, rank6, rank7 (padded (-1,-1))] followed by an open-addressing hash table of the deg-5 edges of rank >= 5:
+// samd_spill_slots(deg) slots (a power of two, load factor <= 1/2), slot = samd_spill_hash(tok), linear probing,
+// empty = (-1,-1).  A high-degree state (short context) is resolved in ~1.5 probes of one or two adjacent lines;
+// a sorted block would cost log2(deg) DEPENDENT loads, which is what a wavefront then waits for (profiles/).
+#define SAMD_SINGLE 0x40000000     // flag bit in `length`: the state has at most one outgoing edge
 struct __attribute__((aligned(64))) SamNode {
-    int32_t link, length, aux, deg;
-    int32_t e[2 * SAMD_INLINE_EDGES];
-    int32_t spill, reserved;
+    int32_t link, length, e0_tok, e0_dst;
+    int32_t aux, deg, e1_tok, e1_dst;
+    int32_t e2_tok, e2_dst, e3_tok, e3_dst;
+    int32_t e4_tok, e4_dst, spill, reserved;
 };
 static_assert(sizeof(SamNode) == 64, "SamNode must be one 64-byte line");
+// int32 word index of inline edge k's token inside the node (its target follows)
+#define SAMD_EDGE_WORD(k) ((k) == 0 ? 2 : 4 + 2 * (k))
 
 struct SamEdge { int32_t tok, dst; };
+
+#if defined(__HIPCC__)
+#define SAMD_HD __host__ __device__
+#else
+#define SAMD_HD
+#endif
+// number of hash slots of a spill block (excluding the 3-entry head) for a state of degree deg > SAMD_INLINE_EDGES
+SAMD_HD static inline uint32_t samd_spill_slots(int32_t deg) {
+    uint32_t need = 2u * (uint32_t)(deg - SAMD_INLINE_EDGES), m = 4;
+    while (m < need) m <<= 1;
+    return m;
+}
+SAMD_HD static inline uint32_t samd_spill_hash(int32_t tok, uint32_t slots) {
+    return (((uint32_t)tok * 0x9E3779B1u) >> 7) & (slots - 1);
+}
 
 // device view of a static automaton
 struct StaticDev {
