@@ -7,8 +7,8 @@ Workload (config.workload): BASELINE.json configs[1] -- samd_sam_only on a Vicun
 max_predicts 60 / alpha 4 / len_bias 0 (scripts/inference_samd_sam_only.sh:17-19 of the reference).  There are no
 weights, no Spec-Bench and no SAM pickle on the GPU box, so every input is synthetic and seeded:
 random-init weights of the Vicuna-7B architecture, a sparse order-2 Markov corpus for the static automaton, requests =
-512-token prompts made of copied corpus spans / noise / an in-prompt repeat with 512-token continuations of the same
-process.  The verify forward runs in full every step; its per-node arg-max is then replaced by the request's
+512-token prompts made of copied corpus spans / in-request repeats / noise with 512-token continuations of the same
+process, span lengths calibrated to the reference's published mean accepted tokens (2.30, README.md:53).  The verify forward runs in full every step; its per-node arg-max is then replaced by the request's
 continuation stream (samd_hip.engine.ScriptedAcceptance) so that accept lengths are those of a model that actually
 continues the text -- `--acceptance natural` keeps the random-init model's own arg-max instead.
 
@@ -72,23 +72,27 @@ def synth_corpus(n_tokens, vocab=VOCAB, seed=0, doc_len=256):
     return flat, off, docs
 
 
-def synth_request(rng, docs, vocab=VOCAB, prompt_len=512, total_len=2048):
-    """prompt + continuation: alternating copied corpus spans (geometric, mean 16), fresh noise (mean 4) and repeats of
-    earlier text of the same request (mean 12)."""
+def synth_request(rng, docs, vocab=VOCAB, prompt_len=512, total_len=2048, copy_mean=8.0, repeat_mean=8.0, noise_mean=3.0,
+                  p_copy=0.47, p_repeat=0.15):
+    """prompt + continuation of one request: a mix of copied corpus spans (geometric length, mean `copy_mean`), repeats
+    of earlier text of the same request (mean `repeat_mean`) and fresh noise tokens (mean `noise_mean`).  The defaults
+    are calibrated (CPU oracle, 2^20-token corpus) so that samd_sam_only at max_predicts 60 / alpha 4 / len_bias 0
+    accepts ~2.3 tokens per step -- the mean accepted tokens the reference publishes for this configuration
+    (README.md:53); BASELINE.md section 3's longer spans (16 / 4) give ~5.2 and would flatter the speed-up."""
     out = []
     n_docs, doc_len = docs.shape
     while len(out) < total_len:
         r = rng.random()
-        if r < 0.55:
-            ln = int(rng.geometric(1 / 16.0))
+        if r < p_copy:
+            ln = int(rng.geometric(1.0 / copy_mean))
             d, s = int(rng.integers(0, n_docs)), int(rng.integers(0, doc_len - 1))
             out.extend(docs[d, s:s + ln].tolist())
-        elif r < 0.80 and len(out) > 32:
-            ln = int(rng.geometric(1 / 12.0))
+        elif r < p_copy + p_repeat and len(out) > 32:
+            ln = int(rng.geometric(1.0 / repeat_mean))
             s = int(rng.integers(0, len(out) - 8))
             out.extend(out[s:s + ln])
         else:
-            out.extend(rng.integers(3, vocab, int(rng.geometric(1 / 4.0))).tolist())
+            out.extend(rng.integers(3, vocab, int(rng.geometric(1.0 / noise_mean))).tolist())
     out = [t if t != EOS else 3 for t in out[:total_len]]
     return out[:prompt_len], out
 

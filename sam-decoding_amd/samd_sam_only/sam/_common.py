@@ -6,6 +6,7 @@ import samd_hip
 
 
 def dev_i32(values, device="cuda"):
+    samd_hip.require_gpu()
     return torch.as_tensor(np.asarray(values, dtype=np.int32)).to(device)
 
 

@@ -87,8 +87,9 @@ class DynSAM(CursorOwner):
 
     def lookup(self, token: int):
         """dyn_sam.py:111-114: peek, the cursor does not move."""
+        sess = self._sess()
         out = torch.zeros(2, dtype=torch.int32, device="cuda")
-        self._sess().dyn_walk(dev_i32([token]), 1, commit=False, d_out=out)
+        sess.dyn_walk(dev_i32([token]), 1, commit=False, d_out=out)
         i, l = out.tolist()
         return i, l
 

@@ -157,8 +157,9 @@ class StaticSAM(CursorOwner):
 
     def lookup(self, token: int):
         """static_sam.py:122-125"""
+        sess = self._sess()
         out = torch.zeros(2, dtype=torch.int32, device="cuda")
-        self._sess().static_walk(self._automaton(), dev_i32([token]), 1, commit=False, d_out=out)
+        sess.static_walk(self._automaton(), dev_i32([token]), 1, commit=False, d_out=out)
         i, l = out.tolist()
         return i, l
 

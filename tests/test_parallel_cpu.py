@@ -1,0 +1,76 @@
+"""CPU (gloo, world size 2) coverage of the request-parallel helpers: contiguous sharding as
+evaluation/eval_vicuna.py:50-65, broadcast of the static automaton's flat image from rank 0, all-gather of ragged
+results.  The GPU path differs only in where the four image regions live (RCCL into device buffers + adopt)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "sam-decoding_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import samd_hip
+    from samd_hip import parallel
+    from util import markov_stream
+    try:
+        rng = np.random.default_rng(0)
+        docs = [markov_stream(rng, 120, vocab=60) for _ in range(8)] + [[i] for i in range(60)]
+        ref = samd_hip.StaticAutomaton.build(docs, 2, samd_hip.KIND_COUNT)
+        mine = parallel.broadcast_static(ref if rank == 0 else None, src=0)
+        a, b = ref.export(), mine.export()
+        same = all(np.array_equal(a[k], b[k]) for k in a) and ref.info()["n_spill"] == mine.info()["n_spill"]
+        # shard 11 requests, every rank produces ragged rows for its chunk
+        lo, hi = parallel.shard_bounds(11, world, rank)
+        rows = [list(range(100 * i, 100 * i + (i % 4))) for i in range(lo, hi)]
+        got = parallel.gather_results(rows)
+        flat = [r for per_rank in got for r in per_rank]
+        q.put((rank, same, (lo, hi), flat))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_shard_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [list(range(100 * i, 100 * i + (i % 4))) for i in range(11)]
+    assert [r[2] for r in res] == [(0, 5), (5, 11)]          # chunk = 11 // 2, remainder to the last rank
+    for rank, same, _, flat in res:
+        assert same, "broadcast automaton differs from the source"
+        assert flat == want                                   # every rank sees all results, in request order
+
+
+def test_shard_bounds_cover_everything():
+    from samd_hip import parallel
+    for n in (0, 1, 7, 80, 481):
+        for world in (1, 2, 4, 8):
+            spans = [parallel.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
