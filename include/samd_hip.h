@@ -283,20 +283,34 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
  * forward lives in HuggingFace transformers in the reference (third party, not vendored; call sites
  * SO/samd_model.py:102-106 and :134-138); these follow LlamaDecoderLayer's operators and take every
  * dynamic scalar from device memory so that one decode step is graph-capturable. ---- */
+/* In the three consumers below the GEMM-output operand (delta / qkv / gate_up) may be given as fp32 split-K partial
+ * sums of samd_gemm_skinny: n_partials > 0, the pointer then addresses float [n_partials][...] with `partial_stride`
+ * elements between splits; the sum is rounded to `dtype` before use.  n_partials == 0: a plain `dtype` tensor. */
 /* hidden = embed_tokens(input_ids) */
 int samd_embed_rows(const int32_t *d_tokens, const void *d_table, void *d_out, int32_t rows, int32_t hidden, int32_t vocab,
                     int32_t dtype, void *stream);
 /* LlamaRMSNorm; if d_delta != NULL first x += delta (residual add) and store x back */
 int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_out, int32_t rows, int32_t hidden, float eps,
-                 int32_t dtype, void *stream);
+                 int32_t dtype, int32_t n_partials, int64_t partial_stride, void *stream);
 /* rotary embedding of q,k at positions L + rel_pos[r] (SO/samd_model.py:127-132) and
  * SamdStaticCache.update (SO/cache.py:103-115): K/V rows written at [L, L+n).  d_qkv [rows][(H+2Hkv)*D]. */
 int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
                        const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
                        int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
-                       void *stream);
+                       int32_t n_partials, int64_t partial_stride, void *stream);
 /* LlamaMLP activation: silu(gate) * up with gate|up concatenated per row */
-int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, void *stream);
+int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,
+                  int64_t partial_stride, void *stream);
+
+/* weight-streaming skinny GEMM of the verify forward: out[m][n] = sum_k A[m][k] * W[n][k], m < rows_pad in {16,32,64},
+ * W = an nn.Linear weight [N][K] (what the reference runs through HF's q/k/v/o/gate/up/down/lm_head projections,
+ * call sites SO/samd_model.py:102-106, :134-138).  N % 128 == 0, K % 256 == 0.  splits == 1: writes d_out (dtype,
+ * [rows_pad][N]); splits > 1: writes fp32 partial sums d_partial [splits][rows_pad][N] that the consuming kernel adds up
+ * (samd_rmsnorm / samd_rope_kv_write / samd_silu_mul with n_partials > 0). */
+int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad);
+int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits);
+int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
+                     void *d_out, int32_t dtype, void *stream);
 
 /* ---- scripted verifier (tests, smoke and bench only): replaces the LM arg-max of every draft node by
  * the next token of a target stream while the node's context (committed history + root->node path) is a

@@ -19,6 +19,25 @@ template <typename T> __device__ __forceinline__ void st8(T *p, const Vec8<T> &x
     *reinterpret_cast<uint4 *>(p) = __builtin_bit_cast(uint4, x);
 }
 
+// 8 consecutive values of a GEMM output that exists either as a T tensor (n_part == 0) or as fp32 split-K partial sums
+// [n_part][...] (samd_gemm_skinny); the sum is rounded to T, as the GEMM's own epilogue would have done
+template <typename T> __device__ __forceinline__ Vec8<T> ld8_or_partials(const T *src, const float *part, int n_part, size_t part_stride,
+                                                                        size_t off) {
+    if (n_part == 0) return ld8(src + off);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    for (int s = 0; s < n_part; s++) {
+        const float4 a = *reinterpret_cast<const float4 *>(part + (size_t)s * part_stride + off);
+        const float4 b = *reinterpret_cast<const float4 *>(part + (size_t)s * part_stride + off + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    }
+    Vec8<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o.v[j] = (T)acc[j];
+    return o;
+}
+
 __device__ __forceinline__ float block_sum(float v, float *smem) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -45,14 +64,14 @@ __global__ __launch_bounds__(256) void k_embed_rows(const int *__restrict__ toke
 // x <- x + delta first (stored back), as LlamaDecoderLayer does between its two halves.
 template <typename T, bool ADD>
 __global__ __launch_bounds__(256) void k_rmsnorm(T *__restrict__ x, const T *__restrict__ delta, const T *__restrict__ w,
-                                                 T *__restrict__ out, int hidden, float eps) {
+                                                 T *__restrict__ out, int hidden, float eps, int n_part, long long part_stride) {
     __shared__ float red[4];
     const size_t base = (size_t)blockIdx.x * hidden;
     float ss = 0.f;
     for (int c = threadIdx.x * 8; c < hidden; c += blockDim.x * 8) {
         Vec8<T> a = ld8(x + base + c);
         if (ADD) {
-            const Vec8<T> d = ld8(delta + base + c);
+            const Vec8<T> d = ld8_or_partials<T>(delta, reinterpret_cast<const float *>(delta), n_part, (size_t)part_stride, base + c);
 #pragma unroll
             for (int j = 0; j < 8; j++) a.v[j] = (T)((float)a.v[j] + (float)d.v[j]);
             st8(x + base + c, a);
@@ -81,20 +100,27 @@ template <typename T>
 __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel_pos, const int *__restrict__ d_L,
                           const int *__restrict__ d_n, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
                           T *__restrict__ q_out, T *__restrict__ k_cache, T *__restrict__ v_cache, int H, int Hkv, int D,
-                          long long max_len, int max_pos) {
+                          long long max_len, int max_pos, int n_part, long long part_stride) {
     const int r = blockIdx.x, hh = blockIdx.y, j = threadIdx.x, half = D >> 1;
     if (r >= d_n[0]) return;
     const int L = d_L[0];
     if (L + r >= max_len) return;                              // never write past the cache (the host guard breaks earlier)
-    const T *src = qkv + ((size_t)r * (H + 2 * Hkv) + hh) * D;
+    const size_t soff = ((size_t)r * (H + 2 * Hkv) + hh) * D;
+    float x1, x2;                                              // elements j and j + D/2 of this head's row
+    if (n_part == 0) { x1 = (float)qkv[soff + j]; x2 = (float)qkv[soff + j + half]; }
+    else {
+        const float *part = reinterpret_cast<const float *>(qkv);
+        float a = 0.f, b = 0.f;
+        for (int s = 0; s < n_part; s++) { a += part[(size_t)s * part_stride + soff + j]; b += part[(size_t)s * part_stride + soff + j + half]; }
+        x1 = (float)(T)a; x2 = (float)(T)b;                    // rounded like the GEMM's own output
+    }
     if (hh >= H + Hkv) {                                       // V: plain copy
         T *dst = v_cache + ((size_t)(hh - H - Hkv) * max_len + L + r) * D;
-        dst[j] = src[j]; dst[j + half] = src[j + half];
+        dst[j] = (T)x1; dst[j + half] = (T)x2;
         return;
     }
     int pos = L + rel_pos[r]; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
     const float c = cos_t[(size_t)pos * half + j], s = sin_t[(size_t)pos * half + j];
-    const float x1 = (float)src[j], x2 = (float)src[j + half];
     const T o1 = (T)(x1 * c - x2 * s), o2 = (T)(x2 * c + x1 * s);
     T *dst = hh < H ? q_out + ((size_t)r * H + hh) * D : k_cache + ((size_t)(hh - H) * max_len + L + r) * D;
     dst[j] = o1; dst[j + half] = o2;
@@ -102,11 +128,13 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
 
 // out = silu(gate) * up, gate|up concatenated per row: gu[r] = [gate(I) | up(I)]
 template <typename T>
-__global__ __launch_bounds__(256) void k_silu_mul(const T *__restrict__ gu, T *__restrict__ out, int inter) {
+__global__ __launch_bounds__(256) void k_silu_mul(const T *__restrict__ gu, T *__restrict__ out, int inter, int n_part, long long part_stride) {
     const size_t r = blockIdx.y;
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (c >= inter) return;
-    const Vec8<T> g = ld8(gu + r * 2 * inter + c), u = ld8(gu + r * 2 * inter + inter + c);
+    const float *part = reinterpret_cast<const float *>(gu);
+    const Vec8<T> g = ld8_or_partials<T>(gu, part, n_part, (size_t)part_stride, r * 2 * inter + c);
+    const Vec8<T> u = ld8_or_partials<T>(gu, part, n_part, (size_t)part_stride, r * 2 * inter + inter + c);
     Vec8<T> o;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -131,15 +159,17 @@ int samd_embed_rows(const int32_t *d_tokens, const void *d_table, void *d_out, i
 }
 
 int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_out, int32_t rows, int32_t hidden, float eps,
-                 int32_t dtype, void *stream) {
+                 int32_t dtype, int32_t n_partials, int64_t partial_stride, void *stream) {
+    const int n_part = n_partials; const long long pst = partial_stride;
+    if (n_partials < 0 || (n_partials > 0 && !d_delta)) { samd_set_error("samd_rmsnorm: partials without a source"); return SAMD_E_INVALID; }
     if (!d_x || !d_weight || !d_out || rows < 1 || hidden % 8 != 0) { samd_set_error("samd_rmsnorm: invalid argument"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SAMD_F16) {
-        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<_Float16, true>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)d_delta, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps);
-        else hipLaunchKernelGGL((k_rmsnorm<_Float16, false>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)nullptr, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps);
+        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<_Float16, true>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)d_delta, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps, n_part, pst);
+        else hipLaunchKernelGGL((k_rmsnorm<_Float16, false>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)nullptr, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps, n_part, pst);
     } else if (dtype == SAMD_BF16) {
-        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<__bf16, true>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)d_delta, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps);
-        else hipLaunchKernelGGL((k_rmsnorm<__bf16, false>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)nullptr, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps);
+        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<__bf16, true>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)d_delta, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps, n_part, pst);
+        else hipLaunchKernelGGL((k_rmsnorm<__bf16, false>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)nullptr, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps, n_part, pst);
     } else { samd_set_error("samd_rmsnorm: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
@@ -148,24 +178,25 @@ int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_o
 int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
                        const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
                        int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
-                       void *stream) {
+                       int32_t n_partials, int64_t partial_stride, void *stream) {
     if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || !d_cos || !d_sin || !d_q_out || !d_k_cache || !d_v_cache || rows < 1 ||
         head_dim % 2 != 0 || head_dim > 2048) { samd_set_error("samd_rope_kv_write: invalid argument"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(rows, n_heads + 2 * n_kv_heads), block(head_dim / 2);
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride);
     else { samd_set_error("samd_rope_kv_write: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
 }
 
-int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, void *stream) {
+int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,
+                  int64_t partial_stride, void *stream) {
     if (!d_gate_up || !d_out || rows < 1 || inter % 8 != 0) { samd_set_error("samd_silu_mul: invalid argument"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((inter / 8 + 255) / 256, rows), block(256);
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_silu_mul<_Float16>, grid, block, 0, st, (const _Float16 *)d_gate_up, (_Float16 *)d_out, inter);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_silu_mul<__bf16>, grid, block, 0, st, (const __bf16 *)d_gate_up, (__bf16 *)d_out, inter);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_silu_mul<_Float16>, grid, block, 0, st, (const _Float16 *)d_gate_up, (_Float16 *)d_out, inter, n_partials, (long long)partial_stride);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_silu_mul<__bf16>, grid, block, 0, st, (const __bf16 *)d_gate_up, (__bf16 *)d_out, inter, n_partials, (long long)partial_stride);
     else { samd_set_error("samd_silu_mul: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;

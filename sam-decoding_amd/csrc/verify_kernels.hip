@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_kv_compact(void *const *__restrict__ te
 // in registers in the exp2 domain; partial (m, l, O) per split, merged by k_attn_combine.
 // ================================================================================================
 #define ATT_TILE 64
-#define ATT_SPLITS 8
+#define ATT_SPLITS 16
 #define ATT_D 128
 #define VT_STRIDE (ATT_TILE + 8)      // halfs per Vt row: 144 B keeps 16-B alignment, spreads banks
 #define P_STRIDE (ATT_TILE + 8)

@@ -11,7 +11,7 @@ from typing import Dict, Optional
 import torch
 
 import samd_hip
-from samd_hip.engine import DecodeEngine
+from samd_hip.engine import DecodeEngine, TreeModelEngine
 from samd_sam_only.model_patch.llama import mask_rows_u64
 from samd_sam_only.samd_model import Outputs, SamdModel as _SoSamdModel  # noqa: F401
 from .draft import DraftModel
@@ -32,7 +32,7 @@ class SamdModel(_SoSamdModel):
         """samd_model.py:86-92"""
         self.seq_position_ids = self.init_seq_position_ids()
         self.base_seq_position_ids = self.seq_position_ids
-        buffers = self.draft.tree_model.gen_buffers()
+        buffers = self.draft.tree_model.gen_buffers()       # all None for dynamic-tree plugins (EAGLE-2)
         self.base_tree_attn_mask = buffers["tree_attn_mask"]
         self.base_tree_position_ids = buffers["tree_position_ids"]
         self.base_tree_retrieve_indices = buffers["tree_retrieve_indices"]
@@ -47,7 +47,7 @@ class SamdModel(_SoSamdModel):
     def _make_engine(self, session):
         tm = self.draft.tree_model
         if not getattr(tm, "fused", False):
-            raise samd_hip.SamdError(f"{type(tm).__name__} has no device-side hooks; drive it through prefill()/decode()")
+            return TreeModelEngine(self.verifier, session, self.draft.static_automaton(), self.draft.params(), tm)
         return DecodeEngine(self.verifier, session, self.draft.static_automaton(), self.draft.params(), recycle=tm.table(),
                             recycle_parent=tm.parents)
 
@@ -58,8 +58,11 @@ class SamdModel(_SoSamdModel):
         session = self.draft.session()
         tm = self.draft.tree_model
 
-        def on_chunk(tokens, logits, n):
-            tm.update(tree_tokens=tokens[:n], tree_logits=logits[:n])
+        use_hidden = self.samd_config.use_last_hidden_states
+
+        def on_chunk(tokens, logits, n, hidden):
+            tm.update(tokens=tokens[:n].to(torch.long), last_hidden_states=hidden[:n].clone() if use_hidden else None,
+                      tree_tokens=tokens[:n], tree_logits=logits[:n])
         last_logits = self.verifier.prefill(session, input_ids.reshape(-1), on_chunk)
         t = input_ids.reshape(-1).to(device="cuda", dtype=torch.int32)
         session.add_tokens(t)
@@ -89,19 +92,25 @@ class SamdModel(_SoSamdModel):
             rel = self.tree_position_ids[0]
             mask_rows = mask_rows_u64(self.tree_attn_mask)
             # the tree plugin's draft is not in the session yet (lookup returned host lists): install it for the verifier
-            session.set_draft(candidates.tokens[0].to(torch.int32), torch.tensor(self.draft.tree_model.parents, dtype=torch.int32, device="cuda"),
-                              n, type_=1, reverse=True)
+            tm = self.draft.tree_model
+            static_tree = hasattr(tm, "parents")
+            par = torch.tensor(tm.parents, dtype=torch.int32, device="cuda") if static_tree else tm.last_parents.to(torch.int32)
+            session.set_draft(candidates.tokens[0].to(torch.int32), par, n, type_=1, reverse=static_tree)
         input_ids = candidates.tokens
-        tree_logits = self.verifier.forward_tokens(session, input_ids[0], rel, mask_rows, n, length).unsqueeze(0)
+        use_hidden = self.samd_config.use_last_hidden_states
+        fw = self.verifier.forward_tokens(session, input_ids[0], rel, mask_rows, n, length, **({"return_hidden": True} if use_hidden else {}))
+        tree_logits, tree_hidden = (fw[0].unsqueeze(0), OptionalTensor(fw[1])) if use_hidden else (fw.unsqueeze(0), OptionalTensor(None))
         if candidates.type == CandidateType.sequence:
             candidate_logits = tree_logits
+            candidate_hidden = tree_hidden.apply(lambda x: x.unsqueeze(0))
             candidate_indices = OptionalTensor(None)
         else:
             candidate_logits = tree_logits.squeeze(0)[self.tree_retrieve_indices]
+            candidate_hidden = tree_hidden.apply(lambda x: x[self.tree_retrieve_indices])
             candidate_indices = OptionalTensor(self.tree_retrieve_indices)
         best_candidate, accept_length, sample_p = eval_posterior(candidate_logits, candidates.candidate_tokens, self.gen_config)
         new_tokens = self.update_state(input_ids.squeeze(0), tree_logits.squeeze(0), best_candidate, accept_length,
-                                       candidates.candidate_tokens, candidate_indices, OptionalTensor(None))
+                                       candidates.candidate_tokens, candidate_indices, candidate_hidden)
         self.lookup_stats[candidates.type.value][0] += 1
         self.lookup_stats[candidates.type.value][1] += len(new_tokens)
         return sample_p, new_tokens

@@ -100,9 +100,12 @@ _PROTOS = {
     "samd_tree_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
                                       _VP, _I64, _VP]),
     "samd_embed_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
-    "samd_rmsnorm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _VP]),
-    "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
-    "samd_silu_mul": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
+    "samd_rmsnorm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _I32, _I64, _VP]),
+    "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
+    "samd_silu_mul": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I64, _VP]),
+    "samd_gemm_splits": (C.c_int, [_I32, _I32, _I32]),
+    "samd_gemm_workspace": (_I64, [_I32, _I32, _I32]),
+    "samd_gemm_skinny": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "samd_recycle_create": (C.c_int, [_I32, _VP, _VP, _I32, _VP]),
     "samd_recycle_free": (None, [_VP]),
     "samd_recycle_update": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _I64, _I64, _VP]),

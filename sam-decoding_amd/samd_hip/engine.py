@@ -81,7 +81,7 @@ class ScriptedVerifier:
                 am = [self.next_token(ids[:c0 + i + 1]) for i in range(m)]
                 self.argmax[:m] = torch.tensor(am, dtype=torch.int32, device=self.device)
                 self._rows(m)
-                on_chunk(torch.tensor(ids[c0:c0 + m] + [0] * (MAX_DRAFT - m), dtype=torch.int32, device=self.device), self.logits, m)
+                on_chunk(torch.tensor(ids[c0:c0 + m] + [0] * (MAX_DRAFT - m), dtype=torch.int32, device=self.device), self.logits, m, None)
         first = torch.tensor([self.next_token(ids)], dtype=torch.int32, device=self.device)
         session.set_start_token(first)
         self._keep = first
@@ -150,6 +150,9 @@ class ScriptedAcceptance:
     def warm(self, R):
         self.runner.warm(R)
 
+    def hidden_rows(self, R):
+        return self.runner.hidden_rows(R)
+
 
 class DecodeEngine:
     def __init__(self, verifier, session: Session, static: StaticAutomaton, params: Params, recycle: TokenRecycleTable = None,
@@ -197,7 +200,7 @@ class DecodeEngine:
         s.reset()
         on_chunk = None
         if self.recycle is not None:
-            on_chunk = lambda toks, logits, n: self._recycle_update(toks, logits, n, None)
+            on_chunk = lambda toks, logits, n, hidden: self._recycle_update(toks, logits, n, None)
         ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
         self.verifier.prefill(s, ids, on_chunk)
         s.add_tokens(ids)                                    # DraftModel.update(prompt): dyn add_tokens ...
@@ -240,3 +243,57 @@ class DecodeEngine:
         v = self.verifier
         if hasattr(v, "warm"):
             v.warm(R)
+
+
+class TreeModelEngine(DecodeEngine):
+    """DecodeEngine for tree-draft plugins without device-side hooks (EAGLE-2: samd/tree_model/eagle2.py).  The verify
+    forward + accept + SAM update + lookup stay one hipGraph; afterwards the host reads the report, hands the accepted
+    tokens and their last hidden states to the plugin (samd/samd_model.py:203-208) and, when the lookup deferred to the
+    plugin (samd/draft.py:63), runs its expansion on the device and installs the draft (tokens + parent array; mask,
+    positions and retrieve rows come from the tree-buffer kernel)."""
+
+    def __init__(self, verifier, session, static, params, tree_model, use_graphs=True):
+        super().__init__(verifier, session, static, params, use_graphs=use_graphs)
+        self.tm = tree_model
+
+    def _report(self):
+        self.session.report_async(self.report_buf)
+        torch.cuda.current_stream().synchronize()
+        return StepReport(self._report_np)
+
+    def _maybe_tree(self, rep):
+        if rep.type != 2:
+            return rep
+        d = self.session.read_draft()
+        start = torch.tensor([d.tokens[0]], dtype=torch.long, device=self.device)
+        tokens, parents = self.tm.gen_draft_device(start)
+        self._keep = (tokens.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous())
+        self.session.set_draft(self._keep[0], self._keep[1], int(tokens.numel()), type_=1)
+        return self._report()
+
+    def start(self, input_ids):
+        s = self.session
+        s.reset()
+        self.tm.reset()
+        ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
+        hidden = []
+        self.verifier.prefill(s, ids, lambda toks, logits, n, h: hidden.append(h[:n].clone()))
+        s.add_tokens(ids)
+        s.static_walk(self.static, ids, ids.numel(), commit=True)
+        self.tm.update(tokens=ids.to(torch.long), last_hidden_states=torch.cat(hidden, dim=0))
+        s.draft(self.static, self.params, self._views["start_token"])
+        return self._maybe_tree(self._report())
+
+    def step(self, n_next):
+        R = self.verifier.bucket(n_next)
+        if not self.use_graphs:
+            self._enqueue_step(R)
+        else:
+            g = self._graphs.get(R) or self._capture(R)
+            g.replay()
+        torch.cuda.current_stream().synchronize()
+        rep = StepReport(self._report_np)
+        rows = [k if k >= 0 else n_next - 1 for k in rep.kv_index]       # -1 padding selects the last tree node (SO/samd_model.py:144)
+        hs = self.verifier.hidden_rows(R)[torch.tensor(rows, dtype=torch.long, device=self.device)]
+        self.tm.update(tokens=torch.tensor(rep.tokens, dtype=torch.long, device=self.device), last_hidden_states=hs)
+        return self._maybe_tree(rep)

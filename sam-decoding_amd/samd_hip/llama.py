@@ -75,7 +75,7 @@ class LlamaRunner:
 
     BUCKETS = (1, 8, 16, 32, 64)
 
-    def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None):
+    def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None, native_gemm=True):
         require_gpu()
         self.shape, self.dtype, self.device = shape, dtype, torch.device(device)
         self.dt = torch_dtype_code(dtype)
@@ -84,6 +84,10 @@ class LlamaRunner:
         self.max_len = int(max_cache_len)
         s = shape
         self.w = weights
+        # samd_gemm_skinny streams the weights itself (N % 128 == 0, K % 256 == 0); otherwise the library GEMM runs
+        qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
+        shapes = [(qkv_out, s.hidden), (s.hidden, s.heads * s.head_dim), (2 * s.inter, s.hidden), (s.hidden, s.inter), (s.vocab, s.hidden)]
+        self.native_gemm = bool(native_gemm) and all(n % 128 == 0 and k % 256 == 0 for n, k in shapes)
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
         self.bind_cache(kv if kv is not None else
                         torch.zeros((s.layers, 2, s.kv_heads, self.max_len, s.head_dim), dtype=dtype, device=self.device))
@@ -168,12 +172,19 @@ class LlamaRunner:
     def _buffers(self, R):
         if R not in self._buf:
             s, dt, dev = self.shape, self.dtype, self.device
-            z = lambda *sz: torch.zeros(sz, dtype=dt, device=dev)
+            RP = max(R, 16) if self.native_gemm else R           # the skinny GEMM reads 16 / 32 / 64 rows (pad rows are zero)
+            z = lambda r, *sz: torch.zeros((max(r, RP),) + sz, dtype=dt, device=dev)
             ws_bytes = lib().samd_tree_attention_workspace(R, s.heads, s.head_dim)
+            part_elems = 0
+            if self.native_gemm:
+                qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
+                for n, k in ((qkv_out, s.hidden), (s.hidden, s.heads * s.head_dim), (2 * s.inter, s.hidden), (s.hidden, s.inter)):
+                    part_elems = max(part_elems, lib().samd_gemm_splits(n, k, RP) * RP * n)
             self._buf[R] = dict(x=z(R, s.hidden), h=z(R, s.hidden), qkv=z(R, (s.heads + 2 * s.kv_heads) * s.head_dim),
                                 q=z(R, s.heads, s.head_dim), attn=z(R, s.heads, s.head_dim), o=z(R, s.hidden),
                                 gu=z(R, 2 * s.inter), act=z(R, s.inter), d=z(R, s.hidden), logits=z(R, s.vocab),
-                                argmax=torch.zeros(MAX_DRAFT, dtype=torch.int32, device=dev),
+                                argmax=torch.zeros(MAX_DRAFT, dtype=torch.int32, device=dev), rows_pad=RP,
+                                part=torch.zeros(max(part_elems, 1), dtype=torch.float32, device=dev),
                                 ws=torch.zeros(ws_bytes, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes)
         return self._buf[R]
 
@@ -187,25 +198,38 @@ class LlamaRunner:
         """one forward over R rows; all of d_* are device pointers (ints / tensors).  Returns the buffers of bucket R
         (logits [R, V], argmax int32[64] with rows < n valid)."""
         L, s, b, dt, st = lib(), self.shape, self._buffers(R), self.dt, current_stream()
+        RP, part = b["rows_pad"], b["part"]
+
+        def gemm(a, w, out):
+            """out = a @ w.T; returns (operand pointer for the consumer, n_partials, partial_stride)."""
+            n, k = w.shape
+            # measured on MI355X (scripts/forward_ablation.py, whole forward incl. the consumers' partial-sum reads):
+            # the weight-streaming kernel wins up to 16 rows (4.30 vs 4.75 ms), ties at 32, loses at 64 (5.51 vs 5.22 ms)
+            if not self.native_gemm or RP > 16:
+                torch.mm(a[:R], w.t(), out=out[:R])
+                return out, 0, 0
+            sp = L.samd_gemm_splits(n, k, RP) if out is not b["logits"] else 1
+            check(L.samd_gemm_skinny(_ptr(a), _ptr(w), RP, n, k, sp, _ptr(part), _ptr(out), dt, st))
+            return (out, 0, 0) if sp == 1 else (part, sp, RP * n)
+
         check(L.samd_embed_rows(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(b["x"]), R, s.hidden, s.vocab, dt, st))
-        delta = None
+        delta, dn, dstride = None, 0, 0
         for li, w in enumerate(self.w["layers"]):
-            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, st))
-            torch.mm(b["h"], w["wqkv"].t(), out=b["qkv"])
-            check(L.samd_rope_kv_write(_ptr(b["qkv"]), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
+            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
+            src, n_p, stride = gemm(b["h"], w["wqkv"], b["qkv"])
+            check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
                                        _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
-                                       s.head_dim, self.max_len, self.rope_rows, dt, st))
+                                       s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
             check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
                                         s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
                                         _ptr(b["ws"]), b["ws_bytes"], st))
-            torch.mm(b["attn"].view(R, -1), w["wo"].t(), out=b["o"])
-            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(b["o"]), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, st))
-            torch.mm(b["h"], w["wgu"].t(), out=b["gu"])
-            check(L.samd_silu_mul(_ptr(b["gu"]), _ptr(b["act"]), R, s.inter, dt, st))
-            torch.mm(b["act"], w["wdown"].t(), out=b["d"])
-            delta = b["d"]
-        check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, st))
-        torch.mm(b["h"], self.w["lm_head"].t(), out=b["logits"])
+            src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], b["o"])
+            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride, st))
+            src, n_p, stride = gemm(b["h"], w["wgu"], b["gu"])
+            check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
+            delta, dn, dstride = gemm(b["act"], w["wdown"], b["d"])
+        check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
+        gemm(b["h"], self.w["lm_head"], b["logits"])
         check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
         return b
 
@@ -213,8 +237,9 @@ class LlamaRunner:
     def prefill(self, session: Session, input_ids, on_chunk=None):
         """SamdModel.prefill's LM part (SO/samd_model.py:96-114): the prompt goes through the same kernels in chunks of
         64 rows with a causal chain mask; K/V land at [0, N).  Leaves cache_length = N in the session and the arg-max of
-        the last prompt position in session.start_token.  on_chunk(tokens int32[64], logits [64,V], n) is called per
-        chunk (Token Recycle learns from the prompt logits: S/samd_model.py:117-122)."""
+        the last prompt position in session.start_token.  on_chunk(tokens int32[64], logits [64,V], n, hidden [64,H]) is
+        called per chunk (Token Recycle learns from the prompt logits, EAGLE-2 from the last hidden states:
+        S/samd_model.py:117-122)."""
         ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
         N = ids.numel()
         if N < 1 or N > self.max_len:
@@ -229,7 +254,7 @@ class LlamaRunner:
             session.set_cache_length(c0)
             b = self.forward_rows(MAX_DRAFT, self.pf_tokens, self.pf_relpos, self.pf_mask, v["cache_length"], self.pf_n)
             if on_chunk is not None:
-                on_chunk(self.pf_tokens, b["logits"], n)
+                on_chunk(self.pf_tokens, b["logits"], n, b["h"])
         session.set_cache_length(N)
         session.set_start_token(b["argmax"][(N - 1) % MAX_DRAFT:])
         return b["logits"][(N - 1) % MAX_DRAFT]
@@ -242,7 +267,12 @@ class LlamaRunner:
         self.forward_rows(R, self.pf_tokens, self.pf_relpos, self.pf_mask, scratch_L, self.pf_n)
         torch.cuda.current_stream().synchronize()
 
-    def forward_tokens(self, session: Session, tokens, relpos, mask_rows, n, L):
+    def hidden_rows(self, R):
+        """last hidden states (after the final norm) of the most recent forward of bucket R: what the reference's patched
+        LlamaForCausalLM.forward returns as `last_hidden_states` (SO/model_patch/llama.py:112-202)."""
+        return self._buffers(R)["h"]
+
+    def forward_tokens(self, session: Session, tokens, relpos, mask_rows, n, L, return_hidden=False):
         """granular verify (SamdModel.decode): explicit draft tokens / relative positions / u64 mask rows -> logits [n, V]."""
         R = self.bucket(n)
         tok = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
@@ -253,7 +283,7 @@ class LlamaRunner:
         session.set_cache_length(L)
         b = self.forward_rows(R, tok, rel, mask_rows, session.device_views()["cache_length"], d_n)
         torch.cuda.current_stream().synchronize()
-        return b["logits"][:n]
+        return (b["logits"][:n], b["h"][:n]) if return_hidden else b["logits"][:n]
 
     def verify(self, session: Session, R):
         """SamdModel.decode's LM call (SO/samd_model.py:134-138) on the session's current draft."""

@@ -1,0 +1,53 @@
+"""GPU parity of the weight-streaming skinny GEMM (samd_gemm_skinny) against a plain PyTorch fp32 reference of the same
+product.  Tolerance: fp16/bf16 inputs, fp32 accumulation -> the only rounding is the final cast (or none for fp32
+split-K partials): |err| <= 2^-10 (fp16) / 2^-7 (bf16) relative to the row's magnitude."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import samd_hip
+
+
+def run(A, W, rows_pad, splits, dtype):
+    N, K = W.shape
+    L = samd_hip.lib()
+    if splits == 1:
+        out = torch.full((rows_pad, N), float("nan"), device="cuda", dtype=dtype)
+        samd_hip.check(L.samd_gemm_skinny(samd_hip._ptr(A), samd_hip._ptr(W), rows_pad, N, K, 1, None, samd_hip._ptr(out),
+                                          samd_hip.torch_dtype_code(dtype), samd_hip.current_stream()))
+        return out.float()
+    part = torch.full((splits, rows_pad, N), float("nan"), device="cuda", dtype=torch.float32)
+    samd_hip.check(L.samd_gemm_skinny(samd_hip._ptr(A), samd_hip._ptr(W), rows_pad, N, K, splits, samd_hip._ptr(part), None,
+                                      samd_hip.torch_dtype_code(dtype), samd_hip.current_stream()))
+    return part.sum(0)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("rows_pad,N,K,splits", [(16, 128, 256, 1), (16, 4096, 4096, 4), (32, 1024, 768, 3), (64, 12288, 4096, 2),
+                                                 (64, 4096, 11008, 8), (64, 32000, 4096, 1), (32, 22016, 4096, 1), (16, 128, 2816, 11)])
+def test_gemm_matches_fp32_reference(dtype, tol, rows_pad, N, K, splits):
+    g = torch.Generator(device="cuda").manual_seed(N + K + rows_pad)
+    A = torch.randn((rows_pad, K), generator=g, device="cuda").to(dtype)
+    W = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(dtype)
+    got = run(A, W, rows_pad, splits, dtype)
+    want = A.float() @ W.float().t()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    assert err <= tol * max(1.0, want.abs().max().item()), err
+
+
+def test_gemm_rejects_bad_shapes():
+    L = samd_hip.lib()
+    a = torch.zeros((16, 256), device="cuda", dtype=torch.float16)
+    w = torch.zeros((128, 256), device="cuda", dtype=torch.float16)
+    o = torch.zeros((16, 128), device="cuda", dtype=torch.float16)
+    ok = lambda *args: L.samd_gemm_skinny(samd_hip._ptr(a), samd_hip._ptr(w), *args, None, samd_hip._ptr(o), samd_hip.F16, None)
+    assert ok(16, 128, 256, 1) == 0
+    assert ok(8, 128, 256, 1) != 0         # rows_pad must be 16 / 32 / 64
+    assert ok(16, 100, 256, 1) != 0        # N % 128
+    assert ok(16, 128, 200, 1) != 0        # K % 256
+    assert ok(16, 128, 256, 2) != 0        # more splits than chunks
+    assert L.samd_gemm_splits(4096, 4096, 16) >= 2 and L.samd_gemm_splits(4096, 4096, 64) <= 4

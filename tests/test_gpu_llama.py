@@ -134,3 +134,58 @@ def test_llama3_rope_scaling_matches_hf():
     except Exception as e:                                                   # HF signature drift: not our arithmetic
         pytest.skip(f"HF rope init unavailable: {e}")
     assert torch.allclose(mine.float(), want.float(), rtol=1e-6, atol=0)
+
+
+def test_eagle2_plugin_is_lossless_and_paths_agree():
+    """samd[EAGLE2] (BASELINE config 4 shape of the loop): SAM sequence drafts when the match is long, otherwise the
+    EAGLE-2 head's dynamic 63-node tree.  With a random head the drafts are poor, but verification makes the output the
+    autoregressive greedy sequence whatever the draft -- the reference's losslessness criterion (evaluation/equal.py)."""
+    import samd as S
+    import samd_sam_only as SO
+    from samd.tree_model.eagle2 import Eagle2, Eagle2Head
+    lm = tiny_llama(2, seed=5)
+    rng = np.random.default_rng(4)
+    prompt = rng.integers(3, 512, 70).tolist()              # > 64: two prefill chunks feed the head
+    prompt[40:52] = prompt[10:22]                           # an in-prompt repeat -> dynamic-SAM sequence drafts
+    ids = torch.tensor([prompt], device="cuda")
+    gcfg = SO.SamdGenerationConfig(max_new_tokens=48, max_cache_len=512)
+    ar_cfg = SO.SamdConfig(max_predicts=1)
+    ar = SO.SamdModel(ar_cfg, lm, SO.DraftModel(ar_cfg, device="cuda"), eos_token_id=2, dtype=torch.float16, device="cuda")
+    seq_ar = ar.generate(ids, generation_config=gcfg).output_ids[0]
+
+    tree_cfg = dict(hidden_size=256, intermediate_size=512, num_attention_heads=2, num_key_value_heads=2, vocab_size=512,
+                    rms_norm_eps=1e-5, bias=True)
+    cfg = S.SamdConfig(n_predicts=12, len_threshold=3, len_bias=0, tree_method="eagle2", tree_config=tree_cfg)
+    assert cfg.use_last_hidden_states
+
+    def build():
+        head = Eagle2Head(tree_cfg, dtype=torch.float16, device="cuda")
+        head.random_init(seed=3, std=0.08)
+        tm = Eagle2(cfg, lm, torch.float16, "cuda", head=head)
+        draft = S.DraftModel(cfg, tree_model=tm, lm=lm, device="cuda")
+        return S.SamdModel(cfg, lm, draft, eos_token_id=2, dtype=torch.float16, device="cuda")
+
+    def check(seq):
+        m = min(len(seq), len(seq_ar))
+        diff = [i for i in range(m) if seq[i] != seq_ar[i]]
+        assert not diff or (diff[0] > len(prompt) + 4 and _near_tie(lm, seq[:diff[0]], seq[diff[0]], seq_ar[diff[0]])), diff[:3]
+
+    model = build()
+    out = model.generate(ids, generation_config=gcfg)
+    check(out.output_ids[0])
+    assert model.lookup_stats["tree"][0] > 0, "the EAGLE-2 tree path never ran"
+    # granular form: prefill / decode / update_state with the plugin's host-visible gen_draft
+    model2 = build()
+    model2.gen_config = gcfg
+    got = list(prompt)
+    for new_ids, _ in model2._run_granular(ids, gcfg, 16):
+        got.extend(new_ids)
+    check(got)
+    # a draft straight from the plugin: 63 nodes, parents precede children
+    model3 = build()
+    model3.set_cache(gcfg)
+    rep = model3.engine.start(ids)
+    d = model3.draft.session().read_draft()
+    if rep.type == 1 and d.n == 63:
+        par = list(d.parent[:63])
+        assert par[0] == -1 and all(0 <= par[i] < i for i in range(1, 63))
