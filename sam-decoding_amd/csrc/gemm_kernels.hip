@@ -7,9 +7,11 @@
 // each lane therefore owns 32 contiguous bytes of a weight row per 64-wide k block (4 lanes = 128 B of one row), and
 // the MFMA k index is permuted accordingly (the A operand is read from LDS with the same permutation, so the product
 // is unchanged).  A (the activations, <= 512 KB, L2 resident) is staged per workgroup through LDS in 256-wide k chunks,
-// double buffered; the weights go HBM -> VGPR -> MFMA one chunk ahead.  Split-K partial sums are written as fp32 and
+// double buffered; the weights go HBM -> VGPR -> MFMA one chunk ahead.  (Measured and dropped: a 16-row variant that stages the
+// whole A slice once and streams without per-chunk barriers -- 159 vs 141 us per layer-set, the serial staging costs more.)  Split-K partial sums are written as fp32 and
 // summed by the consuming kernel (rmsnorm+residual, rope, silu*up), so the split costs no extra launch.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "samd_common.h"
 
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)

@@ -164,6 +164,18 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 
     for (int t = t0; t < t1; t++) {
         const int key0 = t * ATT_TILE;
+        // ---- issue this tile's K fragment loads first: their HBM latency overlaps the V staging below
+        uint4 kraw[4][4];
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                int key = key0 + 16 * st + lr;
+                key = key < (int)max_len ? key : (int)max_len - 1;
+                const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) kraw[st][kk] = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
+            }
+        }
         __syncthreads();                                   // previous tile's Vt / Pw reads are done
         // ---- stage V^T: thread handles key pair (2p, 2p+1) x one 8-wide d chunk, twice
 #pragma unroll
@@ -184,15 +196,9 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
         if (active) {
 #pragma unroll
             for (int st = 0; st < 4; st++) {
-                int key = key0 + 16 * st + lr;
-                key = key < (int)max_len ? key : (int)max_len - 1;
-                const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
                 floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const uint4 raw = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
-                    acc = Mfma<TT>::run(qa[kk], __builtin_bit_cast(V8, raw), acc);
-                }
+                for (int kk = 0; kk < 4; kk++) acc = Mfma<TT>::run(qa[kk], __builtin_bit_cast(V8, kraw[st][kk]), acc);
                 s[st] = acc;
             }
             // ---- mask, online softmax (exp2 domain); lane holds rows 4*lg+r, key 16*st+lr
