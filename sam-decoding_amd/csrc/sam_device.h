@@ -342,6 +342,14 @@ __device__ __forceinline__ void build_buffers(StepShared &sh, int n, int reverse
     const int i = lane_id();
     if (i == 0) sh.child_mask = 0ull;
     __syncthreads();
+    // a well-formed parent array has parent[0] == -1 and 0 <= parent[i] < i; anything else (an externally supplied draft
+    // with a missing ancestor) is re-attached to the root so that the ancestor walks below always terminate
+    if (i < n) {
+        const int p = sh.parent[i];
+        if (i == 0) sh.parent[0] = -1;
+        else if (p < 0 || p >= i) sh.parent[i] = 0;
+    }
+    __syncthreads();
     int depth = 0; unsigned long long m = 0ull;
     if (i < n) {
         for (int j = i; j != -1; j = sh.parent[j]) { m |= 1ull << j; depth++; }

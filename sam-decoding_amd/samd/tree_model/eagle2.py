@@ -134,7 +134,7 @@ class Eagle2Head(torch.nn.Module):
         self.stable_kv = kv
         pos_len = kv[0].shape[1]
         last_hidden = out[-1:]
-        logp = torch.log_softmax(F.linear(last_hidden, head_weight), dim=-1)
+        logp = torch.log_softmax(F.linear(last_hidden, head_weight).float(), dim=-1)      # fp32: no -inf ties in half precision
         top = torch.topk(logp, top_k, dim=-1)
         scores = top.values[0]
         scores_list, parents_list, tokens_list = [scores[None]], [torch.zeros(1, dtype=torch.long, device=dev)], [top.indices]
@@ -148,7 +148,7 @@ class Eagle2Head(torch.nn.Module):
             pos_len += 1
             bias = 1 + top_k ** 2 * max(0, i - 1) + (top_k if i > 0 else 0)
             parents_list.append(cs_index + bias)
-            logp = torch.log_softmax(F.linear(out, head_weight), dim=-1)
+            logp = torch.log_softmax(F.linear(out, head_weight).float(), dim=-1)
             top = torch.topk(logp, top_k, dim=-1)
             cu = top.values + scores[:, None]
             best = torch.topk(cu.view(-1), top_k, dim=-1)
@@ -167,6 +167,10 @@ class Eagle2Head(torch.nn.Module):
         mask_index = torch.searchsorted(keep, draft_parents - 1, right=False)
         mask_index[draft_parents == 0] = -1
         parents = torch.cat((torch.full((1,), -1, dtype=torch.long, device=dev), mask_index + 1), dim=0)
+        # a kept node whose parent was not kept (possible only on exact score ties) hangs off the root, as the tree-buffer
+        # kernel would do anyway
+        idx = torch.arange(parents.numel(), device=dev)
+        parents = torch.where((parents >= idx) & (idx > 0), torch.zeros_like(parents), parents)
         return draft_tokens, parents
 
 

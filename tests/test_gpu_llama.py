@@ -189,3 +189,57 @@ def test_eagle2_plugin_is_lossless_and_paths_agree():
     if rep.type == 1 and d.n == 63:
         par = list(d.parent[:63])
         assert par[0] == -1 and all(0 <= par[i] < i for i in range(1, 63))
+
+
+def test_bf16_gqa_runner_matches_hf():
+    """Llama-3-style numerics path: bf16, grouped-query attention (2 query heads per KV head), llama3 rope scaling.
+    Tolerance: bf16 has 8 mantissa bits; logits of this 2-layer model agree with fp32 HF to 0.15 absolute."""
+    from transformers import LlamaConfig, LlamaForCausalLM, DynamicCache
+    torch.manual_seed(11)
+    rs = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=64,
+              rope_theta=500000.0)
+    try:
+        cfg = LlamaConfig(hidden_size=512, intermediate_size=768, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                          vocab_size=640, max_position_embeddings=512, head_dim=128, rms_norm_eps=1e-5, tie_word_embeddings=False,
+                          rope_parameters=rs)
+    except Exception as e:
+        pytest.skip(f"LlamaConfig(rope_parameters=...) unsupported: {e}")
+    cfg._attn_implementation = "eager"
+    lm = LlamaForCausalLM(cfg).cuda().float().eval()
+    runner = LlamaRunner.from_hf(lm, max_cache_len=256, dtype=torch.bfloat16)
+    sess = samd_hip.Session(512)
+    rng = np.random.default_rng(3)
+    prompt = rng.integers(3, 640, 90).tolist()
+    ids = torch.tensor([prompt], device="cuda")
+    last = runner.prefill(sess, ids)
+    with torch.no_grad():
+        ref = lm(input_ids=ids).logits[0, -1]
+    err = (last.float() - ref).abs().max().item()
+    assert err < 0.15, err
+    assert int(last.float().argmax()) == int(ref.argmax()) or (ref.topk(2).values[0] - ref.topk(2).values[1]).item() < 0.1
+
+
+def test_token_recycle_on_real_logits_is_lossless():
+    """samd[Token Recycle] (BASELINE config 3 loop) on a tiny Llama: the [V,8] table is fed from real fp16 logits inside
+    the step's hipGraph; the output must still be the autoregressive greedy sequence."""
+    import samd as S
+    import samd_sam_only as SO
+    lm = tiny_llama(2, seed=9)
+    rng = np.random.default_rng(8)
+    prompt = rng.integers(3, 512, 48).tolist()
+    ids = torch.tensor([prompt], device="cuda")
+    gcfg = SO.SamdGenerationConfig(max_new_tokens=64, max_cache_len=512)
+    ar_cfg = SO.SamdConfig(max_predicts=1)
+    ar = SO.SamdModel(ar_cfg, lm, SO.DraftModel(ar_cfg, device="cuda"), eos_token_id=2, dtype=torch.float16, device="cuda")
+    seq_ar = ar.generate(ids, generation_config=gcfg).output_ids[0]
+    cfg = S.SamdConfig(n_predicts=16, len_threshold=4, len_bias=0, tree_method="token_recycle")
+    draft = S.DraftModel(cfg, lm=lm, device="cuda")
+    model = S.SamdModel(cfg, lm, draft, eos_token_id=2, dtype=torch.float16, device="cuda")
+    for rep in range(2):                              # the table persists: the second request drafts from what it learned
+        out = model.generate(ids, generation_config=gcfg)
+        seq = out.output_ids[0]
+        m = min(len(seq), len(seq_ar))
+        diff = [i for i in range(m) if seq[i] != seq_ar[i]]
+        assert not diff or (diff[0] > len(prompt) + 4 and _near_tie(lm, seq[:diff[0]], seq[diff[0]], seq_ar[diff[0]])), diff[:3]
+    assert out.decode_steps < out.decode_tokens, "Token Recycle never got a draft accepted on a repeated request"
+    assert len(draft.tree_model.cache) > 0

@@ -465,3 +465,19 @@ def test_loop_so_golden(golden, fused):
         # the dynamic automaton's text is exactly prompt + every committed (untruncated) token
         committed = case["prompt"] + [t for st in case["trace"] for t in st["accepted"]]
         assert e["n_text"] - 1 == len(committed)
+
+
+def test_tree_buffers_malformed_parents_terminate():
+    """an externally supplied draft whose parent array is not a tree (forward reference, self loop, out of range) must not
+    hang the wavefront: such nodes are re-attached to the root."""
+    bad = [-1, 0, 5, 3, 99, 1, -7, 2]
+    fixed = [-1, 0, 0, 0, 0, 1, 0, 2]
+    n = len(bad)
+    sess = samd_hip.Session(64)
+    sess.set_draft(dev(list(range(10, 10 + n))), dev(bad), n, type_=1)
+    d = sess.read_draft()
+    want = O.gen_buffers(fixed)
+    assert list(d.parent[:n]) == fixed
+    assert list(d.position[:n]) == want["tree_position_ids"][0].tolist()
+    ret = np.asarray(d.retrieve[:d.n_leaves * d.max_depth]).reshape(d.n_leaves, d.max_depth)
+    assert ret.tolist() == want["tree_retrieve_indices"].tolist()
