@@ -95,3 +95,25 @@ def test_run_eval_speed_equal(tmp_path):
     slow[0]["choices"][0]["turns"][0] = "different"
     base.write_text("".join(json.dumps(r) + "\n" for r in slow))
     assert not equal(str(ans), str(base), report=False)
+
+
+def test_gen_sam_tool_builds_corpus_with_vocab_documents(tmp_path):
+    """tools.gen_sam: prompt + response per dialogue, then every vocabulary id as a one-token document
+    (tools/gen_sam_alpaca_sam_only.py:39-44); the automaton must equal a direct build of that corpus."""
+    import samd_sam_only as SO
+    from tools.gen_sam import build_corpus_tokens, load_dialogues
+
+    class Tok(ToyTokenizer):
+        def __call__(self, text, padding=False, return_tensors=None):
+            return {"input_ids": [0] + [self._id(w) for w in text.split()]}
+
+        def __len__(self):
+            return 40
+    tok = Tok()
+    p = tmp_path / "d.jsonl"
+    p.write_text(json.dumps({"prompt": "a b c ", "response": "a b d"}) + "\n" + json.dumps({"prompt": "e a ", "response": "b c"}) + "\n")
+    batch = build_corpus_tokens(load_dialogues(str(p)), tok)
+    assert len(batch) == 2 + 40 and batch[2:5] == [[0], [1], [2]] and len(batch[0]) == 7
+    sam = SO.build_sam(batch, 2)
+    assert len(sam.states[0].next) >= 40                      # the root has an edge for every vocabulary id
+    assert load_dialogues("none") == []
