@@ -184,3 +184,44 @@ def test_cache_select_indices():
     assert cache.cache_length == 15
     cache.reset()
     assert cache.get_seq_length() == 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_generate_random_cases_vs_oracle(seed):
+    """whole-loop parity on seeded random corpora / prompts / continuations / hyper-parameters: the fused hipGraph step
+    behind SamdModel.generate() against the CPU oracle's restatement of the reference loop (same scripted LM)."""
+    import samd_sam_only as SO
+    from test_oracle_golden import oracle_generate_so
+    from util import markov_stream
+    rng = np.random.default_rng(1000 + seed)
+    V = int(rng.choice([37 * 2 + 1, 97, 150, 211]))                       # coprime with 37 (scripted LM rows)
+    while np.gcd(37, V) != 1:
+        V += 1
+    docs = [markov_stream(rng, int(rng.integers(30, 120)), vocab=V, succ=int(rng.integers(2, 4)), noise=0.03) for _ in range(int(rng.integers(4, 20)))]
+    docs += [[i] for i in range(V)]
+    flat = [t for d in docs[:-V] for t in d]
+    p = int(rng.integers(0, max(1, len(flat) - 60)))
+    prompt = flat[p:p + int(rng.integers(8, 40))] + rng.integers(3, V, int(rng.integers(0, 5))).tolist()
+    prompt += prompt[2:2 + int(rng.integers(0, 10))]
+    cont = []
+    max_new = int(rng.integers(20, 90))
+    while len(cont) < max_new + 70:
+        r = rng.random()
+        if r < 0.5:
+            q = int(rng.integers(0, max(1, len(flat) - 30))); cont += flat[q:q + int(rng.integers(3, 25))]
+        elif r < 0.75 and len(prompt) > 8:
+            q = int(rng.integers(0, len(prompt) - 4)); cont += prompt[q:q + int(rng.integers(2, 9))]
+        else:
+            cont += rng.integers(3, V, int(rng.integers(1, 4))).tolist()
+    cont = [t if t != 2 else 3 for t in cont]
+    if seed % 3 == 0:
+        cont[int(rng.integers(5, max_new))] = 2                             # an EOS inside the continuation
+    case = {"docs": docs, "eos": 2, "vocab": V, "max_predicts": int(rng.choice([1, 4, 16, 40, 60, 64])), "alpha": float(rng.choice([1.0, 2.5, 4.0])),
+            "K": int(rng.choice([1, 3, 8])), "len_bias": int(rng.choice([0, 0, 2, 5])), "max_new_tokens": max_new,
+            "max_cache_len": int(rng.choice([len(prompt) + 70, 256, 512])), "prompt": prompt, "target": prompt + cont}
+    want = oracle_generate_so(case)
+    SO_, model = so_model(case)
+    gcfg = SO_.SamdGenerationConfig(max_new_tokens=case["max_new_tokens"], max_cache_len=case["max_cache_len"])
+    out = model.generate(torch.tensor([prompt], dtype=torch.long, device="cuda"), generation_config=gcfg)
+    assert out.output_ids == [want["output_ids"]]
+    assert (out.decode_tokens, out.decode_steps, out.accepet_length_per_step) == (want["decode_tokens"], want["decode_steps"], want["accept_lengths"])
