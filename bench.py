@@ -39,6 +39,7 @@ VOCAB, EOS = 32000, 2
 VICUNA_7B = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=32,
                  vocab_size=VOCAB, max_position_embeddings=2048, rms_norm_eps=1e-6, rope_theta=10000.0)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+HBM_REQUESTS_PER_S = 48.6e9     # measured: scripts/hbm_probe.hip (profiles/r01_hbm_probe.md) -- requests/s whatever their size
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -144,7 +145,10 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
     return dict(bound="hbm", kernel="k_static_walk", achieved=round(gbps, 2), peak=HBM_PEAK_GBPS, unit="GB/s",
                 frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=traffic, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
                 visited_states=n_visited, alg_bytes_per_launch=int(alg_bytes), transitions_per_s=round(B * T / (ms * 1e-3), 1),
-                line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2)), toks
+                line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2),
+                # the walk is request-bound: one 64-byte request per visited state carries 16 algorithmic bytes
+                request_ceiling_gbps=round(HBM_REQUESTS_PER_S * 16 / 1e9, 1),
+                frac_of_request_ceiling=round(gbps / (HBM_REQUESTS_PER_S * 16 / 1e9), 4)), toks
 
 
 def cpu_baseline(flat, off, requests, cfg, toks_walk, budget_s=12.0):
