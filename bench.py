@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--corpus-tokens", type=int, default=1 << 22)
     ap.add_argument("--acceptance", choices=["scripted", "natural"], default="scripted")
+    ap.add_argument("--variant", choices=["sam_only", "token_recycle"], default="sam_only",
+                    help="sam_only = BASELINE configs[1] (the headline); token_recycle = configs[2] (samd[Token Recycle], n_predicts 40, "
+                         "len_threshold 5, len_bias 5): informational, the table learns from the random-init model's logits")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the result is then not a benchmark)")
     ap.add_argument("--walk-streams", type=int, default=1 << 20)
     ap.add_argument("--walk-tokens", type=int, default=16)
@@ -258,8 +261,15 @@ def main():
     runner = LlamaRunner.random_init(mcfg, max_len, torch.float16, seed=0)
     lm = ScriptedAcceptance(runner, VOCAB, max_len) if args.acceptance == "scripted" else runner
 
-    samd_cfg = SO.SamdConfig(**cfg)
-    model = SO.SamdModel(samd_cfg, lm, SO.DraftModel(samd_cfg, sam_static=sam, device="cuda"), EOS, torch.float16, "cuda")
+    if args.variant == "sam_only":
+        samd_cfg = SO.SamdConfig(**cfg)
+        model = SO.SamdModel(samd_cfg, lm, SO.DraftModel(samd_cfg, sam_static=sam, device="cuda"), EOS, torch.float16, "cuda")
+    else:
+        import samd as S
+        auto_s = samd_hip.StaticAutomaton.build_flat(flat, off, EOS, samd_hip.KIND_ENDPOS).upload()
+        samd_cfg = S.SamdConfig(n_predicts=40, len_threshold=5, len_bias=5, tree_method="token_recycle")
+        draft = S.DraftModel(samd_cfg, sam_static=S.sam.StaticSAM._from_automaton(auto_s), lm=runner, device="cuda")
+        model = S.SamdModel(samd_cfg, lm, draft, EOS, torch.float16, "cuda")
     gcfg = SO.SamdGenerationConfig(max_new_tokens=512, max_cache_len=max_len)
     model.set_cache(gcfg)
     model.engine.use_graphs = not args.no_graphs
@@ -328,6 +338,8 @@ def main():
                                      overhead_frac=round((ms_full - ms_fwd) / ms_full, 4),
                                      weight_gbps=round(runner.weight_bytes() / (ms_fwd * 1e-3) / 1e9, 1))
         # autoregressive baseline: same kernels, max_predicts = 1 (the reference's cli_baseline.py does exactly this)
+        if args.variant != "sam_only":
+            import samd_sam_only as SO  # noqa: F811  (the AR baseline always runs through the SAM-only loop)
         ar_cfg = SO.SamdConfig(max_predicts=1, alpha=4.0, K=8, len_bias=0)
         ar = SO.SamdModel(ar_cfg, lm, SO.DraftModel(ar_cfg, device="cuda"), EOS, torch.float16, "cuda")
         ar.set_cache(gcfg)
@@ -360,7 +372,7 @@ def main():
                                    "len_bias 0, K 8; prompts 512 tokens, max_new_tokens 512, max_cache_len 2048",
                        "layers": mcfg["num_hidden_layers"], "corpus_tokens": int(args.corpus_tokens),
                        "static_sam_states": int(sam_info["n_states"]), "static_sam_bytes": int(sam_info["device_bytes"]),
-                       "acceptance": args.acceptance, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
+                       "acceptance": args.acceptance, "variant": args.variant, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
                        "hipgraphs": not args.no_graphs},
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},

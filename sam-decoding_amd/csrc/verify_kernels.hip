@@ -302,36 +302,52 @@ struct samd_recycle {
     int32_t *d_child_off, *d_children, *d_level_off, *d_level_nodes;
 };
 
-// logits.topk(8).indices per row: 8 selection rounds in (value desc, index asc) order
+// logits.topk(8).indices per row in (value desc, index asc) order -- torch.topk's order on tie-free rows.
+// One pass over the row: every thread keeps the best 8 of its strided elements in registers (insertion into a sorted
+// list), the 256 x 8 survivors meet in LDS and 8 block arg-max rounds pick the winners.
+__device__ __forceinline__ bool topk_before(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_topk8_rows(const T *__restrict__ logits, int rows, long long vocab, long long stride,
                                                     const int *__restrict__ d_rows, int *__restrict__ out) {
     const int row = blockIdx.x;
     if ((d_rows && row >= d_rows[0]) || row >= rows) return;
     const T *x = logits + (size_t)row * stride;
-    __shared__ float sv[4]; __shared__ long long si[4];
-    __shared__ float pv_s; __shared__ long long pi_s;
-    float pv = INFINITY; long long pi = -1;
+    float bv[8]; int bi[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
+    for (long long i = threadIdx.x; i < vocab; i += blockDim.x) {
+        float v = to_f32(x[i]); int id = (int)i;
+        if (!topk_before(v, id, bv[7], bi[7])) continue;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {                      // sorted insertion: swap the carried element down the list
+            if (topk_before(v, id, bv[k], bi[k])) { const float tv = bv[k]; const int ti = bi[k]; bv[k] = v; bi[k] = id; v = tv; id = ti; }
+        }
+    }
+    __shared__ float sv[256 * 8]; __shared__ int si[256 * 8];
+    __shared__ float wv[4]; __shared__ int wi[4], wslot[4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sv[threadIdx.x * 8 + k] = bv[k]; si[threadIdx.x * 8 + k] = bi[k]; }
+    __syncthreads();
     for (int round = 0; round < 8; round++) {
-        float best = -INFINITY; long long bi = 0x7fffffffffffffffll;
-        for (long long i = threadIdx.x; i < vocab; i += blockDim.x) {
-            const float v = to_f32(x[i]);
-            const bool eligible = (v < pv) || (v == pv && i > pi);
-            if (eligible && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+        float best = -INFINITY; int bidx = 0x7fffffff, bslot = -1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int slot = threadIdx.x * 8 + k;
+            if (si[slot] != 0x7fffffff && (bslot < 0 || topk_before(sv[slot], si[slot], best, bidx))) { best = sv[slot]; bidx = si[slot]; bslot = slot; }
         }
         for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o); const long long oi = __shfl_xor(bi, o);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bidx, o), os = __shfl_xor(bslot, o);
+            if (os >= 0 && (bslot < 0 || topk_before(ov, oi, best, bidx))) { best = ov; bidx = oi; bslot = os; }
         }
-        if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+        if ((threadIdx.x & 63) == 0) { wv[threadIdx.x >> 6] = best; wi[threadIdx.x >> 6] = bidx; wslot[threadIdx.x >> 6] = bslot; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int k = 1; k < 4; k++) if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
-            out[(size_t)row * 8 + round] = bi == 0x7fffffffffffffffll ? 0 : (int)bi;
-            pv_s = best; pi_s = bi;
+            for (int k = 1; k < 4; k++)
+                if (wslot[k] >= 0 && (bslot < 0 || topk_before(wv[k], wi[k], best, bidx))) { best = wv[k]; bidx = wi[k]; bslot = wslot[k]; }
+            out[(size_t)row * 8 + round] = bslot < 0 ? 0 : bidx;
+            if (bslot >= 0) si[bslot] = 0x7fffffff;          // consumed
         }
-        __syncthreads();
-        pv = pv_s; pi = pi_s;
         __syncthreads();
     }
 }
