@@ -38,6 +38,10 @@ for p in (ROOT, os.path.join(ROOT, "sam-decoding_amd")):
 VOCAB, EOS = 32000, 2
 VICUNA_7B = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=32,
                  vocab_size=VOCAB, max_position_embeddings=2048, rms_norm_eps=1e-6, rope_theta=10000.0)
+LLAMA3_8B = dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+                 vocab_size=128256, max_position_embeddings=8192, rms_norm_eps=1e-5,
+                 rope_parameters=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                      original_max_position_embeddings=8192, rope_theta=500000.0))
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 HBM_REQUESTS_PER_S = 48.6e9     # measured: scripts/hbm_probe.hip (profiles/r01_hbm_probe.md) -- requests/s whatever their size
 
@@ -220,6 +224,9 @@ def main():
     ap.add_argument("--variant", choices=["sam_only", "token_recycle"], default="sam_only",
                     help="sam_only = BASELINE configs[1] (the headline); token_recycle = configs[2] (samd[Token Recycle], n_predicts 40, "
                          "len_threshold 5, len_bias 5): informational, the table learns from the random-init model's logits")
+    ap.add_argument("--model", choices=["vicuna-7b", "llama3-8b"], default="vicuna-7b",
+                    help="vicuna-7b fp16 = the headline configuration; llama3-8b bf16 = the shape of BASELINE configs[3] (informational; "
+                         "the synthetic corpus keeps the 32000-token vocabulary)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the result is then not a benchmark)")
     ap.add_argument("--walk-streams", type=int, default=1 << 20)
     ap.add_argument("--walk-tokens", type=int, default=16)
@@ -254,22 +261,23 @@ def main():
     sam_info = auto.info()
     sam = SO.sam.StaticSAM._from_automaton(auto)
 
-    mcfg = dict(VICUNA_7B)
+    mcfg = dict(VICUNA_7B if args.model == "vicuna-7b" else LLAMA3_8B)
+    dtype = torch.float16 if args.model == "vicuna-7b" else torch.bfloat16
     if args.layers:
         mcfg["num_hidden_layers"] = args.layers
-    max_len = mcfg["max_position_embeddings"]
-    runner = LlamaRunner.random_init(mcfg, max_len, torch.float16, seed=0)
+    max_len = min(mcfg["max_position_embeddings"], 2048)      # requests are 512 + 512 tokens; the cache guard uses this length
+    runner = LlamaRunner.random_init(mcfg, max_len, dtype, seed=0)
     lm = ScriptedAcceptance(runner, VOCAB, max_len) if args.acceptance == "scripted" else runner
 
     if args.variant == "sam_only":
         samd_cfg = SO.SamdConfig(**cfg)
-        model = SO.SamdModel(samd_cfg, lm, SO.DraftModel(samd_cfg, sam_static=sam, device="cuda"), EOS, torch.float16, "cuda")
+        model = SO.SamdModel(samd_cfg, lm, SO.DraftModel(samd_cfg, sam_static=sam, device="cuda"), EOS, dtype, "cuda")
     else:
         import samd as S
         auto_s = samd_hip.StaticAutomaton.build_flat(flat, off, EOS, samd_hip.KIND_ENDPOS).upload()
         samd_cfg = S.SamdConfig(n_predicts=40, len_threshold=5, len_bias=5, tree_method="token_recycle")
         draft = S.DraftModel(samd_cfg, sam_static=S.sam.StaticSAM._from_automaton(auto_s), lm=runner, device="cuda")
-        model = S.SamdModel(samd_cfg, lm, draft, EOS, torch.float16, "cuda")
+        model = S.SamdModel(samd_cfg, lm, draft, EOS, dtype, "cuda")
     gcfg = SO.SamdGenerationConfig(max_new_tokens=512, max_cache_len=max_len)
     model.set_cache(gcfg)
     model.engine.use_graphs = not args.no_graphs
@@ -341,7 +349,7 @@ def main():
         if args.variant != "sam_only":
             import samd_sam_only as SO  # noqa: F811  (the AR baseline always runs through the SAM-only loop)
         ar_cfg = SO.SamdConfig(max_predicts=1, alpha=4.0, K=8, len_bias=0)
-        ar = SO.SamdModel(ar_cfg, lm, SO.DraftModel(ar_cfg, device="cuda"), EOS, torch.float16, "cuda")
+        ar = SO.SamdModel(ar_cfg, lm, SO.DraftModel(ar_cfg, device="cuda"), EOS, dtype, "cuda")
         ar.set_cache(gcfg)
         prompt, target = req_log[0]
         if args.acceptance == "scripted":
@@ -365,12 +373,12 @@ def main():
             "metric": "tokens/sec (+ mean accepted tokens), Vicuna-7B bs=1, samd_sam_only draft+verify",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic: random-init Vicuna-7B-shaped weights (seed 0), seeded Markov corpus + request streams; "
+            "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic: random-init Vicuna-7B-shaped weights (seed 0), seeded Markov corpus + request streams; "
                                     + ("LM arg-max replaced after the full forward by each request's continuation stream"
                                        if args.acceptance == "scripted" else "the random-init model's own arg-max"),
             "config": {"workload": "BASELINE.json configs[1]: samd_sam_only, Vicuna-7B-v1.3 shape fp16, bs=1, max_predicts 60, alpha 4, "
                                    "len_bias 0, K 8; prompts 512 tokens, max_new_tokens 512, max_cache_len 2048",
-                       "layers": mcfg["num_hidden_layers"], "corpus_tokens": int(args.corpus_tokens),
+                       "model_shape": args.model, "layers": mcfg["num_hidden_layers"], "corpus_tokens": int(args.corpus_tokens),
                        "static_sam_states": int(sam_info["n_states"]), "static_sam_bytes": int(sam_info["device_bytes"]),
                        "acceptance": args.acceptance, "variant": args.variant, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
                        "hipgraphs": not args.no_graphs},
