@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     const int ntiles = (total + ATT_TILE - 1) / ATT_TILE;
     const int tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
     const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
+    if (t0 >= t1) return;                              // no keys for this split: k_attn_combine only reads the splits in use
     const int kvh = h / (n_heads / n_kv_heads);
     const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
     const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
@@ -273,15 +274,18 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 
 template <typename E>
 __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
-                                                      const int *__restrict__ d_n) {
+                                                      const int *__restrict__ d_L, const int *__restrict__ d_n) {
     const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
     int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
     E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d;
     if (row >= n) { *dst = (E)0.f; return; }
+    // the splits k_tree_attention actually ran (same arithmetic as there): the others left their partials untouched
+    const int ntiles = (d_L[0] + n + ATT_TILE - 1) / ATT_TILE, tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
+    const int used = (ntiles + tps - 1) / tps;
     float M = -INFINITY;
-    for (int s = 0; s < ATT_SPLITS; s++) M = fmaxf(M, ws[(((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2) + ATT_D]);
+    for (int s = 0; s < used; s++) M = fmaxf(M, ws[(((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2) + ATT_D]);
     float num = 0.f, den = 0.f;
-    for (int s = 0; s < ATT_SPLITS; s++) {
+    for (int s = 0; s < used; s++) {
         const float *p = ws + (((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
         const float m = p[ATT_D];
         if (m == -INFINITY) continue;
@@ -461,12 +465,12 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
         hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
                            (const _Float16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
-        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_n);
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n);
     } else {
         hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
                            (const __bf16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
-        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_n);
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n);
     }
     LAUNCHCHK();
     return SAMD_OK;

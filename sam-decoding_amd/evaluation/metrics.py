@@ -1,6 +1,6 @@
 """speed / equal (reference: evaluation/speed.py:7-69, evaluation/equal.py:6-54)."""
 import json
-from typing import Callable, List, Optional, Union
+from typing import Callable, Optional, Union
 
 import numpy as np
 

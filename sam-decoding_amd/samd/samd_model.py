@@ -16,7 +16,7 @@ from samd_sam_only.model_patch.llama import mask_rows_u64
 from samd_sam_only.samd_model import Outputs, SamdModel as _SoSamdModel  # noqa: F401
 from .draft import DraftModel
 from .samd_config import ForwardType, SamdConfig
-from .utils import CandidateType, OptionalTensor, SamdGenerationConfig, eval_posterior, gen_candidates
+from .utils import CandidateType, OptionalTensor, eval_posterior, gen_candidates
 
 
 class SamdModel(_SoSamdModel):

@@ -16,7 +16,7 @@ reference (tests/golden/eagle2.npz).
 """
 import math
 import os
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F

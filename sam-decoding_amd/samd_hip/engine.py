@@ -10,12 +10,13 @@ posterior, SAM update, KV compaction -- is here a fixed sequence of kernels on o
 The sequence is captured once per row bucket R into a hipGraph; the host replays it and reads the 704-byte report
 (accepted tokens, next draft size) to apply the reference's stopping rules.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
 from . import (F32, MAX_DRAFT, REP_COUNTERS, REP_DMETA, REP_KVINDEX, REP_META, REP_TOKENS, REP_VERDICT, REPORT_INTS,
-               Params, SamdError, Session, StaticAutomaton, TokenRecycleTable, _ptr, check, current_stream, lib,
-               require_gpu, torch_dtype_code)
+               Params, SamdError, Session, StaticAutomaton, TokenRecycleTable, require_gpu, torch_dtype_code)
 
 
 class StepReport:
@@ -170,7 +171,6 @@ class DecodeEngine:
         self._graphs = {}
         self._views = session.device_views()
         self._n_ptr = self._views["dmeta"] + 4
-        self.timing = None
 
     # ---- pieces ---------------------------------------------------------------------------------------
     def _recycle_update(self, d_tokens, logits, n_rows, d_n):
@@ -185,7 +185,6 @@ class DecodeEngine:
     def _enqueue_step(self, R):
         b = self.verifier.verify(self.session, R)
         if self.recycle is not None:
-            import ctypes as C
             self._recycle_update(self._views["tokens"], b["logits"], min(R, MAX_DRAFT), C.c_void_p(self._n_ptr))
         self.session.step(self.static, self.params, b["argmax"])
         if self.recycle is not None:
@@ -226,15 +225,13 @@ class DecodeEngine:
         return StepReport(self._report_np)
 
     def _capture(self, R):
-        """capture the step for row bucket R.  The warm-up run executes a real step (it advances the request by one
-        step exactly like a replay would), so capture happens on a side copy of nothing: we snapshot nothing and
-        instead capture without running -- hipGraph capture records launches without executing them."""
-        stream = torch.cuda.current_stream()
+        """capture the step for row bucket R.  Capture records the launches without executing them, so the request's
+        state is untouched; the verifier first runs the bucket once with n = 0 rows (no K/V write, every query row
+        masked) so that library handles / workspaces exist before capture."""
         g = torch.cuda.CUDAGraph()
-        # library handles (hipBLASLt workspaces) must exist before capture: warm the GEMMs of this bucket on scratch
         self._warm(R)
-        stream.synchronize()
-        with torch.cuda.graph(g, stream=stream if stream != torch.cuda.default_stream() else None):
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.graph(g):
             self._enqueue_step(R)
         self._graphs[R] = g
         return g

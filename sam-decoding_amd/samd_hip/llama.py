@@ -101,7 +101,6 @@ class LlamaRunner:
         self.rope_rows = max_pos
         self.scale = 1.0 / math.sqrt(s.head_dim)
         self._buf = {}
-        self._graphs = {}
         # prefill staging (chunks of MAX_DRAFT rows with a causal chain mask)
         self.pf_tokens = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
         self.pf_relpos = torch.arange(MAX_DRAFT, dtype=torch.int32, device=self.device)
@@ -117,7 +116,6 @@ class LlamaRunner:
         self.kv = storage
         self.kv_ptrs = torch.tensor([storage[l, j].data_ptr() for j in (0, 1) for l in range(s.layers)],
                                     dtype=torch.int64, device=self.device)
-        self._graphs_dirty = True
 
     # ------------------------------------------------------------------------------------------------
     @classmethod

@@ -9,7 +9,6 @@ from typing import Dict, List
 
 import torch
 
-import samd_hip
 from ._common import CursorOwner, dev_i32, so_params
 
 

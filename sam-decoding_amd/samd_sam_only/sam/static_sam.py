@@ -7,7 +7,6 @@ bound).  Granular calls synchronise; SamdModel.generate() uses the fused step ke
 from dataclasses import dataclass
 from typing import Dict, List
 
-import numpy as np
 import torch
 
 import samd_hip

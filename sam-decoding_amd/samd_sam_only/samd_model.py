@@ -19,11 +19,11 @@ import torch
 import torch.nn as nn
 
 import samd_hip
-from samd_hip.engine import DecodeEngine, StepReport
+from samd_hip.engine import DecodeEngine
 from samd_hip.llama import LlamaRunner
 from .cache import SamdCache, SamdStaticCache
 from .draft import DraftModel
-from .model_patch import attn_patch_dict, patch_dict
+from .model_patch import patch_dict
 from .model_patch.llama import mask_rows_u64
 from .samd_config import ForwardState, ForwardType, MaskState, SamdConfig
 from .utils import CandidateType, OptionalTensor, SamdGenerationConfig, eval_posterior, gen_candidates
