@@ -155,9 +155,11 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
                 frac_of_request_ceiling=round(gbps / (HBM_REQUESTS_PER_S * 16 / 1e9), 4)), toks
 
 
-def cpu_baseline(flat, off, requests, cfg, toks_walk, budget_s=12.0):
-    """the C oracle (single thread, like the reference's Python) on the same request streams: per step
-    lookup -> draft(+buffers) -> greedy accept against the continuation -> update; and the batched walk's CPU twin."""
+def cpu_baseline(flat, off, docs, cfg, toks_walk, wall_budget_s=12.0):
+    """the C oracle (single thread, like the reference's Python) on the same request process as rank 0: per step
+    lookup -> draft(+buffers) -> greedy accept against the continuation -> update; and the batched walk's CPU twin.
+    Runs requests until ~wall_budget_s of wall time is spent; only the oracle's C calls are counted as CPU work (the
+    scripted verdict between them is Python bookkeeping that stands in for the LM)."""
     from oracle import sam_oracle as O
     t0 = time.perf_counter()
     n_build = min(len(off) - 1, 4096 + VOCAB)           # bounded corpus sample for the CPU automaton
@@ -166,14 +168,18 @@ def cpu_baseline(flat, off, requests, cfg, toks_walk, budget_s=12.0):
     st = O.StaticSAM.build(docs_list, EOS)
     build_s = time.perf_counter() - t0
     dm = O.DraftModel(cfg["max_predicts"], cfg["alpha"], cfg["K"], cfg["len_bias"], sam_static=st)
-    spent, steps, tokens = 0.0, 0, 0
-    for prompt, target in requests:
+    rng = np.random.default_rng(1000)
+    spent, steps, tokens, n_req = 0.0, 0, 0, 0
+    t_wall = time.perf_counter()
+    while time.perf_counter() - t_wall < wall_budget_s:
+        prompt, target = synth_request(rng, docs)
+        n_req += 1
         dm.reset()
         t = time.perf_counter()
         dm.update(prompt)
         spent += time.perf_counter() - t
         pos = len(prompt)
-        while pos < len(prompt) + 512 and pos + 70 < len(target) and spent < budget_s:
+        while pos < len(prompt) + 512 and pos + 70 < len(target):
             t = time.perf_counter()
             ty, tok, anc = dm.lookup_raw(target[pos])
             if ty == 1:
@@ -195,8 +201,6 @@ def cpu_baseline(flat, off, requests, cfg, toks_walk, budget_s=12.0):
             pos += len(acc)
             steps += 1
             tokens += len(acc)
-        if spent >= budget_s:
-            break
     # CPU twin of the batched walk (transitions/s, one thread)
     T, B = toks_walk.shape
     nb = min(B, 4096)
@@ -206,8 +210,9 @@ def cpu_baseline(flat, off, requests, cfg, toks_walk, budget_s=12.0):
         st.transfer_tokens(toks_walk[:, b])
     walk_s = time.perf_counter() - t
     return dict(value=round(tokens / max(spent, 1e-9), 1), unit="tokens/s", cores=1, kind="port",
-                sample=f"oracle/sam_oracle.c DraftModel loop (lookup+draft+buffers+update, no LM forward) over {steps} steps of the "
-                       f"same request streams, static automaton from {len(docs_list)} documents ({build_s:.1f} s build); "
+                sample=f"oracle/sam_oracle.c DraftModel loop (lookup+draft+buffers+update, no LM forward) over {steps} steps of {n_req} "
+                       f"requests of rank 0's request process ({time.perf_counter() - t_wall:.0f} s wall incl. the scripted verdict in Python, "
+                       f"{spent:.2f} s inside the oracle), static automaton from {len(docs_list)} documents ({build_s:.1f} s build); "
                        f"walk twin: {nb} streams x {T} tokens",
                 steps=steps, us_per_step=round(spent / max(steps, 1) * 1e6, 2), host_cores_available=os.cpu_count(),
                 walk_transitions_per_s=round(nb * T / max(walk_s, 1e-9), 1))
@@ -364,7 +369,7 @@ def main():
         ar_tps = ar_tokens / (time.perf_counter() - ta)
 
         roof, toks_walk = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20, args.corpus_tokens)
-        cpu = None if args.no_cpu_baseline else cpu_baseline(flat, off, req_log[:4], cfg, toks_walk)
+        cpu = None if args.no_cpu_baseline else cpu_baseline(flat, off, docs, cfg, toks_walk)
 
         n_steps = sum(v[0] for v in stats.values())
         n_tok = sum(v[1] for v in stats.values())
