@@ -244,6 +244,8 @@ class LlamaRunner:
         N = ids.numel()
         if N < 1 or N > self.max_len:
             raise SamdError(f"prompt of {N} tokens does not fit max_cache_len {self.max_len}")
+        if on_chunk is None and N >= 2 * MAX_DRAFT and os.environ.get("SAMD_PREFILL", "wide") != "chunked":
+            return self._prefill_wide(session, ids)
         v = session.device_views()
         b = None
         for c0 in range(0, N, MAX_DRAFT):
@@ -258,6 +260,44 @@ class LlamaRunner:
         session.set_cache_length(N)
         session.set_start_token(b["argmax"][(N - 1) % MAX_DRAFT:])
         return b["logits"][(N - 1) % MAX_DRAFT]
+
+    def _prefill_wide(self, session: Session, ids):
+        """the whole prompt in one pass: compute-bound, so the GEMMs go to the library (N x K x N_out at full MFMA rate) and
+        the causal attention to PyTorch's fused SDPA; norm / RoPE + K/V write / SiLU*up / arg-max stay our kernels.  Used
+        when no per-chunk consumer (Token Recycle, EAGLE-2) needs the prompt's logits or hidden states."""
+        L, s, dt, st, N = lib(), self.shape, self.dt, current_stream(), ids.numel()
+        dev, ty = self.device, self.dtype
+        z = lambda *sz: torch.empty(sz, dtype=ty, device=dev)
+        x, h, qkv = z(N, s.hidden), z(N, s.hidden), z(N, (s.heads + 2 * s.kv_heads) * s.head_dim)
+        q, o, gu, act, d = z(N, s.heads, s.head_dim), z(N, s.hidden), z(N, 2 * s.inter), z(N, s.inter), z(N, s.hidden)
+        relpos = torch.arange(N, dtype=torch.int32, device=dev)
+        d_L = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_n = torch.full((1,), N, dtype=torch.int32, device=dev)
+        check(L.samd_embed_rows(_ptr(ids), _ptr(self.w["embed"]), _ptr(x), N, s.hidden, s.vocab, dt, st))
+        delta = None
+        for li, w in enumerate(self.w["layers"]):
+            check(L.samd_rmsnorm(_ptr(x), _ptr(delta), _ptr(w["ln1"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
+            torch.mm(h, w["wqkv"].t(), out=qkv)
+            check(L.samd_rope_kv_write(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
+                                       _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), N, s.heads, s.kv_heads, s.head_dim, self.max_len,
+                                       self.rope_rows, dt, 0, 0, st))
+            kk, vv = self.kv[li, 0][:, :N], self.kv[li, 1][:, :N]
+            if s.kv_heads != s.heads:
+                kk, vv = kk.repeat_interleave(s.heads // s.kv_heads, dim=0), vv.repeat_interleave(s.heads // s.kv_heads, dim=0)
+            att = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1)[None], kk[None], vv[None], is_causal=True, scale=self.scale)
+            torch.mm(att[0].transpose(0, 1).reshape(N, -1), w["wo"].t(), out=o)
+            check(L.samd_rmsnorm(_ptr(x), _ptr(o), _ptr(w["ln2"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
+            torch.mm(h, w["wgu"].t(), out=gu)
+            check(L.samd_silu_mul(_ptr(gu), _ptr(act), N, s.inter, dt, 0, 0, st))
+            torch.mm(act, w["wdown"].t(), out=d)
+            delta = d
+        check(L.samd_rmsnorm(_ptr(x), _ptr(delta), _ptr(self.w["norm"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
+        b = self._buffers(1)
+        torch.mm(h[N - 1:N], self.w["lm_head"].t(), out=b["logits"][:1])
+        check(L.samd_argmax_rows(_ptr(b["logits"]), dt, 1, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
+        session.set_cache_length(N)
+        session.set_start_token(b["argmax"])
+        return b["logits"][0]
 
     def warm(self, R):
         """run the launch sequence of bucket R once with n = 0 rows (no K/V row is written, every query row is

@@ -243,3 +243,25 @@ def test_token_recycle_on_real_logits_is_lossless():
         assert not diff or (diff[0] > len(prompt) + 4 and _near_tie(lm, seq[:diff[0]], seq[diff[0]], seq_ar[diff[0]])), diff[:3]
     assert out.decode_steps < out.decode_tokens, "Token Recycle never got a draft accepted on a repeated request"
     assert len(draft.tree_model.cache) > 0
+
+
+def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
+    """prompts of >= 128 tokens go through the one-pass prefill (library GEMMs + fused causal SDPA); K/V cache, last
+    logits and the following decode must agree with the chunked path and with HF (fp16 tolerance 3e-2)."""
+    lm = tiny_llama(2, seed=13)
+    rng = np.random.default_rng(13)
+    prompt = rng.integers(3, 512, 200).tolist()
+    ids = torch.tensor([prompt], device="cuda")
+    outs = {}
+    for mode in ("wide", "chunked"):
+        monkeypatch.setenv("SAMD_PREFILL", mode)
+        runner = LlamaRunner.from_hf(lm, max_cache_len=512, dtype=torch.float16)
+        sess = samd_hip.Session(1024)
+        last = runner.prefill(sess, ids)
+        torch.cuda.synchronize()
+        outs[mode] = (last.float().clone(), runner.kv[:, :, :, :200].float().clone(), sess.get_cache_length())
+    with torch.no_grad():
+        ref = lm(input_ids=ids).logits[0, -1]
+    assert outs["wide"][2] == outs["chunked"][2] == 200
+    assert (outs["wide"][0] - ref).abs().max().item() < TOL and (outs["chunked"][0] - ref).abs().max().item() < TOL
+    assert (outs["wide"][1] - outs["chunked"][1]).abs().max().item() < 2e-2          # same K/V rows up to fp16 GEMM rounding
