@@ -124,7 +124,8 @@ extern "C" {
 // that the fp32 partials (written here, read by the consumer) stay a small fraction of the weight bytes
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad) {
     const int cols = N / GEMM_COLS, chunks = K / GEMM_KC;
-    const int cap = rows_pad <= 32 ? 8 : 4;
+    int cap = rows_pad <= 32 ? 8 : 4;
+    if (const char *e = getenv("SAMD_GEMM_SPLIT_CAP")) cap = atoi(e);
     int s = 1;
     while (cols * s < 512 && s * 2 <= chunks && s * 2 <= cap) s *= 2;
     return s;

@@ -89,7 +89,7 @@ class LlamaRunner:
         qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
         shapes = [(qkv_out, s.hidden), (s.hidden, s.heads * s.head_dim), (2 * s.inter, s.hidden), (s.hidden, s.inter), (s.vocab, s.hidden)]
         self.native_gemm = bool(native_gemm) and all(n % 128 == 0 and k % 256 == 0 for n, k in shapes)
-        self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 16))     # tuning knob; see forward_rows
+        self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 32))     # tuning knob; see forward_rows
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
         self.bind_cache(kv if kv is not None else
                         torch.zeros((s.layers, 2, s.kv_heads, self.max_len, s.head_dim), dtype=dtype, device=self.device))
@@ -204,7 +204,7 @@ class LlamaRunner:
             """out = a @ w.T; returns (operand pointer for the consumer, n_partials, partial_stride)."""
             n, k = w.shape
             # measured on MI355X (scripts/forward_ablation.py, whole forward incl. the consumers' partial-sum reads):
-            # the weight-streaming kernel wins up to 16 rows (4.30 vs 4.75 ms), ties at 32, loses at 64 (5.51 vs 5.22 ms)
+            # the weight-streaming kernel wins at <= 16 rows (4.28 vs 4.75 ms) and at 32 (4.52 vs 4.62 ms), loses at 64 (5.51 vs 5.22 ms)
             if not self.native_gemm or RP > self.native_gemm_max_rows:
                 torch.mm(a[:R], w.t(), out=out[:R])
                 return out, 0, 0
