@@ -1,33 +1,19 @@
-"""build_sam / dump_sam / load_sam of the full variant (reference: samd/sam/utils.py:10-37); same flat image format as
-samd_sam_only, automaton kind = first end positions + text."""
-import pickle
-import time
+"""build_sam / dump_sam / load_sam of the full variant (reference surface: samd/sam/utils.py:10-37): the automaton keeps first
+end positions and the corpus text instead of occurrence counts; same flat image format as samd_sam_only."""
 from typing import List
 
-import samd_hip
+from samd_sam_only.sam.utils import load_image_or_pickle
 from .static_sam import StaticSAM
 
 
-def build_sam(batch_tokens: List[List[int]], eos_token: int):
+def build_sam(batch_tokens: List[List[int]], eos_token: int) -> StaticSAM:
     return StaticSAM.build(batch_tokens, eos_token)
 
 
-def dump_sam(path: str, sam: StaticSAM):
+def dump_sam(path: str, sam: StaticSAM) -> None:
     sam.init_topk_next()
     sam._auto.save(path)
 
 
-def load_sam(path: str):
-    print("load sam...")
-    start = time.perf_counter()
-    with open(path, "rb") as f:
-        magic = f.read(8)
-    if magic == b"SAMDHIP1":
-        sam = StaticSAM._from_automaton(samd_hip.StaticAutomaton.load(path))
-    else:
-        with open(path, "rb") as f:
-            sam = pickle.load(f)
-        assert type(sam) is StaticSAM
-        sam.init_topk_next()
-    print("loading ended in {} seconds.".format(time.perf_counter() - start))
-    return sam
+def load_sam(path: str) -> StaticSAM:
+    return load_image_or_pickle(path, StaticSAM)

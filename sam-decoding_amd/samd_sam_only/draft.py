@@ -26,7 +26,37 @@ Candidates = namedtuple('Candidates', ['type', 'tokens', 'candidate_tokens', 'bu
 TOPK = samd_hip.TOPK
 
 
-class DraftModel(torch.nn.Module):
+class SessionPlumbing:
+    """what both variants' DraftModel need to hand to SamdModel's fused path: the shared device session (the DynSAM's
+    arena, which also carries the static cursor, the draft block and the verdict) and the uploaded static automaton."""
+
+    def session(self) -> samd_hip.Session:
+        s = self.sam_dyn._sess()
+        if self.sam_static is not None:
+            self.sam_static._bind(s)
+        return s
+
+    def ensure_capacity(self, max_tokens: int):
+        """the dynamic automaton's arena is bounded (prompt + generated tokens <= max_cache_len)."""
+        if self.sam_dyn._session is None:
+            self.sam_dyn._own_capacity = max(self.sam_dyn._own_capacity, int(max_tokens))
+        elif self.sam_dyn._session.max_tokens < max_tokens:
+            self.sam_dyn._session = samd_hip.Session(int(max_tokens))
+        return self.session()
+
+    def static_automaton(self) -> Optional[samd_hip.StaticAutomaton]:
+        return None if self.sam_static is None else self.sam_static._automaton()
+
+    def _extend(self, tokens: torch.Tensor):
+        """DynSAM.add_tokens + StaticSAM.transfer_tokens of the same tokens (draft.py:62-67)."""
+        t = tokens.reshape(-1).to(device="cuda", dtype=torch.int32)
+        if t.numel():
+            s = self.session()
+            s.add_tokens(t)
+            s.static_walk(self.static_automaton(), t, t.numel(), commit=True)
+
+
+class DraftModel(SessionPlumbing, torch.nn.Module):
 
     def __init__(self,
         config: SamdConfig,
@@ -52,24 +82,6 @@ class DraftModel(torch.nn.Module):
         self.len_bias = config.len_bias
         self._start = None
 
-    # ---- device handles used by SamdModel's fused path ----------------------------------------------------------
-    def session(self) -> samd_hip.Session:
-        s = self.sam_dyn._sess()
-        if self.sam_static is not None:
-            self.sam_static._bind(s)
-        return s
-
-    def ensure_capacity(self, max_tokens: int):
-        """the dynamic automaton's arena is bounded (prompt + generated tokens <= max_cache_len)."""
-        if self.sam_dyn._session is None:
-            self.sam_dyn._own_capacity = max(self.sam_dyn._own_capacity, int(max_tokens))
-        elif self.sam_dyn._session.max_tokens < max_tokens:
-            self.sam_dyn._session = samd_hip.Session(int(max_tokens))
-        return self.session()
-
-    def static_automaton(self) -> Optional[samd_hip.StaticAutomaton]:
-        return None if self.sam_static is None else self.sam_static._automaton()
-
     def params(self) -> samd_hip.Params:
         c = self.config
         return so_params(c.max_predicts, c.alpha, c.K, self.len_bias)
@@ -94,12 +106,7 @@ class DraftModel(torch.nn.Module):
 
     def update(self, tokens: Optional[torch.Tensor] = None):
         """draft.py:62-67: dyn add_tokens + static transfer_tokens of the accepted tokens."""
-        t = tokens.reshape(-1).to(device="cuda", dtype=torch.int32)
-        if t.numel() == 0:
-            return
-        s = self.session()
-        s.add_tokens(t)
-        s.static_walk(self.static_automaton(), t, t.numel(), commit=True)
+        self._extend(tokens)
 
     def prefill_update(self, tokens: Optional[torch.Tensor] = None):
         self.update(tokens)

@@ -1,0 +1,100 @@
+"""Candidate construction and posterior evaluation in their host-visible (granular) form.
+
+Reference semantics: samd_sam_only/utils.py:66-104 (gen_candidates) and :107-184 (eval_posterior).  SamdModel.generate()
+does not come through here -- the fused step kernel applies the same rules on the device (sam_device.h: do_accept) --
+these functions serve SamdModel.decode() and tools that drive single steps.  Given identical logits the greedy branch
+is integer-exact with the reference, including its padding quirks (pad token 0 for candidates, the LAST tree node's
+logits for -1 retrieve entries)."""
+import random
+from typing import Callable, Optional
+
+import torch
+
+import samd_hip
+from .draft import Candidates, CandidateType
+
+
+class OptionalTensor:
+    """a tensor or nothing, with map semantics (utils.py:19-28)."""
+
+    def __init__(self, data: Optional[torch.Tensor] = None):
+        self.data = data
+
+    def apply(self, fn: Callable) -> 'OptionalTensor':
+        return self if self.data is None else OptionalTensor(fn(self.data))
+
+
+def device_argmax(logits: torch.Tensor) -> torch.Tensor:
+    """arg-max over the last dimension by the library kernel (first maximum wins, like torch.argmax) -> int64."""
+    vocab = logits.shape[-1]
+    rows = logits.reshape(-1, vocab)
+    if not rows.is_cuda or rows.stride(-1) != 1 or rows.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise samd_hip.SamdError("device_argmax needs contiguous CUDA logits in f16/bf16/f32 (there is no CPU path)")
+    out = torch.zeros(rows.shape[0], dtype=torch.int32, device=rows.device)
+    if rows.shape[0]:
+        samd_hip.check(samd_hip.lib().samd_argmax_rows(samd_hip._ptr(rows), samd_hip.torch_dtype_code(rows.dtype), rows.shape[0], vocab,
+                                                       rows.stride(0), None, samd_hip._ptr(out), samd_hip.current_stream()))
+    return out.to(torch.long).reshape(logits.shape[:-1])
+
+
+def gen_candidates(sample_p, tree_retrieve_indices, draft, samd_config, gen_config, device):
+    """start token (arg-max, or a multinomial draw when sampling) -> draft.lookup -> Candidates.  Tree drafts are gathered
+    through the retrieve table after appending the pad token 0, so that -1 entries select it."""
+    start = device_argmax(sample_p).reshape(-1)[0] if gen_config.greedy else torch.multinomial(sample_p, 1).reshape(-1)[0]
+    kind, draft_tokens, buffers = draft.lookup(int(start.item()))
+    as_row = torch.tensor([draft_tokens], dtype=torch.long, device=device)
+    if kind == CandidateType.sequence:
+        return Candidates(kind, as_row, as_row, buffers)
+    retrieve = buffers.get("tree_retrieve_indices", tree_retrieve_indices)
+    padded = torch.cat((as_row[0], torch.zeros(1, dtype=torch.long, device=device)))
+    return Candidates(kind, as_row, padded[retrieve], buffers)
+
+
+def _greedy(logits, candidates):
+    """longest prefix of every candidate that the arg-max chain reproduces; the first longest candidate wins."""
+    predicted = device_argmax(logits)[:, :-1]
+    agree = (candidates[:, 1:] == predicted).to(torch.int32)
+    accepted = torch.cumprod(agree, dim=1).sum(dim=1)                 # per candidate
+    longest = accepted.max()
+    best = torch.argmax(accepted).to(torch.long) if longest != 0 else torch.zeros((), dtype=torch.long, device=candidates.device)
+    return best, longest + 1, logits[best, longest].view(1, -1)
+
+
+def _sampled(logits, candidates, config):
+    """utils.py:142-184: walk the candidate trie depth by depth; at each depth try the distinct next tokens of the surviving
+    candidates in row order, accepting token x with probability p(x) under the warped distribution (host `random`), and
+    renormalising the residual after every rejection."""
+    n_rows, depth = candidates.shape
+    prefix, n_acc, best = candidates[0][:1], 1, 0
+    residual, rejected_last = None, False
+    while n_acc < depth:
+        rejected_last = False
+        alive = (candidates[:, :n_acc] == prefix).all(dim=1)
+        anchor = int(torch.nonzero(alive, as_tuple=True)[0][0])
+        residual = torch.softmax(config.logits_processor(None, logits[anchor, n_acc - 1][None])[0], dim=0)
+        seen, grown = set(), False
+        for row in range(n_rows):
+            token = int(candidates[row, n_acc]) if bool(alive[row]) else -1
+            if token == -1 or token in seen:
+                continue
+            seen.add(token)
+            if random.random() <= float(residual[token]):
+                prefix = torch.cat((prefix, candidates[row, n_acc][None]))
+                n_acc, best, grown = n_acc + 1, row, True
+                break
+            residual[token] = 0
+            residual = residual / residual.sum()
+            rejected_last = True
+        if not grown:
+            break
+    if rejected_last and n_acc != depth:
+        sample_p = residual
+    else:
+        sample_p = torch.softmax(logits[best, n_acc - 1], dim=0)
+    dev = candidates.device
+    return torch.tensor(best, dtype=torch.long, device=dev), torch.tensor(n_acc, dtype=torch.long, device=dev), sample_p.view(1, -1)
+
+
+def eval_posterior(logits: torch.Tensor, candidates: torch.Tensor, config):
+    """logits [C, depth, V], candidates [C, depth] -> (best_candidate, accept_length, next sample_p [1, V])."""
+    return _greedy(logits, candidates) if config.greedy else _sampled(logits, candidates, config)

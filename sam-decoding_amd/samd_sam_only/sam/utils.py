@@ -22,17 +22,22 @@ def dump_sam(path: str, sam: StaticSAM):
     sam._auto.save(path)
 
 
-def load_sam(path: str):
+def load_image_or_pickle(path: str, cls):
+    """a SAMDHIP1 image, or a pickle of the reference's object graph that unpickles into `cls` (its __setstate__ converts)."""
     print("load sam...")
     start = time.perf_counter()
     with open(path, "rb") as f:
-        magic = f.read(8)
-    if magic == b"SAMDHIP1":
-        sam = StaticSAM._from_automaton(samd_hip.StaticAutomaton.load(path))
+        is_image = f.read(8) == b"SAMDHIP1"
+    if is_image:
+        sam = cls._from_automaton(samd_hip.StaticAutomaton.load(path))
     else:
         with open(path, "rb") as f:
             sam = pickle.load(f)
-        assert type(sam) is StaticSAM
+        assert type(sam) is cls
         sam.init_topk_next()
     print("loading ended in {} seconds.".format(time.perf_counter() - start))
     return sam
+
+
+def load_sam(path: str):
+    return load_image_or_pickle(path, StaticSAM)

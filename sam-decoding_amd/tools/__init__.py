@@ -1,0 +1,1 @@
+"""Corpus tooling for the MI355X path (static-automaton builder CLI)."""
