@@ -225,3 +225,67 @@ def test_generate_random_cases_vs_oracle(seed):
     out = model.generate(torch.tensor([prompt], dtype=torch.long, device="cuda"), generation_config=gcfg)
     assert out.output_ids == [want["output_ids"]]
     assert (out.decode_tokens, out.decode_steps, out.accepet_length_per_step) == (want["decode_tokens"], want["decode_steps"], want["accept_lengths"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_generate_s_random_cases_vs_oracle(seed, golden):
+    """full variant (SAM sequences + Token Recycle trees) on seeded random inputs: samd.SamdModel.generate() (Token-Recycle
+    update/fill inside the step's hipGraph) against the oracle loop that is itself pinned by the reference's traces."""
+    from test_oracle_golden import oracle_generate_s
+    from util import markov_stream
+    rng = np.random.default_rng(2000 + seed)
+    V = 97 if seed % 2 else 150
+    while np.gcd(37, V) != 1:
+        V += 1
+    docs = [markov_stream(rng, int(rng.integers(40, 100)), vocab=V, succ=2, noise=0.03) for _ in range(int(rng.integers(4, 14)))] + [[i] for i in range(V)]
+    flat = [t for d in docs[:-V] for t in d]
+    p = int(rng.integers(0, max(1, len(flat) - 50)))
+    prompt = flat[p:p + int(rng.integers(10, 36))] + rng.integers(3, V, int(rng.integers(0, 4))).tolist()
+    prompt += prompt[3:3 + int(rng.integers(0, 9))]
+    max_new = int(rng.integers(24, 70))
+    cont = []
+    while len(cont) < max_new + 70:
+        r = rng.random()
+        if r < 0.5:
+            q = int(rng.integers(0, max(1, len(flat) - 30))); cont += flat[q:q + int(rng.integers(3, 22))]
+        elif r < 0.75 and len(prompt) > 8:
+            q = int(rng.integers(0, len(prompt) - 4)); cont += prompt[q:q + int(rng.integers(2, 9))]
+        else:
+            cont += rng.integers(3, V, int(rng.integers(1, 4))).tolist()
+    cont = [t if t != 2 else 3 for t in cont]
+    if seed % 4 == 1:
+        cont[int(rng.integers(5, max_new))] = 2
+    tree = golden("buffers.json.gz")["token_recycle"][0]["tree"]
+    case = {"docs": docs, "eos": 2, "vocab": V, "n_predicts": int(rng.choice([6, 12, 40])), "len_threshold": int(rng.choice([2, 3, 5])),
+            "len_bias": int(rng.choice([0, 1, 5])), "max_predicts": 70, "use_static": bool(seed % 3), "tree": tree,
+            "max_new_tokens": max_new, "max_cache_len": 512, "prompt": prompt, "target": prompt + cont}
+    want = oracle_generate_s(case)
+    S, model = s_model(case)
+    gcfg = S.SamdGenerationConfig(max_new_tokens=max_new, max_cache_len=512)
+    out = model.generate(torch.tensor([prompt], dtype=torch.long, device="cuda"), generation_config=gcfg)
+    assert out.output_ids == [want["output_ids"]]
+    assert (out.decode_steps, out.accepet_length_per_step) == (want["decode_steps"], want["accept_lengths"])
+    assert model.lookup_stats["tree"][0] == want["types"].count("tree")
+
+
+def test_sampling_generate_runs_and_is_seeded():
+    """non-greedy generation goes through the granular prefill/decode path with HF's logits warpers and the host RNG
+    (samd_sam_only/utils.py:142-184); with the same seeds it is reproducible, and every token is a valid id."""
+    import random
+    import samd_sam_only as SO
+    from samd_hip.llama import LlamaRunner
+    mcfg = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                vocab_size=512, max_position_embeddings=256, rms_norm_eps=1e-5)
+    prompt = np.random.default_rng(0).integers(3, 512, 20).tolist()
+    ids = torch.tensor([prompt], device="cuda")
+    g = SO.SamdGenerationConfig(max_new_tokens=24, max_cache_len=256, greedy=False, temperature=0.8, top_p=0.9)
+    outs = []
+    for rep in range(2):
+        runner = LlamaRunner.random_init(mcfg, 256, torch.float16, seed=4, std=0.05)
+        cfg = SO.SamdConfig(max_predicts=8, len_bias=0)
+        model = SO.SamdModel(cfg, runner, SO.DraftModel(cfg, device="cuda"), 2, torch.float16, "cuda")
+        random.seed(7); torch.manual_seed(7)
+        outs.append(model.generate(ids, generation_config=g))
+    assert outs[0].output_ids == outs[1].output_ids
+    seq = outs[0].output_ids[0]
+    assert seq[:len(prompt)] == prompt and len(seq) > len(prompt) and all(0 <= t < 512 for t in seq)

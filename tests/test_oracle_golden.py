@@ -259,3 +259,64 @@ def test_loop_so(golden):
         # losslessness: the speculative output equals the scripted greedy continuation
         n = len(got["output_ids"])
         assert got["output_ids"] == case["target"][:n]
+
+
+def oracle_generate_s(case):
+    """samd/samd_model.py prefill (:101-128) / decode (:131-182) / update_state (:185-211) / generate (:230-274) for
+    tree_method=token_recycle, on the oracle pieces and the scripted LM."""
+    lm = ScriptedLM(case["target"], case["vocab"])
+    tree = case["tree"]
+    dyn = O.DynSAM(n_predicts=case["n_predicts"])
+    st = O.StaticSAMFull.build(case["docs"], case["eos"]) if case["use_static"] else None
+    if st is not None:
+        st.n_predicts = case["n_predicts"]
+        st.reset()
+    tr = O.TokenRecycle(tree, case["vocab"])
+    base = O.tr_gen_buffers(tree)
+    base_anc, base_ret = base["anc_tree"].tolist(), base["tree_retrieve_indices"]
+    prompt = case["prompt"]
+    ids = list(prompt)
+    plog = lm.logits([], prompt, [i - 1 for i in range(len(prompt))])
+    dyn.add_tokens(prompt)
+    if st is not None:
+        st.transfer_tokens(prompt)
+    tr.update(prompt, O.topk8_rows(plog))
+    start = int(O.argmax_rows(plog[-1:])[0])
+    dt, ds, acc_list, kinds = 0, 0, [], []
+    for _ in range(case["max_new_tokens"]):
+        if len(prompt) + dt + case["max_predicts"] >= case["max_cache_len"]:
+            break
+        ty, toks = s_lookup(dyn, st, tr, start, case["n_predicts"], case["len_threshold"], case["len_bias"])
+        if ty == "sequence":
+            anc, ret = [i - 1 for i in range(len(toks))], None
+        else:
+            anc, ret = base_anc, base_ret
+        logits = lm.logits(ids, toks, anc)
+        am = O.argmax_rows(logits)
+        best, a, nn = O.eval_posterior(am, toks, ret)
+        cand = np.asarray([toks]) if ret is None else O.candidates(toks, ret)
+        new = cand[best][:a].tolist()
+        dyn.add_tokens(new)
+        if st is not None:
+            st.transfer_tokens(new)
+        tr.update(toks, O.topk8_rows(logits))
+        start = int(am[nn])
+        stop = False
+        if case["eos"] in new:
+            new = new[:new.index(case["eos"]) + 1]
+            stop = True
+        ids.extend(new)
+        ds += 1; dt += len(new); acc_list.append(len(new)); kinds.append(ty)
+        if stop or dt >= case["max_new_tokens"]:
+            break
+    return {"output_ids": ids[:len(prompt) + case["max_new_tokens"]], "decode_tokens": dt, "decode_steps": ds,
+            "accept_lengths": acc_list, "types": kinds}
+
+
+def test_loop_s(golden):
+    """the oracle's full-variant loop reproduces the traces recorded from the imported reference."""
+    for case in golden("loop_s.json.gz"):
+        got = oracle_generate_s(case)
+        for k in ("output_ids", "decode_tokens", "decode_steps", "accept_lengths"):
+            assert got[k] == case[k], k
+        assert got["types"] == [t["type"] for t in case["trace"]]
