@@ -27,10 +27,22 @@ template <typename T> __device__ __forceinline__ Vec8<T> ld8_or_partials(const T
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
-    for (int s = 0; s < n_part; s++) {
-        const float4 a = *reinterpret_cast<const float4 *>(part + (size_t)s * part_stride + off);
-        const float4 b = *reinterpret_cast<const float4 *>(part + (size_t)s * part_stride + off + 4);
-        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    // groups of 8 splits with every load issued before any add (index clamped so the loads are unconditional): one memory
+    // round trip per group instead of one per split
+    for (int s0 = 0; s0 < n_part; s0 += 8) {
+        float4 a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int ss = s0 + k < n_part ? s0 + k : s0;
+            a[k] = *reinterpret_cast<const float4 *>(part + (size_t)ss * part_stride + off);
+            b[k] = *reinterpret_cast<const float4 *>(part + (size_t)ss * part_stride + off + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (s0 + k >= n_part) continue;
+            acc[0] += a[k].x; acc[1] += a[k].y; acc[2] += a[k].z; acc[3] += a[k].w;
+            acc[4] += b[k].x; acc[5] += b[k].y; acc[6] += b[k].z; acc[7] += b[k].w;
+        }
     }
     Vec8<T> o;
 #pragma unroll
@@ -66,10 +78,19 @@ template <typename T, bool ADD>
 __global__ __launch_bounds__(256) void k_rmsnorm(T *__restrict__ x, const T *__restrict__ delta, const T *__restrict__ w,
                                                  T *__restrict__ out, int hidden, float eps, int n_part, long long part_stride) {
     __shared__ float red[4];
+    constexpr int MAXV = 4;                                  // 8-element vectors kept in registers per thread: hidden <= 8192
     const size_t base = (size_t)blockIdx.x * hidden;
+    const int stride = blockDim.x * 8;
+    Vec8<T> xv[MAXV], wv[MAXV];
     float ss = 0.f;
-    for (int c = threadIdx.x * 8; c < hidden; c += blockDim.x * 8) {
+    // one pass: the row stays in registers between the sum of squares and the scaling, and the weight loads are issued
+    // before the block reduction so that their latency hides behind it
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        const int c = threadIdx.x * 8 + i * stride;
+        if (c >= hidden) break;
         Vec8<T> a = ld8(x + base + c);
+        wv[i] = ld8(w + c);
         if (ADD) {
             const Vec8<T> d = ld8_or_partials<T>(delta, reinterpret_cast<const float *>(delta), n_part, (size_t)part_stride, base + c);
 #pragma unroll
@@ -78,14 +99,17 @@ __global__ __launch_bounds__(256) void k_rmsnorm(T *__restrict__ x, const T *__r
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) { const float f = (float)a.v[j]; ss += f * f; }
+        xv[i] = a;
     }
     const float tot = block_sum(ss, red);
     const float rs = rsqrtf(tot / (float)hidden + eps);
-    for (int c = threadIdx.x * 8; c < hidden; c += blockDim.x * 8) {
-        const Vec8<T> a = ld8(x + base + c), ww = ld8(w + c);
+#pragma unroll
+    for (int i = 0; i < MAXV; i++) {
+        const int c = threadIdx.x * 8 + i * stride;
+        if (c >= hidden) break;
         Vec8<T> o;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const T h = (T)((float)a.v[j] * rs); o.v[j] = (T)((float)ww.v[j] * (float)h); }
+        for (int j = 0; j < 8; j++) { const T h = (T)((float)xv[i].v[j] * rs); o.v[j] = (T)((float)wv[i].v[j] * (float)h); }
         st8(out + base + c, o);
     }
 }
@@ -111,7 +135,16 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
     else {
         const float *part = reinterpret_cast<const float *>(qkv);
         float a = 0.f, b = 0.f;
-        for (int s = 0; s < n_part; s++) { a += part[(size_t)s * part_stride + soff + j]; b += part[(size_t)s * part_stride + soff + j + half]; }
+        for (int s0 = 0; s0 < n_part; s0 += 8) {                  // 16 loads in flight per group (see ld8_or_partials)
+            float pa[8], pb[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int ss = s0 + k < n_part ? s0 + k : s0;
+                pa[k] = part[(size_t)ss * part_stride + soff + j]; pb[k] = part[(size_t)ss * part_stride + soff + j + half];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (s0 + k < n_part) { a += pa[k]; b += pb[k]; }
+        }
         x1 = (float)(T)a; x2 = (float)(T)b;                    // rounded like the GEMM's own output
     }
     if (hh >= H + Hkv) {                                       // V: plain copy
@@ -162,7 +195,7 @@ int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_o
                  int32_t dtype, int32_t n_partials, int64_t partial_stride, void *stream) {
     const int n_part = n_partials; const long long pst = partial_stride;
     if (n_partials < 0 || (n_partials > 0 && !d_delta)) { samd_set_error("samd_rmsnorm: partials without a source"); return SAMD_E_INVALID; }
-    if (!d_x || !d_weight || !d_out || rows < 1 || hidden % 8 != 0) { samd_set_error("samd_rmsnorm: invalid argument"); return SAMD_E_INVALID; }
+    if (!d_x || !d_weight || !d_out || rows < 1 || hidden % 8 != 0 || hidden > 8192) { samd_set_error("samd_rmsnorm: invalid argument (hidden must be a multiple of 8, <= 8192)"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SAMD_F16) {
         if (d_delta) hipLaunchKernelGGL((k_rmsnorm<_Float16, true>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)d_delta, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps, n_part, pst);

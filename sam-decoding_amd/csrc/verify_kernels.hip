@@ -125,20 +125,8 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 
     const int h = blockIdx.x, split = blockIdx.y;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lg = l >> 4;
-    const int L = d_L[0];
-    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
-    const int total = L + n;
-    const int ntiles = (total + ATT_TILE - 1) / ATT_TILE;
-    const int tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
-    const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
-    if (t0 >= t1) return;                              // no keys for this split: k_attn_combine only reads the splits in use
-    const int kvh = h / (n_heads / n_kv_heads);
-    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
-    const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
     const int row_base = 16 * w;
-    const bool active = row_base < n;
-
-    // Q fragments (A operand): row = row_base + lr, d = 32*kk + 8*lg .. +8
+    // loads that do not depend on L / n go out first (Q fragments, mask rows), together with the two scalars
     V8 qa[4];
     {
         const int qrow = row_base + lr;
@@ -152,7 +140,20 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     }
     unsigned long long mrow[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) { const int row = row_base + 4 * lg + r; mrow[r] = row < n ? mask[row] : 0ull; }
+    for (int r = 0; r < 4; r++) mrow[r] = mask[row_base + 4 * lg + r];       // mask holds 64 rows; rows >= n are zeroed below
+    const int L = d_L[0];
+    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
+    const int total = L + n;
+    const int ntiles = (total + ATT_TILE - 1) / ATT_TILE;
+    const int tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
+    const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
+    if (t0 >= t1) return;                              // no keys for this split: k_attn_combine only reads the splits in use
+    const int kvh = h / (n_heads / n_kv_heads);
+    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
+    const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
+    const bool active = row_base < n;
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) mrow[r] = 0ull;
 
     float m_run[4], l_run[4];
     floatx4 o[8];
@@ -282,15 +283,23 @@ __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ 
     // the splits k_tree_attention actually ran (same arithmetic as there): the others left their partials untouched
     const int ntiles = (d_L[0] + n + ATT_TILE - 1) / ATT_TILE, tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
     const int used = (ntiles + tps - 1) / tps;
+    // issue every split's (m, l, O[d]) load before consuming any: one memory round trip instead of one per split
+    float mv[ATT_SPLITS], lv[ATT_SPLITS], pv[ATT_SPLITS];
+#pragma unroll
+    for (int s = 0; s < ATT_SPLITS; s++) {
+        const int ss = s < used ? s : 0;                                   // clamp: unconditional loads keep them all in flight
+        const float *p = ws + (((size_t)ss * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
+        mv[s] = p[ATT_D]; lv[s] = p[ATT_D + 1]; pv[s] = p[d];
+    }
     float M = -INFINITY;
-    for (int s = 0; s < used; s++) M = fmaxf(M, ws[(((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2) + ATT_D]);
+#pragma unroll
+    for (int s = 0; s < ATT_SPLITS; s++) if (s < used) M = fmaxf(M, mv[s]);
     float num = 0.f, den = 0.f;
-    for (int s = 0; s < used; s++) {
-        const float *p = ws + (((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
-        const float m = p[ATT_D];
-        if (m == -INFINITY) continue;
-        const float wgt = exp2f(m - M);
-        num += wgt * p[d]; den += wgt * p[ATT_D + 1];
+#pragma unroll
+    for (int s = 0; s < ATT_SPLITS; s++) {
+        if (s >= used || mv[s] == -INFINITY) continue;
+        const float wgt = exp2f(mv[s] - M);
+        num += wgt * pv[s]; den += wgt * lv[s];
     }
     *dst = (E)(den > 0.f ? num / den : 0.f);
 }
