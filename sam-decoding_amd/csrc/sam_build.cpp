@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <vector>
 #include "samd_common.h"
 
@@ -131,6 +132,7 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
            samd_static_t **out) {
     if (n_states < 1 || n_states >= (1ll << 31)) { samd_set_error("bad state count"); return SAMD_E_INVALID; }
     samd_static_t *s = (samd_static_t *)calloc(1, sizeof(samd_static_t));
+    if (!s) { samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     s->kind = kind; s->n_states = n_states; s->n_text = text ? n_text : 0;
     int64_t n_edges = 0, n_spill = 0;
     int32_t max_root_tok = -1;
@@ -145,6 +147,7 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
     s->h_root = (int32_t *)malloc(std::max<int64_t>(1, s->vocab) * sizeof(int32_t));
     s->h_spill = (SamEdge *)malloc(std::max<int64_t>(1, n_spill) * sizeof(SamEdge));
     s->h_text = (int32_t *)malloc(std::max<int64_t>(1, s->n_text) * sizeof(int32_t));
+    if (!s->h_root || !s->h_spill || !s->h_text) { samd_static_free(s); samd_set_error("out of host memory for the automaton image"); return SAMD_E_CAPACITY; }
     if (text) memcpy(s->h_text, text, (size_t)n_text * sizeof(int32_t));
     for (int64_t t = 0; t < s->vocab; t++) s->h_root[t] = -1;
 
@@ -204,6 +207,7 @@ int samd_static_build(const int32_t *h_tokens, const int64_t *h_doc_offsets, int
     if (!out || (kind != SAMD_KIND_COUNT && kind != SAMD_KIND_ENDPOS) || n_docs < 0 || (n_docs > 0 && (!h_tokens || !h_doc_offsets))) {
         samd_set_error("samd_static_build: invalid argument"); return SAMD_E_INVALID;
     }
+    try {
     Builder b(kind);
     for (int64_t d = 0; d < n_docs; d++) {
         int64_t lo = h_doc_offsets[d], hi = h_doc_offsets[d + 1];
@@ -217,6 +221,10 @@ int samd_static_build(const int32_t *h_tokens, const int64_t *h_doc_offsets, int
         for (int32_t e = b.first_[s]; e >= 0; e = b.edge_sibling_[e]) { etok[k] = b.edge_tok_[e]; edst[k] = b.edge_dst_[e]; k++; }
     return layout(kind, (int64_t)b.link_.size(), b.link_.data(), b.length_.data(), b.aux_.data(), b.deg_.data(),
                   etok.data(), edst.data(), kind == SAMD_KIND_ENDPOS ? b.text_.data() : nullptr, (int64_t)b.text_.size(), out);
+    } catch (const std::exception &e) {                     // std::bad_alloc / length_error: never across the C ABI
+        samd_set_error("samd_static_build: %s", e.what());
+        return SAMD_E_CAPACITY;
+    }
 }
 
 int samd_static_from_tables(int32_t kind, int64_t n_states, const int32_t *h_link, const int32_t *h_length,
@@ -225,7 +233,12 @@ int samd_static_from_tables(int32_t kind, int64_t n_states, const int32_t *h_lin
     if (!out || !h_link || !h_length || !h_aux || !h_deg || (kind != SAMD_KIND_COUNT && kind != SAMD_KIND_ENDPOS)) {
         samd_set_error("samd_static_from_tables: invalid argument"); return SAMD_E_INVALID;
     }
-    return layout(kind, n_states, h_link, h_length, h_aux, h_deg, h_edge_tok, h_edge_dst, h_text, n_text, out);
+    try {
+        return layout(kind, n_states, h_link, h_length, h_aux, h_deg, h_edge_tok, h_edge_dst, h_text, n_text, out);
+    } catch (const std::exception &e) {
+        samd_set_error("samd_static_from_tables: %s", e.what());
+        return SAMD_E_CAPACITY;
+    }
 }
 
 void samd_static_free(samd_static_t *s) {
@@ -316,6 +329,7 @@ int samd_static_load(const char *path, samd_static_t **out) {
     s->h_root = (int32_t *)malloc(std::max<int64_t>(1, h.vocab) * 4);
     s->h_spill = (SamEdge *)malloc(std::max<int64_t>(1, h.n_spill) * 8);
     s->h_text = (int32_t *)malloc(std::max<int64_t>(1, h.n_text) * 4);
+    ok = ok && s->h_root && s->h_spill && s->h_text;
     ok = ok && fread(s->h_nodes, sizeof(SamNode), (size_t)h.n_states, f) == (size_t)h.n_states;
     ok = ok && fread(s->h_root, 4, (size_t)h.vocab, f) == (size_t)h.vocab;
     ok = ok && fread(s->h_spill, 8, (size_t)h.n_spill, f) == (size_t)h.n_spill;
@@ -382,6 +396,7 @@ int samd_static_from_host_image(const int64_t info[8], const void *const h_ptrs[
     s->h_root = (int32_t *)malloc(std::max<int64_t>(1, s->vocab) * 4);
     s->h_spill = (SamEdge *)malloc(std::max<int64_t>(1, s->n_spill) * 8);
     s->h_text = (int32_t *)malloc(std::max<int64_t>(1, s->n_text) * 4);
+    if (!s->h_root || !s->h_spill || !s->h_text) { samd_static_free(s); samd_set_error("out of host memory for the automaton image"); return SAMD_E_CAPACITY; }
     memcpy(s->h_nodes, h_ptrs[0], (size_t)s->n_states * sizeof(SamNode));
     if (s->vocab && h_ptrs[1]) memcpy(s->h_root, h_ptrs[1], (size_t)s->vocab * 4);
     if (s->n_spill && h_ptrs[2]) memcpy(s->h_spill, h_ptrs[2], (size_t)s->n_spill * 8);

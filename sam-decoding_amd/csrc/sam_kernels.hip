@@ -290,6 +290,7 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
     if (!out || max_tokens < 1 || max_tokens > (1 << 24)) { samd_set_error("samd_session_create: invalid max_tokens"); return SAMD_E_INVALID; }
     if (samd_device_count() < 1) { samd_set_error("no HIP device"); return SAMD_E_NODEVICE; }
     samd_session_t *s = (samd_session_t *)calloc(1, sizeof(samd_session_t));
+    if (!s) { samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     s->max_tokens = max_tokens;
     SessionDev &D = s->dev;
     D.max_tokens = max_tokens;

@@ -506,6 +506,7 @@ int samd_recycle_create(int32_t vocab, const int32_t *h_child_offsets, const int
     { std::vector<int> fill(level_off.begin(), level_off.end() - 1); for (int i = 0; i < n_nodes; i++) level_nodes[fill[depth[i]]++] = i; }
 
     samd_recycle_t *t = (samd_recycle_t *)calloc(1, sizeof(samd_recycle_t));
+    if (!t) { samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     t->vocab = vocab; t->n_nodes = n_nodes; t->n_levels = n_levels; t->tmp_rows = 16384;
     bool ok = hipMalloc((void **)&t->d_table, (size_t)vocab * 8 * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&t->d_present, (size_t)vocab) == hipSuccess;
