@@ -313,6 +313,35 @@ int samd_static_save(const samd_static_t *s, const char *path) {
     return SAMD_OK;
 }
 
+
+// Structural check of a host image that came from outside the builder (a file, another rank): every index a kernel
+// will follow must stay inside the image, otherwise a damaged file turns into a wild device read.
+static bool image_is_sane(const samd_static_t *s, const char **why) {
+    const int64_t n = s->n_states;
+    auto dst_ok = [&](int32_t tok, int32_t dst) { return tok < 0 ? true : (dst >= 0 && dst < n); };
+    for (int64_t i = 0; i < n; i++) {
+        const SamNode &nd = s->h_nodes[i];
+        if (nd.link < -1 || nd.link >= n) { *why = "suffix link out of range"; return false; }
+        if (nd.deg < 0) { *why = "negative degree"; return false; }
+        if (!dst_ok(nd.e0_tok, nd.e0_dst) || !dst_ok(nd.e1_tok, nd.e1_dst) || !dst_ok(nd.e2_tok, nd.e2_dst) ||
+            !dst_ok(nd.e3_tok, nd.e3_dst) || !dst_ok(nd.e4_tok, nd.e4_dst)) { *why = "edge target out of range"; return false; }
+        if (nd.deg > SAMD_INLINE_EDGES) {
+            int64_t slots = (int64_t)SAMD_SPILL_HEAD + samd_spill_slots(nd.deg);
+            if (nd.spill < 0 || (int64_t)nd.spill + slots > s->n_spill) { *why = "spill block out of range"; return false; }
+            for (int64_t k = 0; k < slots; k++) {
+                const SamEdge &e = s->h_spill[nd.spill + k];
+                if (!dst_ok(e.tok, e.dst)) { *why = "spill edge target out of range"; return false; }
+            }
+        }
+        if (s->kind == SAMD_KIND_ENDPOS && (nd.aux < 0 || nd.aux >= std::max<int64_t>(1, s->n_text))) {
+            *why = "end position outside the text"; return false;
+        }
+    }
+    for (int64_t t = 0; t < s->vocab; t++)
+        if (s->h_root[t] < -1 || s->h_root[t] >= n) { *why = "root table entry out of range"; return false; }
+    return true;
+}
+
 int samd_static_load(const char *path, samd_static_t **out) {
     if (!path || !out) return SAMD_E_INVALID;
     FILE *f = fopen(path, "rb");
@@ -323,6 +352,7 @@ int samd_static_load(const char *path, samd_static_t **out) {
         fclose(f); samd_set_error("%s: not a SAMDHIP1 image", path); return SAMD_E_IO;
     }
     samd_static_t *s = (samd_static_t *)calloc(1, sizeof(samd_static_t));
+    if (!s) { fclose(f); samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     s->kind = (int32_t)h.kind; s->n_states = h.n_states; s->n_edges = h.n_edges; s->n_spill = h.n_spill;
     s->vocab = h.vocab; s->n_text = h.n_text;
     bool ok = posix_memalign((void **)&s->h_nodes, 64, (size_t)h.n_states * sizeof(SamNode)) == 0;
@@ -336,6 +366,8 @@ int samd_static_load(const char *path, samd_static_t **out) {
     ok = ok && fread(s->h_text, 4, (size_t)h.n_text, f) == (size_t)h.n_text;
     fclose(f);
     if (!ok) { samd_static_free(s); samd_set_error("%s: truncated image", path); return SAMD_E_IO; }
+    const char *why = "";
+    if (!image_is_sane(s, &why)) { samd_static_free(s); samd_set_error("%s: damaged image (%s)", path, why); return SAMD_E_IO; }
     *out = s;
     return SAMD_OK;
 }
@@ -384,6 +416,7 @@ int samd_static_host_image(const samd_static_t *s, void *out_ptrs[4], int64_t ou
 
 static samd_static_t *shell_from_info(const int64_t info[8]) {
     samd_static_t *s = (samd_static_t *)calloc(1, sizeof(samd_static_t));
+    if (!s) return nullptr;
     s->n_states = info[0]; s->n_edges = info[1]; s->n_spill = info[2]; s->vocab = info[3];
     s->kind = (int32_t)info[5]; s->n_text = info[6];
     return s;
@@ -392,6 +425,7 @@ static samd_static_t *shell_from_info(const int64_t info[8]) {
 int samd_static_from_host_image(const int64_t info[8], const void *const h_ptrs[4], samd_static_t **out) {
     if (!info || !h_ptrs || !out || info[0] < 1 || !h_ptrs[0]) { samd_set_error("samd_static_from_host_image: invalid argument"); return SAMD_E_INVALID; }
     samd_static_t *s = shell_from_info(info);
+    if (!s) { samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     if (posix_memalign((void **)&s->h_nodes, 64, (size_t)s->n_states * sizeof(SamNode))) { free(s); return SAMD_E_CAPACITY; }
     s->h_root = (int32_t *)malloc(std::max<int64_t>(1, s->vocab) * 4);
     s->h_spill = (SamEdge *)malloc(std::max<int64_t>(1, s->n_spill) * 8);
@@ -401,6 +435,8 @@ int samd_static_from_host_image(const int64_t info[8], const void *const h_ptrs[
     if (s->vocab && h_ptrs[1]) memcpy(s->h_root, h_ptrs[1], (size_t)s->vocab * 4);
     if (s->n_spill && h_ptrs[2]) memcpy(s->h_spill, h_ptrs[2], (size_t)s->n_spill * 8);
     if (s->n_text && h_ptrs[3]) memcpy(s->h_text, h_ptrs[3], (size_t)s->n_text * 4);
+    const char *why = "";
+    if (!image_is_sane(s, &why)) { samd_static_free(s); samd_set_error("samd_static_from_host_image: damaged image (%s)", why); return SAMD_E_INVALID; }
     *out = s;
     return SAMD_OK;
 }
@@ -408,6 +444,7 @@ int samd_static_from_host_image(const int64_t info[8], const void *const h_ptrs[
 int samd_static_adopt_device(const int64_t info[8], void *const d_ptrs[4], samd_static_t **out) {
     if (!info || !d_ptrs || !out || info[0] < 1 || !d_ptrs[0]) { samd_set_error("samd_static_adopt_device: invalid argument"); return SAMD_E_INVALID; }
     samd_static_t *s = shell_from_info(info);
+    if (!s) { samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     s->d_nodes = (SamNode *)d_ptrs[0]; s->d_root = (int32_t *)d_ptrs[1]; s->d_spill = (SamEdge *)d_ptrs[2]; s->d_text = (int32_t *)d_ptrs[3];
     s->uploaded = 1; s->borrowed = 1;
     *out = s;
@@ -417,6 +454,7 @@ int samd_static_adopt_device(const int64_t info[8], void *const d_ptrs[4], samd_
 int samd_static_alloc_like(const int64_t info[8], samd_static_t **out) {
     if (!info || !out || info[0] < 1) return SAMD_E_INVALID;
     samd_static_t *s = (samd_static_t *)calloc(1, sizeof(samd_static_t));
+    if (!s) { samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     s->n_states = info[0]; s->n_edges = info[1]; s->n_spill = info[2]; s->vocab = info[3];
     s->kind = (int32_t)info[5]; s->n_text = info[6];
     int rc = alloc_device_image(s);

@@ -105,3 +105,33 @@ def test_no_gpu_means_loud_failure():
     a = samd_hip.StaticAutomaton.build([[3, 4, 5]], 2, 0)
     with pytest.raises(samd_hip.SamdError):
         a.upload()
+
+
+def test_load_rejects_damaged_image(tmp_path):
+    """A SAMDHIP1 file whose indices point outside the image must be refused at load time (samd_static_load), not
+    discovered by a kernel."""
+    import struct
+    rng = np.random.default_rng(5)
+    docs = [rng.integers(0, 40, 60).tolist() for _ in range(3)]
+    sam = samd_hip.StaticAutomaton.build(docs, 39, 0)
+    good = tmp_path / "good.samd"
+    sam.save(str(good))
+    raw = bytearray(good.read_bytes())
+    inf = sam.info()
+    assert samd_hip.StaticAutomaton.load(str(good)).info()["n_states"] == inf["n_states"]
+    # header = magic[8] + 6 x int64 ... find the first node by searching for state 0's link (-1) after the header
+    hdr = len(raw) - (inf["n_states"] * 64 + inf["vocab"] * 4 + inf["n_spill"] * 8 + inf["n_text"] * 4)
+    assert hdr > 0
+    bad = bytearray(raw)
+    struct.pack_into("<i", bad, hdr + 64 * 1 + 12, inf["n_states"] + 7)          # state 1: e0.dst past the end
+    p = tmp_path / "bad_edge.samd"; p.write_bytes(bytes(bad))
+    with pytest.raises(samd_hip.SamdError, match="damaged"):
+        samd_hip.StaticAutomaton.load(str(p))
+    bad = bytearray(raw)
+    struct.pack_into("<i", bad, hdr + 64 * 2 + 0, -5)                          # state 2: suffix link < -1
+    p = tmp_path / "bad_link.samd"; p.write_bytes(bytes(bad))
+    with pytest.raises(samd_hip.SamdError, match="damaged"):
+        samd_hip.StaticAutomaton.load(str(p))
+    p = tmp_path / "short.samd"; p.write_bytes(bytes(raw[:-16]))
+    with pytest.raises(samd_hip.SamdError, match="truncated"):
+        samd_hip.StaticAutomaton.load(str(p))
