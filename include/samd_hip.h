@@ -304,9 +304,12 @@ int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inte
 
 /* weight-streaming skinny GEMM of the verify forward: out[m][n] = sum_k A[m][k] * W[n][k], m < rows_pad in {16,32,64},
  * W = an nn.Linear weight [N][K] (what the reference runs through HF's q/k/v/o/gate/up/down/lm_head projections,
- * call sites SO/samd_model.py:102-106, :134-138).  N % 128 == 0, K % 256 == 0.  splits == 1: writes d_out (dtype,
- * [rows_pad][N]); splits > 1: writes fp32 partial sums d_partial [splits][rows_pad][N] that the consuming kernel adds up
- * (samd_rmsnorm / samd_rope_kv_write / samd_silu_mul with n_partials > 0). */
+ * call sites SO/samd_model.py:102-106, :134-138).  N % 128 == 0, K % 256 == 0.  The kernel reads W in the PACKED layout
+ * that samd_gemm_pack_weights writes once at load time (64 KiB blocks of 128 columns x 256 k in lane order, so that every
+ * workgroup reads one linear stream).  splits == 1: writes d_out (dtype, [rows_pad][N]); splits > 1: writes fp32
+ * partial sums d_partial [splits][rows_pad][N] that the consuming kernel adds up (samd_rmsnorm / samd_rope_kv_write /
+ * samd_silu_mul with n_partials > 0). */
+int samd_gemm_pack_weights(const void *d_W, void *d_packed, int32_t N, int32_t K, void *stream);
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad);
 int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits);
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,

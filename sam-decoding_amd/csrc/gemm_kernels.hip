@@ -1,12 +1,17 @@
 // gemm_kernels.hip -- weight-streaming skinny GEMM of the verify forward for gfx950:  out[m][n] = sum_k A[m][k] * W[n][k]
-// with m <= 64 draft rows, W = an HF nn.Linear weight [N, K] (row-major, K contiguous).
+// with m <= 64 draft rows, W = an HF nn.Linear weight [N, K], re-tiled once at load time (samd_gemm_pack_weights) so that
+// every workgroup reads its share as one linear stream of 64 KiB blocks.
 //
 // At n <= 64 rows the verify forward is bound by reading the weights once (13.5 GB for Vicuna-7B): the kernel is a
 // weight STREAM with a little MFMA attached.  What shapes it (scripts/hbm_probe.hip, profiles/r01_hbm_probe.md): the
 // memory system retires ~48 G requests/s whatever their size, so every request must carry a full 128-byte line --
 // each lane therefore owns 32 contiguous bytes of a weight row per 64-wide k block (4 lanes = 128 B of one row), and
 // the MFMA k index is permuted accordingly (the A operand is read from LDS with the same permutation, so the product
-// is unchanged).  A (the activations, <= 512 KB, L2 resident) is staged per workgroup through LDS in 256-wide k chunks,
+// is unchanged).  PACKED LAYOUT (scripts/stream_probe.hip, profiles/r01_stream_sweep.log: reading the same bytes with this
+// kernel's grid but the row-major matrix is 8-9 % slower, 79.6 vs 72.8 us for the four projections of a layer): block
+// (tile t = 128 output columns, chunk c = 256 k) is 64 KiB contiguous at ((t * K/256 + c) * 4096) uint4 units; inside it
+// unit (2b + j) * 512 + tid holds W[128 t + 16 w + n][256 c + 64 b + 16 g + 8 j .. +7] for tid = 64 w + 16 g + n -- exactly
+// the order the lanes consume, so one wave-instruction is 1 KiB contiguous.  A (the activations, <= 512 KB, L2 resident) is staged per workgroup through LDS in 256-wide k chunks,
 // double buffered; the weights go HBM -> VGPR -> MFMA one chunk ahead.  (Measured and dropped: a 16-row variant that stages the
 // whole A slice once and streams without per-chunk barriers -- 159 vs 141 us per layer-set, the serial staging costs more.
 // Ablation at 16 rows: with the MFMAs and the LDS traffic compiled out (weight stream only) the five projections of a layer
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny
     const int n0 = blockIdx.x * GEMM_COLS + 16 * w;
     const int split = blockIdx.y;
     const int c0 = (int)((long long)split * n_chunks / n_splits), c1 = (int)((long long)(split + 1) * n_chunks / n_splits);
-    const E *wrow = W + (size_t)(n0 + n) * K + 16 * g;            // this lane's 32 bytes of each 64-wide block of row n0+n
+    const uint4 *wtile = reinterpret_cast<const uint4 *>(W) + (size_t)blockIdx.x * n_chunks * 4096 + tid;   // packed: see header
 
     floatx4 acc[RT];
 #pragma unroll
@@ -62,11 +67,11 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny
 
     uint4 wa[4][2], wb[4][2];
     auto load_w = [&](uint4 (&dst)[4][2], int c) {
-        const E *p = wrow + (size_t)c * GEMM_KC;
+        const uint4 *p = wtile + (size_t)c * 4096;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            dst[b][0] = *reinterpret_cast<const uint4 *>(p + 64 * b);
-            dst[b][1] = *reinterpret_cast<const uint4 *>(p + 64 * b + 8);
+            dst[b][0] = p[512 * (2 * b)];
+            dst[b][1] = p[512 * (2 * b + 1)];
         }
     };
     auto stage_x = [&](int c, int buf) {          // asynchronous: lands in LDS, counted by vmcnt
@@ -121,6 +126,19 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny
     }
 }
 
+// row-major [N][K] (2-byte elements) -> packed blocks; one thread moves one 16-byte unit
+__global__ __launch_bounds__(256) void k_gemm_pack(const uint4 *__restrict__ W, uint4 *__restrict__ out, int N, int K) {
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;          // destination unit
+    const long long total = (long long)N * K / 8;
+    if (u >= total) return;
+    const int n_chunks = K / GEMM_KC;
+    const long long blk = u >> 12;
+    const int in = (int)(u & 4095), jj = in >> 9, tid = in & 511, w = tid >> 6, g = (tid >> 4) & 3, n = tid & 15;
+    const int t = (int)(blk / n_chunks), c = (int)(blk % n_chunks), b = jj >> 1, j = jj & 1;
+    const long long row = 128LL * t + 16 * w + n, col = 256LL * c + 64 * b + 16 * g + 8 * j;
+    out[u] = W[(row * K + col) / 8];
+}
+
 extern "C" {
 
 // choose the split-K factor: enough workgroups to cover the chip twice, never more splits than chunks, and few enough
@@ -129,6 +147,7 @@ int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad) {
     const int cols = N / GEMM_COLS, chunks = K / GEMM_KC;
     int cap = rows_pad <= 32 ? 8 : 4;
     if (const char *e = getenv("SAMD_GEMM_SPLIT_CAP")) cap = atoi(e);
+    if (const char *e = getenv("SAMD_GEMM_SPLITS")) { int v = atoi(e); return v < 1 ? 1 : (v > chunks ? chunks : v); }
     int s = 1;
     while (cols * s < 512 && s * 2 <= chunks && s * 2 <= cap) s *= 2;
     return s;
@@ -138,6 +157,16 @@ int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits) { retur
 
 // out (dtype, [rows_pad][N]) when splits == 1, else fp32 partials [splits][rows_pad][N] in d_partial.
 // rows_pad in {16, 32, 64}; A must hold rows_pad rows (pad rows are read, their products land in pad rows).
+int samd_gemm_pack_weights(const void *d_W, void *d_packed, int32_t N, int32_t K, void *stream) {
+    if (!d_W || !d_packed || d_W == d_packed || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC || K % GEMM_KC != 0) {
+        samd_set_error("samd_gemm_pack_weights: needs N %% 128 == 0, K %% 256 == 0 and distinct buffers"); return SAMD_E_INVALID;
+    }
+    const long long units = (long long)N * K / 8;
+    hipLaunchKernelGGL(k_gemm_pack, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, N, K);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
                      void *d_out, int32_t dtype, void *stream) {
     if (!d_A || !d_W || (rows_pad != 16 && rows_pad != 32 && rows_pad != 64) || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC ||

@@ -90,6 +90,17 @@ class LlamaRunner:
         shapes = [(qkv_out, s.hidden), (s.hidden, s.heads * s.head_dim), (2 * s.inter, s.hidden), (s.hidden, s.inter), (s.vocab, s.hidden)]
         self.native_gemm = bool(native_gemm) and all(n % 128 == 0 and k % 256 == 0 for n, k in shapes)
         self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 32))     # tuning knob; see forward_rows
+        # second copy of the projection weights in the streaming kernel's packed layout (samd_gemm_pack_weights): the
+        # row-major originals stay for the library GEMM of the 64-row bucket and the wide prefill.  2 x 13.5 GB for a 7B
+        # model -- HBM capacity (288 GB) is not what this path is short of, bandwidth is.
+        self.wp = None
+        if self.native_gemm:
+            def pack(t):
+                out = torch.empty_like(t)
+                check(lib().samd_gemm_pack_weights(_ptr(t), _ptr(out), t.shape[0], t.shape[1], current_stream()))
+                return out
+            self.wp = dict(lm_head=pack(weights["lm_head"]),
+                           layers=[{k: pack(l[k]) for k in ("wqkv", "wo", "wgu", "wdown")} for l in weights["layers"]])
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
         self.bind_cache(kv if kv is not None else
                         torch.zeros((s.layers, 2, s.kv_heads, self.max_len, s.head_dim), dtype=dtype, device=self.device))
@@ -200,8 +211,8 @@ class LlamaRunner:
         L, s, b, dt, st = lib(), self.shape, self._buffers(R), self.dt, current_stream()
         RP, part = b["rows_pad"], b["part"]
 
-        def gemm(a, w, out):
-            """out = a @ w.T; returns (operand pointer for the consumer, n_partials, partial_stride)."""
+        def gemm(a, w, wp, out):
+            """out = a @ w.T (wp = w in the packed layout); returns (operand for the consumer, n_partials, partial_stride)."""
             n, k = w.shape
             # measured on MI355X (scripts/forward_ablation.py, whole forward incl. the consumers' partial-sum reads):
             # the weight-streaming kernel wins at <= 16 rows (4.28 vs 4.75 ms) and at 32 (4.52 vs 4.62 ms), loses at 64 (5.51 vs 5.22 ms)
@@ -209,27 +220,29 @@ class LlamaRunner:
                 torch.mm(a[:R], w.t(), out=out[:R])
                 return out, 0, 0
             sp = L.samd_gemm_splits(n, k, RP) if out is not b["logits"] else 1
-            check(L.samd_gemm_skinny(_ptr(a), _ptr(w), RP, n, k, sp, _ptr(part), _ptr(out), dt, st))
+            check(L.samd_gemm_skinny(_ptr(a), _ptr(wp), RP, n, k, sp, _ptr(part), _ptr(out), dt, st))
             return (out, 0, 0) if sp == 1 else (part, sp, RP * n)
 
         check(L.samd_embed_rows(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(b["x"]), R, s.hidden, s.vocab, dt, st))
         delta, dn, dstride = None, 0, 0
+        packed = self.wp["layers"] if self.wp else [{}] * len(self.w["layers"])
         for li, w in enumerate(self.w["layers"]):
+            wp = packed[li]
             check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
-            src, n_p, stride = gemm(b["h"], w["wqkv"], b["qkv"])
+            src, n_p, stride = gemm(b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
             check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
                                        _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
                                        s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
             check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
                                         s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
                                         _ptr(b["ws"]), b["ws_bytes"], st))
-            src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], b["o"])
+            src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"])
             check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride, st))
-            src, n_p, stride = gemm(b["h"], w["wgu"], b["gu"])
+            src, n_p, stride = gemm(b["h"], w["wgu"], wp.get("wgu"), b["gu"])
             check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
-            delta, dn, dstride = gemm(b["act"], w["wdown"], b["d"])
+            delta, dn, dstride = gemm(b["act"], w["wdown"], wp.get("wdown"), b["d"])
         check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
-        gemm(b["h"], self.w["lm_head"], b["logits"])
+        gemm(b["h"], self.w["lm_head"], self.wp["lm_head"] if self.wp else None, b["logits"])
         check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
         return b
 

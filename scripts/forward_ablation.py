@@ -27,18 +27,18 @@ for R in (1, 8, 16, 32, 64):
     def full():
         runner.forward_rows(R, runner.pf_tokens, runner.pf_relpos, runner.pf_mask, v["cache_length"], runner.pf_n)
 
-    def gemm(a, w, out, final=False):
+    def gemm(a, w, out, final=False, wp=None):
         nn, k = w.shape
         if not runner.native_gemm:
             torch.mm(a[:R], w.t(), out=out[:R]); return
         sp = 1 if final else L.samd_gemm_splits(nn, k, RP)
-        check(L.samd_gemm_skinny(_ptr(a), _ptr(w), RP, nn, k, sp, _ptr(part), _ptr(out), dt, current_stream()))
+        check(L.samd_gemm_skinny(_ptr(a), _ptr(wp if wp is not None else w), RP, nn, k, sp, _ptr(part), _ptr(out), dt, current_stream()))
 
     def gemms_only():
-        for w in runner.w["layers"]:
-            gemm(b["h"], w["wqkv"], b["qkv"]); gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], b["o"])
-            gemm(b["h"], w["wgu"], b["gu"]); gemm(b["act"], w["wdown"], b["d"])
-        gemm(b["h"], runner.w["lm_head"], b["logits"], True)
+        for w, p in zip(runner.w["layers"], runner.wp["layers"] if runner.wp else runner.w["layers"]):
+            gemm(b["h"], w["wqkv"], b["qkv"], wp=p["wqkv"]); gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], b["o"], wp=p["wo"])
+            gemm(b["h"], w["wgu"], b["gu"], wp=p["wgu"]); gemm(b["act"], w["wdown"], b["d"], wp=p["wdown"])
+        gemm(b["h"], runner.w["lm_head"], b["logits"], True, wp=runner.wp["lm_head"] if runner.wp else None)
 
     def attn_only():
         st = current_stream()

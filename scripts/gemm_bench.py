@@ -13,15 +13,18 @@ for R in (16, 32, 64):
     for name, N, K in shapes:
         A = torch.randn((R, K), device="cuda").half()
         Ws = [(torch.randn((N, K), device="cuda") * 0.02).half() for _ in range(6)]      # rotate > L2/MALL
+        Wp = [torch.empty_like(w) for w in Ws]
+        for w, p in zip(Ws, Wp):
+            samd_hip.check(L.samd_gemm_pack_weights(samd_hip._ptr(w), samd_hip._ptr(p), N, K, samd_hip.current_stream()))
         out = torch.zeros((R, N), device="cuda", dtype=torch.float16)
-        for S in sorted({1, L.samd_gemm_splits(N, K, R), 2, 4, 8, 16}):
+        for S in sorted({1, L.samd_gemm_splits(N, K, R), 2, 3, 4, 5, 6, 8, 12, 16}):
             if S > K // 256:
                 continue
             part = torch.zeros((S, R, N), device="cuda", dtype=torch.float32)
             i = [0]
             def mine():
                 i[0] = (i[0] + 1) % len(Ws)
-                samd_hip.check(L.samd_gemm_skinny(samd_hip._ptr(A), samd_hip._ptr(Ws[i[0]]), R, N, K, S, samd_hip._ptr(part),
+                samd_hip.check(L.samd_gemm_skinny(samd_hip._ptr(A), samd_hip._ptr(Wp[i[0]]), R, N, K, S, samd_hip._ptr(part),
                                                   samd_hip._ptr(out), samd_hip.F16, samd_hip.current_stream()))
             ms = hip_time_ms(mine, 30)
             tag = " <- auto" if S == L.samd_gemm_splits(N, K, R) else ""

@@ -14,6 +14,8 @@ import samd_hip
 def run(A, W, rows_pad, splits, dtype):
     N, K = W.shape
     L = samd_hip.lib()
+    Wrow, W = W, torch.empty_like(W)                   # the kernel reads the packed layout
+    samd_hip.check(L.samd_gemm_pack_weights(samd_hip._ptr(Wrow), samd_hip._ptr(W), N, K, samd_hip.current_stream()))
     if splits == 1:
         out = torch.full((rows_pad, N), float("nan"), device="cuda", dtype=dtype)
         samd_hip.check(L.samd_gemm_skinny(samd_hip._ptr(A), samd_hip._ptr(W), rows_pad, N, K, 1, None, samd_hip._ptr(out),
@@ -37,6 +39,18 @@ def test_gemm_matches_fp32_reference(dtype, tol, rows_pad, N, K, splits):
     assert torch.isfinite(got).all()
     err = (got - want).abs().max().item()
     assert err <= tol * max(1.0, want.abs().max().item()), err
+
+
+def test_pack_weights_is_the_documented_permutation():
+    """unit (2b + j) * 512 + tid of block (t, c) holds W[128 t + 16 w + n][256 c + 64 b + 16 g + 8 j ..+7], tid = 64 w + 16 g + n
+    (include/samd_hip.h, gemm_kernels.hip header)."""
+    N, K = 256, 768
+    W = torch.arange(N * K, device="cuda", dtype=torch.int32).to(torch.int16).view(N, K)      # any 2-byte payload
+    out = torch.empty_like(W)
+    samd_hip.check(samd_hip.lib().samd_gemm_pack_weights(samd_hip._ptr(W), samd_hip._ptr(out), N, K, samd_hip.current_stream()))
+    want = W.view(N // 128, 8, 16, K // 256, 4, 4, 2, 8).permute(0, 3, 4, 6, 1, 5, 2, 7).contiguous()     # [t][c][b][j][w][g][n][e]
+    assert torch.equal(out.view(-1), want.view(-1))
+    assert samd_hip.lib().samd_gemm_pack_weights(samd_hip._ptr(W), samd_hip._ptr(W), N, K, None) != 0           # in place: refused
 
 
 def test_gemm_rejects_bad_shapes():
