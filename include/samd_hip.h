@@ -310,6 +310,12 @@ int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inte
  * partial sums d_partial [splits][rows_pad][N] that the consuming kernel adds up (samd_rmsnorm / samd_rope_kv_write /
  * samd_silu_mul with n_partials > 0). */
 int samd_gemm_pack_weights(const void *d_W, void *d_packed, int32_t N, int32_t K, void *stream);
+/* the MLP's gate and up projections with LlamaMLP's activation in the epilogue: d_out [rows_pad][N/2] =
+ * silu(A @ Wgate^T) * (A @ Wup^T) with the model dtype's roundings (HF LlamaMLP.forward: act_fn(gate_proj(x)) * up_proj(x)).
+ * d_W = samd_gemm_pack_weights of the [N][K] matrix whose rows are gate and up interleaved in groups of 64:
+ * rows 128t..128t+63 = gate rows 64t..64t+63, rows 128t+64..128t+127 = up rows 64t..64t+63. */
+int samd_gemm_skinny_silu(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, void *d_out, int32_t dtype,
+                          void *stream);
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad);
 int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits);
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,

@@ -12,7 +12,7 @@
 // (tile t = 128 output columns, chunk c = 256 k) is 64 KiB contiguous at ((t * K/256 + c) * 4096) uint4 units; inside it
 // unit (2b + j) * 512 + tid holds W[128 t + 16 w + n][256 c + 64 b + 16 g + 8 j .. +7] for tid = 64 w + 16 g + n -- exactly
 // the order the lanes consume, so one wave-instruction is 1 KiB contiguous.  A (the activations, <= 512 KB, L2 resident) is staged per workgroup through LDS in 256-wide k chunks,
-// double buffered; the weights go HBM -> VGPR -> MFMA one chunk ahead.  (Measured and dropped: a 16-row variant that stages the
+// triple buffered; the weights go HBM -> VGPR -> MFMA two chunks ahead.  (Measured and dropped: a 16-row variant that stages the
 // whole A slice once and streams without per-chunk barriers -- 159 vs 141 us per layer-set, the serial staging costs more.
 // Ablation at 16 rows: with the MFMAs and the LDS traffic compiled out (weight stream only) the five projections of a layer
 // take 137 us vs 141 us for the real kernel, and dropping the barriers changes nothing: the kernel runs at what separate
@@ -27,6 +27,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GF16 { typedef _Float16 elem; typedef half8 vec8;
     static __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
@@ -40,7 +41,10 @@ struct GBF16 { typedef __bf16 elem; typedef bf16x8 vec8;
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <typename TT, int RT>
+// EPI 0: out / fp32 partials as they are.  EPI 1 (splits == 1 only): the matrix is the MLP's gate|up pair with its rows
+// interleaved in groups of 64 (tile t = gate columns 64t.. | up columns 64t..), and the epilogue writes
+// silu(gate) * up [rows][N/2] -- LlamaMLP's activation without a launch, a 2N-wide intermediate or its re-read.
+template <typename TT, int RT, int EPI>
 __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                         float *__restrict__ partial, typename TT::elem *__restrict__ out,
                                                         int K, int N, int n_chunks, int n_splits) {
@@ -53,26 +57,33 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny
     // ds_read_b128 wave-instruction touches (same unit, rows m..m+15) land in 16 different 16-byte slots -> no bank
     // conflict, and rows stay contiguous so the tile can be filled by LDS-DMA (global_load_lds, 1 KiB per wave-instruction,
     // no VGPR round trip; the swizzle goes on the SOURCE address).
-    __shared__ __attribute__((aligned(1024))) E xs[2][R][GEMM_KC];
+    __shared__ __attribute__((aligned(1024))) E xs[3][R][GEMM_KC];
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n0 = blockIdx.x * GEMM_COLS + 16 * w;
     const int split = blockIdx.y;
     const int c0 = (int)((long long)split * n_chunks / n_splits), c1 = (int)((long long)(split + 1) * n_chunks / n_splits);
-    const uint4 *wtile = reinterpret_cast<const uint4 *>(W) + (size_t)blockIdx.x * n_chunks * 4096 + tid;   // packed: see header
+    const char *wtile = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * 65536;           // packed: see header
+    const uint32_t wlane = (uint32_t)tid * 16;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)&xs[0][0][0];
 
     floatx4 acc[RT];
 #pragma unroll
     for (int mt = 0; mt < RT; mt++) acc[mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 wa[4][2], wb[4][2];
-    auto load_w = [&](uint4 (&dst)[4][2], int c) {
-        const uint4 *p = wtile + (size_t)c * 4096;
+    // The weight loads, the LDS reads and the waits between them are hand-issued.  The compiler's wait-count pass is
+    // path-insensitive and cannot tell which LDS buffer an LDS-DMA in flight writes: left to itself it drains every
+    // outstanding load (vmcnt(0)) in front of each chunk's first LDS read and first MFMA, which leaves ONE chunk in flight.
+    // Here TWO chunks (+ their A tiles) are in flight whenever a wave waits: memory ops retire in issue order, so "chunk c
+    // has landed, chunk c+1 may still fly" is vmcnt(8 + XV).  scripts/stream_probe.hip: 18.3 vs 20.2 us for the QKV matrix.
+    u32x4 wa[4][2], wb[4][2];
+    auto load_w = [&](u32x4 (&dst)[4][2], int c) {
+        const char *p = wtile + (size_t)c * 65536;                   // wave-uniform -> SGPR base, one offset VGPR
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            dst[b][0] = p[512 * (2 * b)];
-            dst[b][1] = p[512 * (2 * b + 1)];
-        }
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 8192 * (2 * b + j)) : "memory");
     };
     auto stage_x = [&](int c, int buf) {          // asynchronous: lands in LDS, counted by vmcnt
 #pragma unroll
@@ -82,39 +93,74 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny
             E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;       // wave-uniform base; the hardware adds lane * 16 B
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         }
+        asm volatile("" ::: "memory");
     };
-    // one phase = the MFMAs of chunk c on `cur` (weights loaded one phase earlier) and LDS buffer `buf`, while the
-    // weights and the A tile of chunk c+1 are in flight; two alternating phases so the weight registers are never copied
-    auto phase = [&](uint4 (&cur)[4][2], uint4 (&nxt)[4][2], int c, int buf) {
-        const bool more = c + 1 < c1;
-        if (more) { load_w(nxt, c + 1); stage_x(c + 1, buf ^ 1); }
+    // wait for the oldest chunk in flight, then meet the other waves -- their LDS-DMA shares of the A tile are then in
+    // place.  Bare s_barrier: __syncthreads() carries a fence that would drain the younger chunk as well.  Nothing ties
+    // the weight registers to the wait (an in/out operand would make the compiler copy them BEFORE the wait, i.e. while
+    // the load is in flight); instead every MFMA also consumes an LDS operand that a volatile asm after the wait produces,
+    // and volatile asm statements keep their order.
+    auto landed = [&](bool younger_in_flight) {
+        if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + XV) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // one phase: MFMAs of chunk c out of `cur` / LDS buffer `buf`, then the same registers are refilled with chunk c+2
+    // and LDS buffer (buf + 2) % 3, which every wave finished reading before this phase's barrier
+    auto phase = [&](u32x4 (&cur)[4][2], int c, int buf) {
+        landed(c + 1 < c1);
+        const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
+            const uint32_t u0 = (uint32_t)((8 * b + 2 * g) ^ n) * 16, u1 = (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;   // rows 16 mt + n: (row & 15) == n
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const V8 bf = __builtin_bit_cast(V8, cur[b][j]);
-                const int unit = (8 * b + 2 * g + j) ^ n;                    // rows 16 mt + n: (row & 15) == n
-#pragma unroll
-                for (int mt = 0; mt < RT; mt++) {
-                    const uint4 raw = *reinterpret_cast<const uint4 *>(&xs[buf][16 * mt + n][8 * unit]);
-                    acc[mt] = TT::mfma(__builtin_bit_cast(V8, raw), bf, acc[mt]);
-                }
+            for (int mt = 0; mt < RT; mt++) {
+                u32x4 r0, r1;
+                const uint32_t row = xbase + (uint32_t)mt * (16 * GEMM_KC * 2);
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(row + u0), "v"(row + u1));
+                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r0), __builtin_bit_cast(V8, cur[b][0]), acc[mt]);
+                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r1), __builtin_bit_cast(V8, cur[b][1]), acc[mt]);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // next chunk's weights + A tile have landed
-        __syncthreads();
+        if (c + 2 < c1) { load_w(cur, c + 2); stage_x(c + 2, buf == 0 ? 2 : buf - 1); }
     };
     if (c0 < c1) {
         load_w(wa, c0);
         stage_x(c0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (c0 + 1 < c1) { load_w(wb, c0 + 1); stage_x(c0 + 1, 1); }
+        int buf = 0;
         for (int c = c0; c < c1; c += 2) {
-            phase(wa, wb, c, 0);
-            if (c + 1 < c1) phase(wb, wa, c + 1, 1);
+            phase(wa, c, buf);
+            buf = buf == 2 ? 0 : buf + 1;
+            if (c + 1 < c1) { phase(wb, c + 1, buf); buf = buf == 2 ? 0 : buf + 1; }
         }
     }
     // C layout of mfma_16x16: lane holds rows 4g + r of column n
+    if constexpr (EPI == 1) {
+        float *ex = reinterpret_cast<float *>(&xs[0][0][0]);        // [R][64] up values; the A tiles are dead by now
+        __syncthreads();
+        if (w >= 4) {
+#pragma unroll
+            for (int mt = 0; mt < RT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) ex[(16 * mt + 4 * g + r) * 64 + 16 * (w - 4) + n] = acc[mt][r];
+        }
+        __syncthreads();
+        if (w < 4) {
+#pragma unroll
+            for (int mt = 0; mt < RT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = 16 * mt + 4 * g + r;
+                    // the roundings of HF's act_fn(gate_proj(x)) * up_proj(x) in the model dtype (same as k_silu_mul)
+                    const float gf = (float)(E)acc[mt][r], uf = (float)(E)ex[m * 64 + 16 * w + n];
+                    const E sv = (E)(gf / (1.f + __expf(-gf)));
+                    out[(size_t)m * (N / 2) + blockIdx.x * 64 + 16 * w + n] = (E)((float)sv * uf);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < RT; mt++) {
 #pragma unroll
@@ -141,22 +187,42 @@ __global__ __launch_bounds__(256) void k_gemm_pack(const uint4 *__restrict__ W, 
 
 extern "C" {
 
-// choose the split-K factor: enough workgroups to cover the chip twice, never more splits than chunks, and few enough
-// that the fp32 partials (written here, read by the consumer) stay a small fraction of the weight bytes
+// choose the split-K factor.  Measured (scripts/gemm_bench.py, profiles/): the stream is fastest when the launch is ONE
+// balanced wave of workgroups -- at most one per CU, each with a long run of chunks (gate|up: 172 workgroups x 16 chunks
+// 5.47 TB/s, lm_head 250 x 16 5.92 TB/s; QKV 96 x 2 splits 5.15 TB/s vs 4.9 with 4 or 8) -- so: the largest split count
+// that keeps columns x splits <= 256 and leaves every split at least one chunk.  Fewer splits also mean fewer fp32
+// partials for the consumer to add up.  The 64-row tile keeps at most 4 (its partials are 4x the bytes).
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad) {
     const int cols = N / GEMM_COLS, chunks = K / GEMM_KC;
     int cap = rows_pad <= 32 ? 8 : 4;
     if (const char *e = getenv("SAMD_GEMM_SPLIT_CAP")) cap = atoi(e);
     if (const char *e = getenv("SAMD_GEMM_SPLITS")) { int v = atoi(e); return v < 1 ? 1 : (v > chunks ? chunks : v); }
-    int s = 1;
-    while (cols * s < 512 && s * 2 <= chunks && s * 2 <= cap) s *= 2;
-    return s;
+    int s = 256 / (cols > 0 ? cols : 1);
+    if (s > cap) s = cap;
+    if (s > chunks) s = chunks;
+    return s < 1 ? 1 : s;
 }
 
 int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits) { return (int64_t)splits * rows_pad * N * 4; }
 
 // out (dtype, [rows_pad][N]) when splits == 1, else fp32 partials [splits][rows_pad][N] in d_partial.
 // rows_pad in {16, 32, 64}; A must hold rows_pad rows (pad rows are read, their products land in pad rows).
+int samd_gemm_skinny_silu(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, void *d_out, int32_t dtype, void *stream) {
+    if (!d_A || !d_W || !d_out || (rows_pad != 16 && rows_pad != 32 && rows_pad != 64) || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC ||
+        K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_skinny_silu: unsupported shape (rows 16/32/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
+    }
+    const dim3 grid(N / GEMM_COLS, 1), block(64 * GEMM_WAVES);
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = K / GEMM_KC;
+#define GO(TT, RT) hipLaunchKernelGGL((k_gemm_skinny<TT, RT, 1>), grid, block, 0, st, (const TT::elem *)d_A, (const TT::elem *)d_W, (float *)nullptr, (TT::elem *)d_out, K, N, chunks, 1)
+    if (dtype == SAMD_F16) { if (rows_pad == 16) GO(GF16, 1); else if (rows_pad == 32) GO(GF16, 2); else GO(GF16, 4); }
+    else { if (rows_pad == 16) GO(GBF16, 1); else if (rows_pad == 32) GO(GBF16, 2); else GO(GBF16, 4); }
+#undef GO
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
 int samd_gemm_pack_weights(const void *d_W, void *d_packed, int32_t N, int32_t K, void *stream) {
     if (!d_W || !d_packed || d_W == d_packed || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC || K % GEMM_KC != 0) {
         samd_set_error("samd_gemm_pack_weights: needs N %% 128 == 0, K %% 256 == 0 and distinct buffers"); return SAMD_E_INVALID;
@@ -177,7 +243,7 @@ int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t
     hipStream_t st = (hipStream_t)stream;
     const int chunks = K / GEMM_KC;
     void *out = splits == 1 ? d_out : nullptr;
-#define GO(TT, RT) hipLaunchKernelGGL((k_gemm_skinny<TT, RT>), grid, block, 0, st, (const TT::elem *)d_A, (const TT::elem *)d_W, d_partial, (TT::elem *)out, K, N, chunks, splits)
+#define GO(TT, RT) hipLaunchKernelGGL((k_gemm_skinny<TT, RT, 0>), grid, block, 0, st, (const TT::elem *)d_A, (const TT::elem *)d_W, d_partial, (TT::elem *)out, K, N, chunks, splits)
     if (dtype == SAMD_F16) { if (rows_pad == 16) GO(GF16, 1); else if (rows_pad == 32) GO(GF16, 2); else GO(GF16, 4); }
     else { if (rows_pad == 16) GO(GBF16, 1); else if (rows_pad == 32) GO(GBF16, 2); else GO(GBF16, 4); }
 #undef GO

@@ -99,8 +99,14 @@ class LlamaRunner:
                 out = torch.empty_like(t)
                 check(lib().samd_gemm_pack_weights(_ptr(t), _ptr(out), t.shape[0], t.shape[1], current_stream()))
                 return out
+            def pack_gate_up(t):
+                """gate|up rows interleaved in groups of 64 for the GEMM's silu(gate) * up epilogue (samd_gemm_skinny_silu)"""
+                gate, up = t[:s.inter].view(s.inter // 64, 64, -1), t[s.inter:].view(s.inter // 64, 64, -1)
+                return pack(torch.stack([gate, up], dim=1).reshape(2 * s.inter, -1).contiguous())
             self.wp = dict(lm_head=pack(weights["lm_head"]),
-                           layers=[{k: pack(l[k]) for k in ("wqkv", "wo", "wgu", "wdown")} for l in weights["layers"]])
+                           layers=[dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")},
+                                        wgu=pack_gate_up(l["wgu"]) if s.inter % 64 == 0 else pack(l["wgu"])) for l in weights["layers"]])
+        self.fused_mlp = self.wp is not None and s.inter % 64 == 0
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
         self.bind_cache(kv if kv is not None else
                         torch.zeros((s.layers, 2, s.kv_heads, self.max_len, s.head_dim), dtype=dtype, device=self.device))
@@ -216,7 +222,7 @@ class LlamaRunner:
             n, k = w.shape
             # measured on MI355X (scripts/forward_ablation.py, whole forward incl. the consumers' partial-sum reads):
             # the weight-streaming kernel wins at <= 16 rows (4.28 vs 4.75 ms) and at 32 (4.52 vs 4.62 ms), loses at 64 (5.51 vs 5.22 ms)
-            if not self.native_gemm or RP > self.native_gemm_max_rows:
+            if wp is None or RP > self.native_gemm_max_rows:
                 torch.mm(a[:R], w.t(), out=out[:R])
                 return out, 0, 0
             sp = L.samd_gemm_splits(n, k, RP) if out is not b["logits"] else 1
@@ -238,8 +244,11 @@ class LlamaRunner:
                                         _ptr(b["ws"]), b["ws_bytes"], st))
             src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"])
             check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride, st))
-            src, n_p, stride = gemm(b["h"], w["wgu"], wp.get("wgu"), b["gu"])
-            check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
+            if self.fused_mlp and RP <= self.native_gemm_max_rows:
+                check(L.samd_gemm_skinny_silu(_ptr(b["h"]), _ptr(wp["wgu"]), RP, 2 * s.inter, s.hidden, _ptr(b["act"]), dt, st))
+            else:
+                src, n_p, stride = gemm(b["h"], w["wgu"], None if self.fused_mlp else wp.get("wgu"), b["gu"])
+                check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
             delta, dn, dstride = gemm(b["act"], w["wdown"], wp.get("wdown"), b["d"])
         check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
         gemm(b["h"], self.w["lm_head"], self.wp["lm_head"] if self.wp else None, b["logits"])

@@ -41,6 +41,29 @@ def test_gemm_matches_fp32_reference(dtype, tol, rows_pad, N, K, splits):
     assert err <= tol * max(1.0, want.abs().max().item()), err
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("rows_pad,inter,K", [(16, 64, 256), (16, 11008, 4096), (32, 1408, 768), (64, 2816, 1024)])
+def test_gemm_silu_epilogue_matches_reference(dtype, tol, rows_pad, inter, K):
+    """samd_gemm_skinny_silu = LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) with the model dtype's roundings."""
+    g = torch.Generator(device="cuda").manual_seed(inter + K + rows_pad)
+    A = torch.randn((rows_pad, K), generator=g, device="cuda").to(dtype)
+    Wg = (torch.randn((inter, K), generator=g, device="cuda") * 0.05).to(dtype)
+    Wu = (torch.randn((inter, K), generator=g, device="cuda") * 0.05).to(dtype)
+    L = samd_hip.lib()
+    inter_leaved = torch.stack([Wg.view(inter // 64, 64, K), Wu.view(inter // 64, 64, K)], dim=1).reshape(2 * inter, K).contiguous()
+    packed = torch.empty_like(inter_leaved)
+    samd_hip.check(L.samd_gemm_pack_weights(samd_hip._ptr(inter_leaved), samd_hip._ptr(packed), 2 * inter, K, samd_hip.current_stream()))
+    out = torch.full((rows_pad, inter), float("nan"), device="cuda", dtype=dtype)
+    samd_hip.check(L.samd_gemm_skinny_silu(samd_hip._ptr(A), samd_hip._ptr(packed), rows_pad, 2 * inter, K, samd_hip._ptr(out),
+                                           samd_hip.torch_dtype_code(dtype), samd_hip.current_stream()))
+    gate = (A.float() @ Wg.float().t()).to(dtype)
+    up = (A.float() @ Wu.float().t()).to(dtype)
+    want = (torch.nn.functional.silu(gate.float()).to(dtype).float() * up.float())
+    assert torch.isfinite(out).all()
+    err = (out.float() - want).abs().max().item()
+    assert err <= tol * max(1.0, want.abs().max().item()), err
+
+
 def test_pack_weights_is_the_documented_permutation():
     """unit (2b + j) * 512 + tid of block (t, c) holds W[128 t + 16 w + n][256 c + 64 b + 16 g + 8 j ..+7], tid = 64 w + 16 g + n
     (include/samd_hip.h, gemm_kernels.hip header)."""
@@ -65,3 +88,4 @@ def test_gemm_rejects_bad_shapes():
     assert ok(16, 128, 200, 1) != 0        # K % 256
     assert ok(16, 128, 256, 2) != 0        # more splits than chunks
     assert L.samd_gemm_splits(4096, 4096, 16) >= 2 and L.samd_gemm_splits(4096, 4096, 64) <= 4
+    assert L.samd_gemm_splits(22016, 4096, 16) == 1 and L.samd_gemm_splits(12288, 4096, 16) == 2      # one balanced wave of workgroups
