@@ -89,7 +89,7 @@ class LlamaRunner:
         qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
         shapes = [(qkv_out, s.hidden), (s.hidden, s.heads * s.head_dim), (2 * s.inter, s.hidden), (s.hidden, s.inter), (s.vocab, s.hidden)]
         self.native_gemm = bool(native_gemm) and all(n % 128 == 0 and k % 256 == 0 for n, k in shapes)
-        self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 32))     # tuning knob; see forward_rows
+        self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 64))     # tuning knob; see forward_rows
         # second copy of the projection weights in the streaming kernel's packed layout (samd_gemm_pack_weights): the
         # row-major originals stay for the library GEMM of the 64-row bucket and the wide prefill.  2 x 13.5 GB for a 7B
         # model -- HBM capacity (288 GB) is not what this path is short of, bandwidth is.
@@ -220,8 +220,8 @@ class LlamaRunner:
         def gemm(a, w, wp, out):
             """out = a @ w.T (wp = w in the packed layout); returns (operand for the consumer, n_partials, partial_stride)."""
             n, k = w.shape
-            # measured on MI355X (scripts/forward_ablation.py, whole forward incl. the consumers' partial-sum reads):
-            # the weight-streaming kernel wins at <= 16 rows (4.28 vs 4.75 ms) and at 32 (4.52 vs 4.62 ms), loses at 64 (5.51 vs 5.22 ms)
+            # measured on MI355X (scripts/forward_ablation.py, whole forward incl. the consumers' partial-sum reads), ours vs
+            # the library GEMM: 3.46 vs 4.75 ms at <= 16 rows, 3.74 vs 4.62 at 32, 4.72 vs 5.15 at 64
             if wp is None or RP > self.native_gemm_max_rows:
                 torch.mm(a[:R], w.t(), out=out[:R])
                 return out, 0, 0
