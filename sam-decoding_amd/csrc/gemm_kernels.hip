@@ -2,22 +2,24 @@
 // with m <= 64 draft rows, W = an HF nn.Linear weight [N, K], re-tiled once at load time (samd_gemm_pack_weights) so that
 // every workgroup reads its share as one linear stream of 64 KiB blocks.
 //
-// At n <= 64 rows the verify forward is bound by reading the weights once (13.5 GB for Vicuna-7B): the kernel is a
-// weight STREAM with a little MFMA attached.  What shapes it (scripts/hbm_probe.hip, profiles/r01_hbm_probe.md): the
-// memory system retires ~48 G requests/s whatever their size, so every request must carry a full 128-byte line --
-// each lane therefore owns 32 contiguous bytes of a weight row per 64-wide k block (4 lanes = 128 B of one row), and
-// the MFMA k index is permuted accordingly (the A operand is read from LDS with the same permutation, so the product
-// is unchanged).  PACKED LAYOUT (scripts/stream_probe.hip, profiles/r01_stream_sweep.log: reading the same bytes with this
-// kernel's grid but the row-major matrix is 8-9 % slower, 79.6 vs 72.8 us for the four projections of a layer): block
-// (tile t = 128 output columns, chunk c = 256 k) is 64 KiB contiguous at ((t * K/256 + c) * 4096) uint4 units; inside it
-// unit (2b + j) * 512 + tid holds W[128 t + 16 w + n][256 c + 64 b + 16 g + 8 j .. +7] for tid = 64 w + 16 g + n -- exactly
-// the order the lanes consume, so one wave-instruction is 1 KiB contiguous.  A (the activations, <= 512 KB, L2 resident) is staged per workgroup through LDS in 256-wide k chunks,
-// triple buffered; the weights go HBM -> VGPR -> MFMA two chunks ahead.  (Measured and dropped: a 16-row variant that stages the
-// whole A slice once and streams without per-chunk barriers -- 159 vs 141 us per layer-set, the serial staging costs more.
-// Ablation at 16 rows: with the MFMAs and the LDS traffic compiled out (weight stream only) the five projections of a layer
-// take 137 us vs 141 us for the real kernel, and dropping the barriers changes nothing: the kernel runs at what separate
-// launches of 33-180 MB can stream (4.0-5.2 TB/s incl. ramp-up and tail); the rest is launch granularity, not the kernel body.)  Split-K partial sums are written as fp32 and
-// summed by the consuming kernel (rmsnorm+residual, rope, silu*up), so the split costs no extra launch.
+// At <= 64 rows the verify forward is bound by reading the weights once (13.5 GB for Vicuna-7B): the kernel is a weight
+// STREAM with a little MFMA attached.  What shapes it (scripts/hbm_probe.hip, scripts/stream_probe.hip, profiles/):
+//   * the memory system retires ~48 G requests/s whatever their size, so every request carries full lines: a lane loads
+//     16 bytes, a wave-instruction 1 KiB contiguous;
+//   * PACKED LAYOUT: block (tile t = 128 output columns, chunk c = 256 k) is 64 KiB contiguous at
+//     ((t * K/256 + c) * 4096) uint4 units; inside it unit (2b + j) * 512 + tid holds
+//     W[128 t + 16 w + n][256 c + 64 b + 16 g + 8 j .. +7] for tid = 64 w + 16 g + n -- exactly the order the lanes consume
+//     (lane (g, n) of wave w feeds column 16 w + n; its 8-element vectors cover k = 64 b + 16 g + 8 j .. within each 64-wide
+//     k block, and the A operand is read from LDS with the same k permutation, so the product is unchanged).  Reading the
+//     same bytes with this grid from the row-major matrix is 8-9 % slower (79.6 vs 72.8 us for a layer's four projections);
+//   * A (the activations, <= 1 MB, L2 resident) is staged per workgroup through LDS by LDS-DMA in 256-wide k chunks, three
+//     buffers; the weights go HBM -> VGPR -> MFMA with TWO chunks in flight (see the pipeline comment in the kernel);
+//   * one balanced wave of workgroups per launch (samd_gemm_splits); split-K partial sums are written as fp32 and added up
+//     by the consuming kernel (rmsnorm + residual, rope), so a split costs no extra launch.
+// Measured and dropped: a 16-row variant that stages the whole A slice once (159 vs 141 us per layer), nontemporal loads,
+// 16-wave workgroups, an intra-workgroup K split, an Infinity-Cache warmer on a side stream, producers of A inside the launch
+// (DESIGN.md, K7).  Ablation: with the MFMAs and the LDS traffic compiled out the kernel is 3 % faster -- it runs at what
+// separate launches of 33-180 MB can stream (4.1-5.9 TB/s incl. ramp-up and tail).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "samd_common.h"
