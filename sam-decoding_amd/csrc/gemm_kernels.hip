@@ -193,10 +193,11 @@ extern "C" {
 // balanced wave of workgroups -- at most one per CU, each with a long run of chunks (gate|up: 172 workgroups x 16 chunks
 // 5.47 TB/s, lm_head 250 x 16 5.92 TB/s; QKV 96 x 2 splits 5.15 TB/s vs 4.9 with 4 or 8) -- so: the largest split count
 // that keeps columns x splits <= 256 and leaves every split at least one chunk.  Fewer splits also mean fewer fp32
-// partials for the consumer to add up.  The 64-row tile keeps at most 4 (its partials are 4x the bytes).
+// partials for the consumer to add up; capped at 8 (whole forward at 64 rows: 4.47 ms with cap 8, 4.56 with 6, 4.64 with 4).
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad) {
     const int cols = N / GEMM_COLS, chunks = K / GEMM_KC;
-    int cap = rows_pad <= 32 ? 8 : 4;
+    int cap = 8;
+    (void)rows_pad;
     if (const char *e = getenv("SAMD_GEMM_SPLIT_CAP")) cap = atoi(e);
     if (const char *e = getenv("SAMD_GEMM_SPLITS")) { int v = atoi(e); return v < 1 ? 1 : (v > chunks ? chunks : v); }
     int s = 256 / (cols > 0 ? cols : 1);

@@ -87,5 +87,5 @@ def test_gemm_rejects_bad_shapes():
     assert ok(16, 100, 256, 1) != 0        # N % 128
     assert ok(16, 128, 200, 1) != 0        # K % 256
     assert ok(16, 128, 256, 2) != 0        # more splits than chunks
-    assert L.samd_gemm_splits(4096, 4096, 16) >= 2 and L.samd_gemm_splits(4096, 4096, 64) <= 4
+    assert L.samd_gemm_splits(4096, 4096, 16) == 8 and L.samd_gemm_splits(4096, 4096, 64) == 8
     assert L.samd_gemm_splits(22016, 4096, 16) == 1 and L.samd_gemm_splits(12288, 4096, 16) == 2      # one balanced wave of workgroups
