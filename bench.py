@@ -391,6 +391,13 @@ def main():
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
             "step_breakdown_by_rows": breakdown,
+            # SURVEY.md 8(d) end-to-end proxy: speed-up = accepted tokens x T_AR / T_step with THIS run's measured step times
+            # (16- and 64-row buckets) and the mean accepted tokens the reference publishes (README.md:53-57) -- a projection,
+            # not a measurement of those configurations
+            "projected_speedup_at_published_mat": {
+                str(m): {"rows16": round(m * (1e3 / ar_tps) / breakdown["16"]["step_ms"], 2),
+                         "rows64": round(m * (1e3 / ar_tps) / breakdown["64"]["step_ms"], 2)}
+                for m in (2.30, 3.03, 4.62)} if "16" in breakdown and "64" in breakdown else None,
             "roofline": roof, "cpu_baseline": cpu,
             "setup": {"static_build_s": round(build_s, 2), "host": f"{os.cpu_count()} cores"},
         }
