@@ -126,9 +126,9 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
                           T *__restrict__ q_out, T *__restrict__ k_cache, T *__restrict__ v_cache, int H, int Hkv, int D,
                           long long max_len, int max_pos, int n_part, long long part_stride) {
     const int r = blockIdx.x, hh = blockIdx.y, j = threadIdx.x, half = D >> 1;
-    if (r >= d_n[0]) return;
-    const int L = d_L[0];
-    if (L + r >= max_len) return;                              // never write past the cache (the host guard breaks earlier)
+    // the operand loads do not depend on n / L: they are issued first, together with the scalars and this row's relative
+    // position, so that the kernel is two memory round trips (operands + scalars, then cos/sin) instead of four
+    const int rel = rel_pos[r], n = d_n[0], L = d_L[0];
     const size_t soff = ((size_t)r * (H + 2 * Hkv) + hh) * D;
     float x1, x2;                                              // elements j and j + D/2 of this head's row
     if (n_part == 0) { x1 = (float)qkv[soff + j]; x2 = (float)qkv[soff + j + half]; }
@@ -147,12 +147,14 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
         }
         x1 = (float)(T)a; x2 = (float)(T)b;                    // rounded like the GEMM's own output
     }
+    if (r >= n) return;
+    if (L + r >= max_len) return;                              // never write past the cache (the host guard breaks earlier)
     if (hh >= H + Hkv) {                                       // V: plain copy
         T *dst = v_cache + ((size_t)(hh - H - Hkv) * max_len + L + r) * D;
         dst[j] = (T)x1; dst[j + half] = (T)x2;
         return;
     }
-    int pos = L + rel_pos[r]; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+    int pos = L + rel; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
     const float c = cos_t[(size_t)pos * half + j], s = sin_t[(size_t)pos * half + j];
     const T o1 = (T)(x1 * c - x2 * s), o2 = (T)(x2 * c + x1 * s);
     T *dst = hh < H ? q_out + ((size_t)r * H + hh) * D : k_cache + ((size_t)(hh - H) * max_len + L + r) * D;

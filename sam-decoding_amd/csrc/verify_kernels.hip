@@ -141,16 +141,41 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     unsigned long long mrow[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) mrow[r] = mask[row_base + 4 * lg + r];       // mask holds 64 rows; rows >= n are zeroed below
+    // Split s owns the key tiles s, s + ATT_SPLITS, s + 2 ATT_SPLITS, ...: the FIRST tile of a workgroup is known from its
+    // block index alone, so its K fragments and V rows are requested here, in the same memory round trip as the two scalars
+    // (L, n) instead of after them.  Keys are clamped to the cache; what lies beyond L + n is masked (K) / zeroed (V) below.
+    const int kvh = h / (n_heads / n_kv_heads);
+    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
+    const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
+    const bool may_be_active = row_base < n_q_pad;     // n <= n_q_pad: waves beyond the row bucket never compute
+    uint4 kraw[4][4], vra[2], vrb[2];
+    auto load_k = [&](int key0) {
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            int key = key0 + 16 * st + lr;
+            key = key < (int)max_len ? key : (int)max_len - 1;
+            const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) kraw[st][kk] = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
+        }
+    };
+    auto load_v = [&](int key0) {                      // thread handles key pair (2p, 2p+1) x one 8-wide d chunk, twice
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+            int ka = key0 + 2 * p, kb = ka + 1;
+            ka = ka < (int)max_len ? ka : (int)max_len - 1; kb = kb < (int)max_len ? kb : (int)max_len - 1;
+            vra[it] = *reinterpret_cast<const uint4 *>(vbase + (size_t)ka * ATT_D + d0);
+            vrb[it] = *reinterpret_cast<const uint4 *>(vbase + (size_t)kb * ATT_D + d0);
+        }
+    };
+    if (may_be_active) load_k(split * ATT_TILE);
+    load_v(split * ATT_TILE);
     const int L = d_L[0];
     int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
     const int total = L + n;
     const int ntiles = (total + ATT_TILE - 1) / ATT_TILE;
-    const int tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
-    const int t0 = split * tps, t1 = min(ntiles, t0 + tps);
-    if (t0 >= t1) return;                              // no keys for this split: k_attn_combine only reads the splits in use
-    const int kvh = h / (n_heads / n_kv_heads);
-    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
-    const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
+    if (split >= ntiles) return;                       // no keys for this split: k_attn_combine only reads the splits in use
     const bool active = row_base < n;
 #pragma unroll
     for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) mrow[r] = 0ull;
@@ -164,29 +189,18 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 
     E *Pmine = Pw + w * 16 * P_STRIDE;
 
-    for (int t = t0; t < t1; t++) {
+    for (int t = split; t < ntiles; t += ATT_SPLITS) {
         const int key0 = t * ATT_TILE;
-        // ---- issue this tile's K fragment loads first: their HBM latency overlaps the V staging below
-        uint4 kraw[4][4];
-        if (active) {
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                int key = key0 + 16 * st + lr;
-                key = key < (int)max_len ? key : (int)max_len - 1;
-                const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) kraw[st][kk] = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
-            }
-        }
+        // ---- later tiles: K fragment loads first, their latency overlaps the V staging below
+        if (t != split && active) load_k(key0);
         __syncthreads();                                   // previous tile's Vt / Pw reads are done
-        // ---- stage V^T: thread handles key pair (2p, 2p+1) x one 8-wide d chunk, twice
+        if (t != split) load_v(key0);
+        // ---- stage V^T (key pairs packed per dword); rows past L + n are zero: their P is 0, but 0 x garbage could be NaN
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
             const int ka = key0 + 2 * p, kb = ka + 1;
-            uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-            if (ka < total) ra = *reinterpret_cast<const uint4 *>(vbase + (size_t)ka * ATT_D + d0);
-            if (kb < total) rb = *reinterpret_cast<const uint4 *>(vbase + (size_t)kb * ATT_D + d0);
+            const uint4 ra = ka < total ? vra[it] : make_uint4(0, 0, 0, 0), rb = kb < total ? vrb[it] : make_uint4(0, 0, 0, 0);
             const unsigned short *ea = reinterpret_cast<const unsigned short *>(&ra);
             const unsigned short *eb = reinterpret_cast<const unsigned short *>(&rb);
 #pragma unroll
@@ -277,20 +291,21 @@ template <typename E>
 __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
                                                       const int *__restrict__ d_L, const int *__restrict__ d_n) {
     const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
-    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
-    E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d;
-    if (row >= n) { *dst = (E)0.f; return; }
-    // the splits k_tree_attention actually ran (same arithmetic as there): the others left their partials untouched
-    const int ntiles = (d_L[0] + n + ATT_TILE - 1) / ATT_TILE, tps = (ntiles + ATT_SPLITS - 1) / ATT_SPLITS;
-    const int used = (ntiles + tps - 1) / tps;
-    // issue every split's (m, l, O[d]) load before consuming any: one memory round trip instead of one per split
+    // every split's (m, l, O[d]) is loaded before anything is consumed, and before the two scalars that say how many
+    // splits ran are known: one memory round trip for the whole kernel.  Splits that did not run hold older partials
+    // (the workspace always has ATT_SPLITS slots); they are ignored below.
     float mv[ATT_SPLITS], lv[ATT_SPLITS], pv[ATT_SPLITS];
 #pragma unroll
     for (int s = 0; s < ATT_SPLITS; s++) {
-        const int ss = s < used ? s : 0;                                   // clamp: unconditional loads keep them all in flight
-        const float *p = ws + (((size_t)ss * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
+        const float *p = ws + (((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
         mv[s] = p[ATT_D]; lv[s] = p[ATT_D + 1]; pv[s] = p[d];
     }
+    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
+    E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d;
+    if (row >= n) { *dst = (E)0.f; return; }
+    // the splits k_tree_attention actually ran: split s owns the key tiles s, s + ATT_SPLITS, ...
+    const int ntiles = (d_L[0] + n + ATT_TILE - 1) / ATT_TILE;
+    const int used = ntiles < ATT_SPLITS ? ntiles : ATT_SPLITS;
     float M = -INFINITY;
 #pragma unroll
     for (int s = 0; s < ATT_SPLITS; s++) if (s < used) M = fmaxf(M, mv[s]);
