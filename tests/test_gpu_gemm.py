@@ -64,6 +64,26 @@ def test_gemm_silu_epilogue_matches_reference(dtype, tol, rows_pad, inter, K):
     assert err <= tol * max(1.0, want.abs().max().item()), err
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_gemm_random_chunk_and_split_counts(seed):
+    """the pipeline has separate paths for 1, 2 and >= 3 chunks per workgroup and for odd / even counts: sweep them all
+    (K = 256 x 1..20, every split count that divides the work unevenly too), all three row tiles, both dtypes."""
+    rng = np.random.default_rng(seed)
+    for _ in range(10):
+        chunks = int(rng.integers(1, 21))
+        K, N = 256 * chunks, 128 * int(rng.integers(1, 9))
+        splits = int(rng.integers(1, chunks + 1))
+        rows_pad = int(rng.choice([16, 32, 64]))
+        dtype, tol = ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2))[int(rng.integers(0, 2))]
+        g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+        A = torch.randn((rows_pad, K), generator=g, device="cuda").to(dtype)
+        W = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(dtype)
+        got = run(A, W, rows_pad, splits, dtype)
+        want = A.float() @ W.float().t()
+        err = (got - want).abs().max().item()
+        assert torch.isfinite(got).all() and err <= tol * max(1.0, want.abs().max().item()), (rows_pad, N, K, splits, dtype, err)
+
+
 def test_pack_weights_is_the_documented_permutation():
     """unit (2b + j) * 512 + tid of block (t, c) holds W[128 t + 16 w + n][256 c + 64 b + 16 g + 8 j ..+7], tid = 64 w + 16 g + n
     (include/samd_hip.h, gemm_kernels.hip header)."""
