@@ -85,28 +85,31 @@ class LlamaRunner:
         self.max_len = int(max_cache_len)
         s = shape
         self.w = weights
-        # samd_gemm_skinny streams the weights itself (N % 128 == 0, K % 256 == 0); otherwise the library GEMM runs
-        qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
-        shapes = [(qkv_out, s.hidden), (s.hidden, s.heads * s.head_dim), (2 * s.inter, s.hidden), (s.hidden, s.inter), (s.vocab, s.hidden)]
-        self.native_gemm = bool(native_gemm) and all(n % 128 == 0 and k % 256 == 0 for n, k in shapes)
+        # samd_gemm_skinny streams the weights itself where the shape allows (N % 128 == 0, K % 256 == 0); a projection that
+        # does not fit (say a fine-tune's 32001-row lm_head) goes to the library GEMM on its own, the others keep the kernel
+        streams = lambda t: bool(native_gemm) and t.shape[0] % 128 == 0 and t.shape[1] % 256 == 0
         self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 64))     # tuning knob; see forward_rows
         # second copy of the projection weights in the streaming kernel's packed layout (samd_gemm_pack_weights): the
-        # row-major originals stay for the library GEMM of the 64-row bucket and the wide prefill.  2 x 13.5 GB for a 7B
-        # model -- HBM capacity (288 GB) is not what this path is short of, bandwidth is.
-        self.wp = None
-        if self.native_gemm:
-            def pack(t):
-                out = torch.empty_like(t)
-                check(lib().samd_gemm_pack_weights(_ptr(t), _ptr(out), t.shape[0], t.shape[1], current_stream()))
-                return out
-            def pack_gate_up(t):
-                """gate|up rows interleaved in groups of 64 for the GEMM's silu(gate) * up epilogue (samd_gemm_skinny_silu)"""
-                gate, up = t[:s.inter].view(s.inter // 64, 64, -1), t[s.inter:].view(s.inter // 64, 64, -1)
-                return pack(torch.stack([gate, up], dim=1).reshape(2 * s.inter, -1).contiguous())
-            self.wp = dict(lm_head=pack(weights["lm_head"]),
-                           layers=[dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")},
-                                        wgu=pack_gate_up(l["wgu"]) if s.inter % 64 == 0 else pack(l["wgu"])) for l in weights["layers"]])
-        self.fused_mlp = self.wp is not None and s.inter % 64 == 0
+        # row-major originals stay for the wide prefill's library GEMMs.  2 x 13.5 GB for a 7B model -- HBM capacity
+        # (288 GB) is not what this path is short of, bandwidth is.
+        def pack(t):
+            if not streams(t):
+                return None
+            out = torch.empty_like(t)
+            check(lib().samd_gemm_pack_weights(_ptr(t), _ptr(out), t.shape[0], t.shape[1], current_stream()))
+            return out
+        def pack_gate_up(t):
+            """gate|up rows interleaved in groups of 64 for the GEMM's silu(gate) * up epilogue (samd_gemm_skinny_silu)"""
+            if s.inter % 64 != 0 or not streams(t):
+                return None
+            gate, up = t[:s.inter].view(s.inter // 64, 64, -1), t[s.inter:].view(s.inter // 64, 64, -1)
+            return pack(torch.stack([gate, up], dim=1).reshape(2 * s.inter, -1).contiguous())
+        self.wp = dict(lm_head=pack(weights["lm_head"]),
+                       layers=[dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")}, wgu=pack_gate_up(l["wgu"])) for l in weights["layers"]])
+        self.native_gemm = self.wp["lm_head"] is not None or any(v is not None for l in self.wp["layers"] for v in l.values())
+        if not self.native_gemm:
+            self.wp = None
+        self.fused_mlp = self.wp is not None and all(l["wgu"] is not None for l in self.wp["layers"])
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
         self.bind_cache(kv if kv is not None else
                         torch.zeros((s.layers, 2, s.kv_heads, self.max_len, s.head_dim), dtype=dtype, device=self.device))
@@ -247,7 +250,7 @@ class LlamaRunner:
             if self.fused_mlp and RP <= self.native_gemm_max_rows:
                 check(L.samd_gemm_skinny_silu(_ptr(b["h"]), _ptr(wp["wgu"]), RP, 2 * s.inter, s.hidden, _ptr(b["act"]), dt, st))
             else:
-                src, n_p, stride = gemm(b["h"], w["wgu"], None if self.fused_mlp else wp.get("wgu"), b["gu"])
+                src, n_p, stride = gemm(b["h"], w["wgu"], None, b["gu"])           # wgu is only ever packed for the fused form
                 check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
             delta, dn, dstride = gemm(b["act"], w["wdown"], wp.get("wdown"), b["d"])
         check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))

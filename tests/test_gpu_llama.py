@@ -73,6 +73,20 @@ def test_prefill_and_tree_verify_match_hf(kv_heads):
     assert (b["argmax"][:n].cpu() == want.argmax(-1).cpu()).float().mean().item() > 0.8
 
 
+def test_projection_that_cannot_stream_falls_back_alone():
+    """a 515-row lm_head (not a multiple of 128) goes to the library GEMM; the layer projections keep the streaming kernel"""
+    lm = tiny_llama(2, vocab=515)
+    runner = LlamaRunner.from_hf(lm, max_cache_len=256, dtype=torch.float16)
+    assert runner.wp is not None and runner.wp["lm_head"] is None and runner.wp["layers"][0]["wqkv"] is not None and runner.fused_mlp
+    sess = samd_hip.Session(512)
+    prompt = np.random.default_rng(3).integers(3, 515, 40).tolist()
+    ids = torch.tensor([prompt], device="cuda")
+    last = runner.prefill(sess, ids)
+    with torch.no_grad():
+        ref = lm(input_ids=ids).logits[0]
+    assert (last.float() - ref[-1]).abs().max().item() < TOL
+
+
 def _near_tie(lm, prefix, a, b, eps=5e-2):
     with torch.no_grad():
         lg = lm(input_ids=torch.tensor([prefix], device="cuda")).logits[0, -1]
