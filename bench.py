@@ -415,7 +415,7 @@ def main():
         ar_tps = ar_tokens / (time.perf_counter() - ta)
 
         roof, toks_walk = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20, args.corpus_tokens)
-        cpu = None if args.no_cpu_baseline else cpu_baseline(flat, off, docs, cfg, toks_walk)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(flat, off, docs, cfg, toks_walk)    # rank 0 at N = 1 only
 
         n_steps = sum(v[0] for v in stats.values())
         n_tok = sum(v[1] for v in stats.values())
