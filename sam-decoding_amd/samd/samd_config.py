@@ -30,12 +30,24 @@ def load_token_recycle(tree_path: Optional[str] = None):
     return [tree_adj[str(i)] for i in range(len(tree_adj))]
 
 
+# the static EAGLE (v1) draft tree the reference ships (config/eagle.json): paths of top-4 ranks, 25 nodes below the root
+EAGLE_TREE_CHOICES: List[List[int]] = [
+    [0], [1], [2], [3], [0, 0], [0, 1], [0, 2], [1, 0], [1, 1], [2, 0], [2, 1], [3, 0],
+    [0, 0, 0], [0, 0, 1], [0, 0, 2], [0, 1, 0], [0, 1, 1], [0, 2, 0], [0, 2, 1], [1, 0, 0],
+    [0, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, 2], [0, 0, 0, 0, 0], [0, 0, 0, 0, 1],
+]
+
+
 def load_eagle(tree_model_path: str, tree_path: Optional[str] = None):
-    """samd_config.py:83-91: static EAGLE tree choices + the draft head's config.json"""
+    """samd_config.py:83-91: static EAGLE tree choices (default: the shipped tree; `tree_path` = a JSON with
+    'tree_choices', relative paths resolved against this package's config/) + the draft head's config.json"""
     if tree_path is None:
-        raise FileNotFoundError("EAGLE-v1 needs an explicit tree_path (JSON with 'tree_choices')")
-    with open(tree_path, "r") as f:
-        tree = json.load(f)["tree_choices"]
+        tree = [list(c) for c in EAGLE_TREE_CHOICES]
+    else:
+        if not os.path.isabs(tree_path):
+            tree_path = os.path.join(os.path.dirname(__file__), "config", tree_path)
+        with open(tree_path, "r") as f:
+            tree = json.load(f)["tree_choices"]
     with open(os.path.join(tree_model_path, "config.json")) as f:
         tree_config = json.load(f)
     return tree, tree_config
@@ -69,7 +81,10 @@ class SamdConfig:
             if self.tree_method == "token_recycle":
                 self.tree = load_token_recycle(self.tree_path)
             elif self.tree_method == "eagle":
-                self.tree, self.tree_config = load_eagle(self.tree_model_path, self.tree_path)
+                if self.tree_config is None:
+                    self.tree, self.tree_config = load_eagle(self.tree_model_path, self.tree_path)
+                else:
+                    self.tree = [list(c) for c in EAGLE_TREE_CHOICES]
                 self.use_last_hidden_states = True
             elif self.tree_method == "eagle2":
                 if self.tree_config is None:

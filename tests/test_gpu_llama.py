@@ -205,6 +205,57 @@ def test_eagle2_plugin_is_lossless_and_paths_agree():
         assert par[0] == -1 and all(0 <= par[i] < i for i in range(1, 63))
 
 
+def test_eagle_static_tree_plugin_is_lossless_and_paths_agree():
+    """samd[EAGLE] (v1, static 26-node tree): same losslessness criterion as EAGLE-2, fused engine and granular form; the
+    installed draft is the static tree (parent array of samd.tree_model.eagle.StaticDraftTree)."""
+    import samd as S
+    import samd_sam_only as SO
+    from samd.tree_model.eagle import Eagle, EagleHead, StaticDraftTree
+    lm = tiny_llama(2, seed=6)
+    rng = np.random.default_rng(5)
+    prompt = rng.integers(3, 512, 70).tolist()
+    prompt[40:52] = prompt[10:22]
+    ids = torch.tensor([prompt], device="cuda")
+    gcfg = SO.SamdGenerationConfig(max_new_tokens=48, max_cache_len=512)
+    ar_cfg = SO.SamdConfig(max_predicts=1)
+    ar = SO.SamdModel(ar_cfg, lm, SO.DraftModel(ar_cfg, device="cuda"), eos_token_id=2, dtype=torch.float16, device="cuda")
+    seq_ar = ar.generate(ids, generation_config=gcfg).output_ids[0]
+    tree_cfg = dict(hidden_size=256, intermediate_size=512, num_attention_heads=2, num_key_value_heads=2, vocab_size=512,
+                    rms_norm_eps=1e-5, bias=True)
+    cfg = S.SamdConfig(n_predicts=12, len_threshold=3, len_bias=0, tree_method="eagle", tree_config=tree_cfg)
+    assert cfg.use_last_hidden_states and len(cfg.tree) == 25
+
+    def build():
+        head = EagleHead(tree_cfg, dtype=torch.float16, device="cuda")
+        head.random_init(seed=3, std=0.08)
+        head.set_tree(StaticDraftTree(cfg.tree))
+        tm = Eagle(cfg, lm, torch.float16, "cuda", head=head)
+        draft = S.DraftModel(cfg, tree_model=tm, lm=lm, device="cuda")
+        return S.SamdModel(cfg, lm, draft, eos_token_id=2, dtype=torch.float16, device="cuda")
+
+    def check(seq):
+        m = min(len(seq), len(seq_ar))
+        diff = [i for i in range(m) if seq[i] != seq_ar[i]]
+        assert not diff or (diff[0] > len(prompt) + 4 and _near_tie(lm, seq[:diff[0]], seq[diff[0]], seq_ar[diff[0]])), diff[:3]
+
+    model = build()
+    out = model.generate(ids, generation_config=gcfg)
+    check(out.output_ids[0])
+    assert model.lookup_stats["tree"][0] > 0, "the EAGLE tree path never ran"
+    model2 = build()
+    model2.gen_config = gcfg
+    got = list(prompt)
+    for new_ids, _ in model2._run_granular(ids, gcfg, 16):
+        got.extend(new_ids)
+    check(got)
+    model3 = build()
+    model3.set_cache(gcfg)
+    rep = model3.engine.start(ids)
+    d = model3.draft.session().read_draft()
+    if rep.type == 1 and d.n == 26:
+        assert list(d.parent[:26]) == StaticDraftTree(cfg.tree).parents
+
+
 def test_bf16_gqa_runner_matches_hf():
     """Llama-3-style numerics path: bf16, grouped-query attention (2 query heads per KV head), llama3 rope scaling.
     Tolerance: bf16 has 8 mantissa bits; logits of this 2-layer model agree with fp32 HF to 0.15 absolute."""
