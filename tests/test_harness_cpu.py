@@ -117,3 +117,63 @@ def test_gen_sam_tool_builds_corpus_with_vocab_documents(tmp_path):
     sam = SO.build_sam(batch, 2)
     assert len(sam.states[0].next) >= 40                      # the root has an edge for every vocabulary id
     assert load_dialogues("none") == []
+
+
+# --------------------------------------------------------------------------------------------------
+# chat REPL (evaluation/chat.py; reference samd_sam_only/inference/cli.py:76-203)
+# --------------------------------------------------------------------------------------------------
+class _EchoModel:
+    """stands in for SamdModel.stream_generate: 'answers' with the number of prompt tokens, a few characters per step"""
+
+    def __init__(self):
+        self.calls = 0
+
+    def stream_generate(self, input_ids, tokenizer, generation_config=None):
+        self.calls += 1
+        full = f"answer {self.calls} to {input_ids.shape[-1]} tokens</s>ignored"
+        for i in range(3, len(full) + 3, 3):
+            yield {"text": full[:i]}
+
+
+class _WordTokenizer:
+    def encode(self, text):
+        return list(range(len(text.split())))
+
+    def __call__(self, text):
+        class R:
+            input_ids = self.encode(text)
+        return R
+
+
+def test_chat_loop_commands(tmp_path):
+    from evaluation.chat import ChatSession, chat_loop, stream_answer
+    model, tok = _EchoModel(), _WordTokenizer()
+    out = []
+    save = str(tmp_path / "conv")
+    script = iter(["hello there", "second question", "!!regen", "!!save " + save, "!!remove", "!!remove", "!!remove",
+                   "!!load " + save, "!!load nowhere", "!!save", "!!reset", "after reset", "!!exit"])
+    session = ChatSession("vicuna")
+    answer = lambda prompt: stream_answer(model, tok, prompt, None, out.append, stop_str="</s>")
+    chat_loop(session, answer, lambda p: next(script), out.append)
+    text = "".join(out)
+    assert "answer 1 to" in text and "answer 2 to" in text and "regenerating last message" in text and "answer 3 to" in text
+    assert "ignored" not in text and "</s>" not in text                 # the stop string cuts the stream
+    assert text.count("removing last message") == 2 and "No messages to remove." in text
+    assert "file not found: nowhere" in text and "usage: !!save <filename>" in text and text.endswith("exit...\n")
+    saved = json.load(open(save + ".json"))
+    assert [m[0] for m in saved["messages"]] == ["USER", "ASSISTANT", "USER", "ASSISTANT"]
+    assert saved["messages"][3][1].startswith("answer 3")               # the regenerated reply replaced the second one
+    # after !!reset only the last exchange is in the conversation, and prompts carry the history while it exists
+    assert [m[1] for m in session.conv.messages][0] == "after reset" and len(session.conv.messages) == 2
+    assert model.calls == 4
+
+
+def test_chat_without_history_and_cli_flags():
+    import argparse
+    from evaluation.chat import ChatSession, add_common_arguments
+    s = ChatSession("llama-3-8b", system_msg="be brief", keep_history=False)
+    p1 = s.open_turn("one"); s.close_turn("uno")
+    p2 = s.open_turn("two")
+    assert "one<|eot_id|>" not in p2 and "be brief" in p2 and p2.endswith("<|start_header_id|>assistant<|end_header_id|>\n\n")
+    args = add_common_arguments(argparse.ArgumentParser()).parse_args(["--model", "m", "--sam_path", "x.samd", "--max-steps", "7", "--no-history"])
+    assert (args.model, args.sam_path, args.max_steps, args.no_history, args.temperature, args.style) == ("m", "x.samd", 7, True, 0.0, "simple")
