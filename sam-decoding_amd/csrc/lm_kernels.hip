@@ -5,6 +5,7 @@
 // Reference semantics: HF LlamaDecoderLayer as driven by samd_sam_only/samd_model.py:134-138 with
 // SamdStaticCache.update (samd_sam_only/cache.py:103-115) writing K/V at [cache_length, +n).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "samd_common.h"
 
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
@@ -75,9 +76,9 @@ __global__ __launch_bounds__(256) void k_embed_rows(const int *__restrict__ toke
 // HF LlamaRMSNorm: out = w * (x * rsqrt(mean(x^2) + eps)).to(dtype); optional fused residual add:
 // x <- x + delta first (stored back), as LlamaDecoderLayer does between its two halves.
 template <typename T, bool ADD>
-__global__ __launch_bounds__(256) void k_rmsnorm(T *__restrict__ x, const T *__restrict__ delta, const T *__restrict__ w,
+__global__ __launch_bounds__(1024) void k_rmsnorm(T *__restrict__ x, const T *__restrict__ delta, const T *__restrict__ w,
                                                  T *__restrict__ out, int hidden, float eps, int n_part, long long part_stride) {
-    __shared__ float red[4];
+    __shared__ float red[16];
     constexpr int MAXV = 4;                                  // 8-element vectors kept in registers per thread: hidden <= 8192
     const size_t base = (size_t)blockIdx.x * hidden;
     const int stride = blockDim.x * 8;
@@ -199,12 +200,16 @@ int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_o
     if (n_partials < 0 || (n_partials > 0 && !d_delta)) { samd_set_error("samd_rmsnorm: partials without a source"); return SAMD_E_INVALID; }
     if (!d_x || !d_weight || !d_out || rows < 1 || hidden % 8 != 0 || hidden > 8192) { samd_set_error("samd_rmsnorm: invalid argument (hidden must be a multiple of 8, <= 8192)"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
+    // one 8-element vector per thread where the row allows it: a row's operands (x, weight, up to 8 fp32 partial sums) are
+    // then requested by twice as many waves at once; measured 3.42 -> 3.36 ms per forward at hidden 4096 (512 vs 256 threads)
+    int rms_threads = ((hidden / 8 + 63) / 64) * 64;
+    rms_threads = rms_threads < 64 ? 64 : (rms_threads > 1024 ? 1024 : rms_threads);
     if (dtype == SAMD_F16) {
-        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<_Float16, true>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)d_delta, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps, n_part, pst);
-        else hipLaunchKernelGGL((k_rmsnorm<_Float16, false>), dim3(rows), dim3(256), 0, st, (_Float16 *)d_x, (const _Float16 *)nullptr, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps, n_part, pst);
+        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<_Float16, true>), dim3(rows), dim3(rms_threads), 0, st, (_Float16 *)d_x, (const _Float16 *)d_delta, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps, n_part, pst);
+        else hipLaunchKernelGGL((k_rmsnorm<_Float16, false>), dim3(rows), dim3(rms_threads), 0, st, (_Float16 *)d_x, (const _Float16 *)nullptr, (const _Float16 *)d_weight, (_Float16 *)d_out, hidden, eps, n_part, pst);
     } else if (dtype == SAMD_BF16) {
-        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<__bf16, true>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)d_delta, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps, n_part, pst);
-        else hipLaunchKernelGGL((k_rmsnorm<__bf16, false>), dim3(rows), dim3(256), 0, st, (__bf16 *)d_x, (const __bf16 *)nullptr, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps, n_part, pst);
+        if (d_delta) hipLaunchKernelGGL((k_rmsnorm<__bf16, true>), dim3(rows), dim3(rms_threads), 0, st, (__bf16 *)d_x, (const __bf16 *)d_delta, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps, n_part, pst);
+        else hipLaunchKernelGGL((k_rmsnorm<__bf16, false>), dim3(rows), dim3(rms_threads), 0, st, (__bf16 *)d_x, (const __bf16 *)nullptr, (const __bf16 *)d_weight, (__bf16 *)d_out, hidden, eps, n_part, pst);
     } else { samd_set_error("samd_rmsnorm: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
