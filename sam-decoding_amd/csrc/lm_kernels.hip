@@ -28,15 +28,14 @@ template <typename T> __device__ __forceinline__ Vec8<T> ld8_or_partials(const T
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
-    // groups of 8 splits with every load issued before any add (index clamped so the loads are unconditional): one memory
-    // round trip per group instead of one per split
+    // groups of 8 splits with every load issued before any add: one memory round trip per group instead of one per split
     for (int s0 = 0; s0 < n_part; s0 += 8) {
         float4 a[8], b[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int ss = s0 + k < n_part ? s0 + k : s0;
-            a[k] = *reinterpret_cast<const float4 *>(part + (size_t)ss * part_stride + off);
-            b[k] = *reinterpret_cast<const float4 *>(part + (size_t)ss * part_stride + off + 4);
+            if (s0 + k >= n_part) continue;                 // wave-uniform: splits that do not exist cost no request
+            a[k] = *reinterpret_cast<const float4 *>(part + (size_t)(s0 + k) * part_stride + off);
+            b[k] = *reinterpret_cast<const float4 *>(part + (size_t)(s0 + k) * part_stride + off + 4);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -140,8 +139,8 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
             float pa[8], pb[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int ss = s0 + k < n_part ? s0 + k : s0;
-                pa[k] = part[(size_t)ss * part_stride + soff + j]; pb[k] = part[(size_t)ss * part_stride + soff + j + half];
+                if (s0 + k >= n_part) continue;
+                pa[k] = part[(size_t)(s0 + k) * part_stride + soff + j]; pb[k] = part[(size_t)(s0 + k) * part_stride + soff + j + half];
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) if (s0 + k < n_part) { a += pa[k]; b += pb[k]; }
