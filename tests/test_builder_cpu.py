@@ -135,3 +135,30 @@ def test_load_rejects_damaged_image(tmp_path):
     p = tmp_path / "short.samd"; p.write_bytes(bytes(raw[:-16]))
     with pytest.raises(samd_hip.SamdError, match="truncated"):
         samd_hip.StaticAutomaton.load(str(p))
+
+
+def test_gemm_kernel_isa_keeps_the_hand_counted_waits_valid(tmp_path):
+    """k_gemm_skinny waits with hand-counted s_waitcnt vmcnt(N) (two weight chunks in flight).  That count is only right
+    while the compiler adds no vector-memory instruction of its own between the hand-issued loads: no scratch spills, and
+    no wait other than vmcnt(0) / vmcnt(8 + XV) inside the kernels.  Checked on the generated gfx950 assembly."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "sam-decoding_amd", "csrc", "gemm_kernels.hip")
+    out = str(tmp_path / "gemm.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+                           "-I" + os.path.join(ROOT, "include"), "-o", out, src], stderr=subprocess.DEVNULL)
+    asm = open(out).read()
+    assert "scratch_" not in asm, "a register spill would add vector-memory instructions the wait counts do not know about"
+    kernels = re.findall(r"^(_Z13k_gemm_skinny\w+):[^\n]*\n(.*?)s_endpgm", asm, flags=re.S | re.M)
+    assert len(kernels) >= 12
+    for name, body in kernels:
+        rt = int(re.search(r"Li(\d)ELi\d", name).group(1))
+        allowed = {0, 8 + rt}                                   # XV = rows * 32 / 512 = RT
+        waits = {int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)}
+        assert waits <= allowed, (name, waits)
+        assert "global_load_lds_dwordx4" in body and "ds_read_b128" in body
+    for m in re.finditer(r"\.name:\s+_Z13k_gemm_skinny.*?\.vgpr_spill_count:\s+(\d+)", asm, flags=re.S):
+        assert int(m.group(1)) == 0
