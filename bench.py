@@ -272,7 +272,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--corpus-tokens", type=int, default=1 << 22)
     ap.add_argument("--acceptance", choices=["scripted", "natural"], default="scripted")
-    ap.add_argument("--variant", choices=["sam_only", "token_recycle"], default="sam_only",
+    ap.add_argument("--variant", choices=["sam_only", "token_recycle", "eagle2", "eagle"], default="sam_only",
                     help="sam_only = BASELINE configs[1] (the headline); token_recycle = configs[2] (samd[Token Recycle], n_predicts 40, "
                          "len_threshold 5, len_bias 5): informational, the table learns from the random-init model's logits")
     ap.add_argument("--model", choices=["vicuna-7b", "llama3-8b"], default="vicuna-7b",
@@ -326,8 +326,24 @@ def main():
     else:
         import samd as S
         auto_s = samd_hip.StaticAutomaton.build_flat(flat, off, EOS, samd_hip.KIND_ENDPOS).upload()
-        samd_cfg = S.SamdConfig(n_predicts=40, len_threshold=5, len_bias=5, tree_method="token_recycle")
-        draft = S.DraftModel(samd_cfg, sam_static=S.sam.StaticSAM._from_automaton(auto_s), lm=runner, device="cuda")
+        if args.variant == "token_recycle":
+            samd_cfg = S.SamdConfig(n_predicts=40, len_threshold=5, len_bias=5, tree_method="token_recycle")
+            tree_model = None
+        else:
+            # samd[EAGLE2] / samd[EAGLE] (configs[3] shape of the loop): a random-init draft head of the base model's width -- its
+            # drafts are as good as noise, so this measures the COST of the plugin path (head forwards between graph replays)
+            from samd.tree_model.eagle import Eagle, EagleHead, StaticDraftTree
+            from samd.tree_model.eagle2 import Eagle2, Eagle2Head
+            tree_cfg = dict(hidden_size=mcfg["hidden_size"], intermediate_size=mcfg["intermediate_size"], num_attention_heads=mcfg["num_attention_heads"],
+                            num_key_value_heads=mcfg.get("num_key_value_heads", mcfg["num_attention_heads"]), vocab_size=mcfg["vocab_size"],
+                            rms_norm_eps=mcfg.get("rms_norm_eps", 1e-6), rope_theta=mcfg.get("rope_theta", 10000.0), bias=True)
+            samd_cfg = S.SamdConfig(n_predicts=40, len_threshold=5, len_bias=5, tree_method=args.variant, tree_config=tree_cfg)
+            head = (Eagle2Head if args.variant == "eagle2" else EagleHead)(tree_cfg, dtype=dtype, device="cuda")
+            head.random_init(seed=3, std=0.02)
+            if args.variant == "eagle":
+                head.set_tree(StaticDraftTree(samd_cfg.tree))
+            tree_model = (Eagle2 if args.variant == "eagle2" else Eagle)(samd_cfg, runner, dtype, "cuda", head=head)
+        draft = S.DraftModel(samd_cfg, sam_static=S.sam.StaticSAM._from_automaton(auto_s), tree_model=tree_model, lm=runner, device="cuda")
         model = S.SamdModel(samd_cfg, lm, draft, EOS, dtype, "cuda")
     gcfg = SO.SamdGenerationConfig(max_new_tokens=512, max_cache_len=max_len)
     model.set_cache(gcfg)

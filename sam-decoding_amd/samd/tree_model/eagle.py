@@ -110,6 +110,16 @@ class EagleHead(Eagle2Head):
         self._levels = [dict(select=torch.tensor(l["select"], dtype=torch.long, device=dev),
                              repeat=torch.tensor(l["repeat"], dtype=torch.long, device=dev),
                              mask=torch.tensor(l["mask"], dtype=torch.float32, device=dev)) for l in tree.levels]
+        # ancestor-or-self matrices over the nodes-with-children of levels 0..i (for the stateless device forward)
+        self._anc, seen = [], 0
+        for l in self._levels:
+            n_l, width = l["mask"].shape
+            full = torch.zeros((width, width), device=dev)
+            if self._anc:
+                full[:seen, :seen] = self._anc[-1]
+            full[seen:width] = l["mask"]
+            self._anc.append(full)
+            seen = width
 
     @torch.no_grad()
     def topk_generate(self, hidden_states, input_ids, head_weight):
@@ -131,6 +141,33 @@ class EagleHead(Eagle2Head):
                                       tree_mask=lvl["mask"])
             pos_len += 1
             logits = F.linear(prev, head_weight)
+        rows.append(torch.topk(logits, k, dim=-1).indices)
+        return torch.cat(rows, dim=0)
+
+
+    @torch.no_grad()
+    def topk_generate_device(self, dh, hidden_states, input_ids, head_weight=None):
+        """topk_generate with every head forward on the library's kernels (device_head.DeviceHead); same selections.  A
+        level's forward carries the nodes-with-children of all levels so far (stateless levels, see device_head.py)."""
+        prev, logits = dh.extend(hidden_states, input_ids[1:])
+        return dh.expand("eagle", lambda h, lg: (self._expand_device(dh, h, lg),), prev, logits)[0]
+
+    def _expand_device(self, dh, prev, logits):
+        """the static levels on device tensors only (fixed shapes, no host round trip): capturable"""
+        k, dev = self.tree.top_k, prev.device
+        rows = []
+        x_rows = torch.empty((0, self.hidden), dtype=prev.dtype, device=dev)
+        depth = torch.empty(0, dtype=torch.int32, device=dev)
+        for i, lvl in enumerate(self._levels):
+            top = torch.topk(logits, k, dim=-1).indices
+            rows.append(top)
+            ids = top.reshape(-1)[lvl["select"]]
+            hidden_in = torch.repeat_interleave(prev[:lvl["repeat"].numel()], lvl["repeat"], dim=0, output_size=int(ids.numel()))
+            n0 = x_rows.shape[0]
+            x_rows = torch.cat((x_rows, dh._x(ids, hidden_in)), dim=0)
+            depth = torch.cat((depth, torch.full((ids.numel(),), i, dtype=torch.int32, device=dev)))
+            out_all, logits_all = dh.tree(x_rows, depth, self._anc[i])
+            prev, logits = out_all[n0:].clone(), logits_all[n0:].clone()
         rows.append(torch.topk(logits, k, dim=-1).indices)
         return torch.cat(rows, dim=0)
 
@@ -161,13 +198,17 @@ class Eagle(Eagle2):
         self._parents = torch.tensor(self.tree.parents, dtype=torch.long, device=device)
         self._flat = torch.tensor(self.tree.flat_index, dtype=torch.long, device=device)
         self.accept_tokens = self.accept_hidden_states = None
+        self.device_head = self._make_device_head(lm)
 
     def gen_draft_device(self, start_token: torch.Tensor):
         """-> (tokens, parents) on the device; consumes the accumulated state (eagle.py:55-69)."""
         ids = torch.cat((self.accept_tokens.to(torch.long), start_token.reshape(1).to(torch.long)), dim=-1)
         hs = self.accept_hidden_states.to(self.model.dtype)
         self.accept_tokens = self.accept_hidden_states = None
-        rows = self.model.topk_generate(hs, ids, self.lm_head.to(self.model.dtype))
+        if self.device_head is not None:
+            rows = self.model.topk_generate_device(self.device_head, hs, ids)
+        else:
+            rows = self.model.topk_generate(hs, ids, self.lm_head.to(self.model.dtype))
         flat = torch.cat((start_token.reshape(1).to(torch.long), rows.reshape(-1)))
         return flat[self._flat], self._parents
 

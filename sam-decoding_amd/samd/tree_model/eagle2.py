@@ -174,6 +174,63 @@ class Eagle2Head(torch.nn.Module):
         return draft_tokens, parents
 
 
+    @torch.no_grad()
+    def topk_generate_device(self, dh, hidden_states, input_ids, head_weight=None):
+        """topk_generate with every head forward on the library's kernels (device_head.DeviceHead `dh`); same tree logic.
+        Each level's forward carries all tree nodes chosen so far (stateless levels, see device_head.py)."""
+        last_hidden, last_logits = dh.extend(hidden_states, input_ids[1:])
+        return dh.expand("eagle2", lambda h, lg, tok: self._expand_device(dh, h, lg, tok), last_hidden, last_logits, input_ids[-1:].clone())
+
+    def _expand_device(self, dh, last_hidden, last_logits, sample_token):
+        """the level loop of topk_generate on device tensors only (fixed shapes, no host round trip): capturable"""
+        top_k, dev = self.top_k, last_hidden.device
+        logp = torch.log_softmax(last_logits.float(), dim=-1)
+        top = torch.topk(logp, top_k, dim=-1)
+        scores = top.values[0]
+        scores_list, parents_list, tokens_list = [scores[None]], [torch.zeros(1, dtype=torch.long, device=dev)], [top.indices]
+        ids = top.indices[0]
+        in_hidden = last_hidden.repeat(top_k, 1)
+        level_mask = torch.eye(top_k, device=dev)
+        cs_index = torch.arange(top_k, device=dev)
+        x_rows = torch.empty((0, self.hidden), dtype=last_hidden.dtype, device=dev)
+        anc = torch.zeros((0, 0), device=dev)
+        depth = torch.empty(0, dtype=torch.int32, device=dev)
+        for i in range(self.depth):
+            n0 = x_rows.shape[0]
+            x_rows = torch.cat((x_rows, dh._x(ids, in_hidden)), dim=0)
+            grown = torch.zeros((n0 + top_k, n0 + top_k), device=dev)
+            grown[:n0, :n0] = anc
+            grown[n0:] = level_mask
+            anc = grown
+            depth = torch.cat((depth, torch.full((top_k,), i, dtype=torch.int32, device=dev)))
+            out_all, logits_all = dh.tree(x_rows, depth, anc)
+            out, logits = out_all[n0:], logits_all[n0:]
+            bias = 1 + top_k ** 2 * max(0, i - 1) + (top_k if i > 0 else 0)
+            parents_list.append(cs_index + bias)
+            logp = torch.log_softmax(logits.float(), dim=-1)
+            top = torch.topk(logp, top_k, dim=-1)
+            cu = top.values + scores[:, None]
+            best = torch.topk(cu.view(-1), top_k, dim=-1)
+            cs_index, scores = best.indices, best.values
+            rows = cs_index // top_k
+            in_hidden = out[rows]
+            ids = top.indices.reshape(-1)[cs_index]
+            tokens_list.append(top.indices)
+            scores_list.append(cu)
+            level_mask = torch.cat((level_mask[rows], torch.eye(top_k, device=dev)), dim=1)
+        all_scores = torch.cat(scores_list, dim=0).view(-1)
+        all_tokens = torch.cat(tokens_list, dim=0).view(-1)
+        keep = torch.sort(torch.topk(all_scores, self.total_tokens, dim=-1).indices).values
+        draft_tokens = torch.cat((sample_token, all_tokens[keep]), dim=0)
+        draft_parents = torch.cat(parents_list, dim=0)[keep // top_k].long()
+        mask_index = torch.searchsorted(keep, draft_parents - 1, right=False)
+        mask_index = torch.where(draft_parents == 0, torch.full_like(mask_index, -1), mask_index)
+        parents = torch.cat((torch.full((1,), -1, dtype=torch.long, device=dev), mask_index + 1), dim=0)
+        idx = torch.arange(parents.numel(), device=dev)
+        parents = torch.where((parents >= idx) & (idx > 0), torch.zeros_like(parents), parents)
+        return draft_tokens, parents
+
+
 class Eagle2(TreeModel):
     """TreeModel plugin over Eagle2Head (reference wrapper: eagle2.py:12-70)."""
     fused = False
@@ -192,6 +249,18 @@ class Eagle2(TreeModel):
         self.model = head
         self.accept_tokens: Optional[torch.Tensor] = None
         self.accept_hidden_states: Optional[torch.Tensor] = None
+        self.device_head = self._make_device_head(lm)
+
+    def _make_device_head(self, lm):
+        """the head on the library's kernels when the base model runs on them too (a samd_hip LlamaRunner, possibly wrapped);
+        SAMD_EAGLE_DEVICE_HEAD=0 keeps the PyTorch forward"""
+        runner = lm if hasattr(lm, "forward_rows") else getattr(lm, "runner", None)
+        if runner is None or not hasattr(runner, "forward_rows") or os.environ.get("SAMD_EAGLE_DEVICE_HEAD", "1") == "0":
+            return None
+        if self.model.head_dim != 128 or str(self.model.device).startswith("cpu"):
+            return None
+        from .device_head import DeviceHead
+        return DeviceHead(self.model, runner)
 
     @staticmethod
     def _find_lm_head(lm):
@@ -206,6 +275,8 @@ class Eagle2(TreeModel):
     def reset(self):
         """eagle2.py:34-35"""
         self.model.stable_kv = None
+        if self.device_head is not None:
+            self.device_head.reset()
 
     def update(self, tokens: torch.Tensor = None, last_hidden_states: torch.Tensor = None, **kwargs):
         """eagle2.py:37-50: accumulate the accepted tokens and their base-model hidden states until the next draft."""
@@ -219,6 +290,8 @@ class Eagle2(TreeModel):
         ids = torch.cat((self.accept_tokens.to(torch.long), start_token.reshape(1).to(torch.long)), dim=-1)
         hs = self.accept_hidden_states.to(self.model.dtype)
         self.accept_tokens = self.accept_hidden_states = None
+        if self.device_head is not None:
+            return self.model.topk_generate_device(self.device_head, hs, ids)
         return self.model.topk_generate(hs, ids, self.lm_head.to(self.model.dtype))
 
     def gen_draft(self, start_token: int):

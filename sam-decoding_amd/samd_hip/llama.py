@@ -76,7 +76,7 @@ class LlamaRunner:
 
     BUCKETS = (1, 8, 16, 32, 64)
 
-    def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None, native_gemm=True):
+    def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None, native_gemm=True, packed_lm_head=None):
         require_gpu()
         self.shape, self.dtype, self.device = shape, dtype, torch.device(device)
         self.dt = torch_dtype_code(dtype)
@@ -104,7 +104,8 @@ class LlamaRunner:
                 return None
             gate, up = t[:s.inter].view(s.inter // 64, 64, -1), t[s.inter:].view(s.inter // 64, 64, -1)
             return pack(torch.stack([gate, up], dim=1).reshape(2 * s.inter, -1).contiguous())
-        self.wp = dict(lm_head=pack(weights["lm_head"]),
+        # packed_lm_head: a draft head shares the base model's lm_head, packed copy included
+        self.wp = dict(lm_head=packed_lm_head if packed_lm_head is not None else pack(weights["lm_head"]),
                        layers=[dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")}, wgu=pack_gate_up(l["wgu"])) for l in weights["layers"]])
         self.native_gemm = self.wp["lm_head"] is not None or any(v is not None for l in self.wp["layers"] for v in l.values())
         if not self.native_gemm:
@@ -214,9 +215,11 @@ class LlamaRunner:
                 return b
         raise SamdError(f"draft of {n} nodes exceeds {MAX_DRAFT}")
 
-    def forward_rows(self, R, d_tokens, d_relpos, d_mask, d_L, d_n):
+    def forward_rows(self, R, d_tokens, d_relpos, d_mask, d_L, d_n, x_in=None):
         """one forward over R rows; all of d_* are device pointers (ints / tensors).  Returns the buffers of bucket R
-        (logits [R, V], argmax int32[64] with rows < n valid)."""
+        (logits [R, V], argmax int32[64] with rows < n valid).  x_in [R, hidden]: the rows' input states instead of the
+        token embedding (EAGLE draft heads feed fc([embed ; hidden])).  With `self.draft_head` the decoder is an EAGLE head:
+        layer 0 has no input norm and lm_head reads the residual stream itself (b["x"] = the head's output states)."""
         L, s, b, dt, st = lib(), self.shape, self._buffers(R), self.dt, current_stream()
         RP, part = b["rows_pad"], b["part"]
 
@@ -232,12 +235,20 @@ class LlamaRunner:
             check(L.samd_gemm_skinny(_ptr(a), _ptr(wp), RP, n, k, sp, _ptr(part), _ptr(out), dt, st))
             return (out, 0, 0) if sp == 1 else (part, sp, RP * n)
 
-        check(L.samd_embed_rows(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(b["x"]), R, s.hidden, s.vocab, dt, st))
+        if x_in is None:
+            check(L.samd_embed_rows(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(b["x"]), R, s.hidden, s.vocab, dt, st))
+        else:
+            rows_in = min(R, x_in.shape[0])
+            b["x"][:rows_in].copy_(x_in[:rows_in])                # rows past d_n are never consumed
+        head = getattr(self, "draft_head", False)
         delta, dn, dstride = None, 0, 0
         packed = self.wp["layers"] if self.wp else [{}] * len(self.w["layers"])
         for li, w in enumerate(self.w["layers"]):
             wp = packed[li]
-            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
+            if head and li == 0:
+                b["h"][:R].copy_(b["x"][:R])                      # eagle2_model.py:516-519: no input layer-norm in the head's layer
+            else:
+                check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
             src, n_p, stride = gemm(b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
             check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
                                        _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
@@ -254,7 +265,8 @@ class LlamaRunner:
                 check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
             delta, dn, dstride = gemm(b["act"], w["wdown"], wp.get("wdown"), b["d"])
         check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
-        gemm(b["h"], self.w["lm_head"], self.wp["lm_head"] if self.wp else None, b["logits"])
+        # (for a draft head the call above only folds the last projection into the residual stream; its norm output is unused)
+        gemm(b["x"] if head else b["h"], self.w["lm_head"], self.wp["lm_head"] if self.wp else None, b["logits"])
         check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
         return b
 

@@ -256,6 +256,78 @@ def test_eagle_static_tree_plugin_is_lossless_and_paths_agree():
         assert list(d.parent[:26]) == StaticDraftTree(cfg.tree).parents
 
 
+def test_draft_head_on_device_matches_the_pytorch_head():
+    """device_head.DeviceHead (the EAGLE head on the library's kernels, stateless tree levels) against Eagle2Head.forward:
+    accepted-token extension in two calls, then two tree levels; output states and logits agree to fp16 tolerance, and
+    both plugins (EAGLE-2 dynamic tree, EAGLE v1 static tree) stay lossless when they draft through it."""
+    import samd as S
+    import samd_sam_only as SO
+    from samd.tree_model.device_head import DeviceHead
+    from samd.tree_model.eagle import Eagle, EagleHead, StaticDraftTree
+    from samd.tree_model.eagle2 import Eagle2, Eagle2Head
+    lm = tiny_llama(2, seed=8)
+    runner = LlamaRunner.from_hf(lm, max_cache_len=512, dtype=torch.float16)
+    tree_cfg = dict(hidden_size=256, intermediate_size=512, num_attention_heads=2, num_key_value_heads=2, vocab_size=512,
+                    rms_norm_eps=1e-5, bias=True)
+    head = Eagle2Head(tree_cfg, dtype=torch.float16, device="cuda")
+    head.random_init(seed=3, std=0.08)
+    dh = DeviceHead(head, runner)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    lm_head = runner.w["lm_head"]
+    close = lambda a, b, tol: (a.float() - b.float()).abs().max().item() <= tol * max(1.0, b.float().abs().max().item())
+    past = None
+    for T in (70, 3):                                            # > 64: the extension runs in two chunks
+        hs = torch.randn((T, 256), generator=g, device="cuda").half()
+        ids = torch.randint(3, 512, (T,), generator=g, device="cuda")
+        out, past = head.forward(hs, ids, past=past)
+        last, logits = dh.extend(hs, ids)
+        assert close(last, out[-1:], 2e-2) and close(logits, torch.nn.functional.linear(out[-1:], lm_head), 2e-2)
+    # two tree levels of 8 nodes: level 1 nodes hang off nodes 2 and 5 of level 0
+    L = past[0].shape[1]
+    ids0 = torch.randint(3, 512, (8,), generator=g, device="cuda")
+    h0 = torch.randn((8, 256), generator=g, device="cuda").half()
+    eye = torch.eye(8, device="cuda")
+    out0, past1 = head.forward(h0, ids0, past=past, position_ids=torch.full((8,), L, device="cuda"), tree_mask=eye)
+    x0 = dh._x(ids0, h0)
+    d_out0, d_log0 = dh.tree(x0, torch.zeros(8, dtype=torch.int32, device="cuda"), eye)
+    assert close(d_out0, out0, 2e-2)
+    par = torch.tensor([2, 2, 2, 5, 5, 5, 5, 2], device="cuda")
+    ids1 = torch.randint(3, 512, (8,), generator=g, device="cuda")
+    m1 = torch.cat((eye[par], eye), dim=1)
+    out1, _ = head.forward(out0[par], ids1, past=past1, position_ids=torch.full((8,), L + 1, device="cuda"), tree_mask=m1)
+    anc = torch.zeros((16, 16), device="cuda"); anc[:8, :8] = eye; anc[8:] = m1
+    x1 = torch.cat((x0, dh._x(ids1, d_out0[par].clone())), dim=0)
+    d_out1, d_log1 = dh.tree(x1, torch.tensor([0] * 8 + [1] * 8, dtype=torch.int32, device="cuda"), anc)
+    assert close(d_out1[8:], out1, 3e-2) and close(d_log1[8:], torch.nn.functional.linear(out1, lm_head), 3e-2)
+    assert dh.length == 73 and int(dh.L.item()) == 73             # tree levels leave the head's cache length alone
+
+    # end to end through both plugins, base model and head on the same kernels
+    rng = np.random.default_rng(9)
+    prompt = rng.integers(3, 512, 70).tolist()
+    prompt[40:52] = prompt[10:22]
+    ids = torch.tensor([prompt], device="cuda")
+    gcfg = SO.SamdGenerationConfig(max_new_tokens=40, max_cache_len=512)
+    ar_cfg = SO.SamdConfig(max_predicts=1)
+    ar = SO.SamdModel(ar_cfg, runner, SO.DraftModel(ar_cfg, device="cuda"), eos_token_id=2, dtype=torch.float16, device="cuda")
+    seq_ar = ar.generate(ids, generation_config=gcfg).output_ids[0]
+    for method in ("eagle2", "eagle"):
+        cfg = S.SamdConfig(n_predicts=12, len_threshold=3, len_bias=0, tree_method=method, tree_config=tree_cfg)
+        if method == "eagle2":
+            tm = Eagle2(cfg, runner, torch.float16, "cuda", head=head)
+        else:
+            h1 = EagleHead(tree_cfg, dtype=torch.float16, device="cuda")
+            h1.random_init(seed=3, std=0.08)
+            h1.set_tree(StaticDraftTree(cfg.tree))
+            tm = Eagle(cfg, runner, torch.float16, "cuda", head=h1)
+        assert tm.device_head is not None
+        model = S.SamdModel(cfg, runner, S.DraftModel(cfg, tree_model=tm, lm=runner, device="cuda"), eos_token_id=2, dtype=torch.float16, device="cuda")
+        seq = model.generate(ids, generation_config=gcfg).output_ids[0]
+        assert model.lookup_stats["tree"][0] > 0
+        m = min(len(seq), len(seq_ar))
+        diff = [i for i in range(m) if seq[i] != seq_ar[i]]
+        assert not diff or (diff[0] > len(prompt) + 4 and _near_tie(lm, seq[:diff[0]], seq[diff[0]], seq_ar[diff[0]])), (method, diff[:3])
+
+
 def test_bf16_gqa_runner_matches_hf():
     """Llama-3-style numerics path: bf16, grouped-query attention (2 query heads per KV head), llama3 rope scaling.
     Tolerance: bf16 has 8 mantissa bits; logits of this 2-layer model agree with fp32 HF to 0.15 absolute."""
