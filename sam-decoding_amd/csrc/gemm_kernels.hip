@@ -47,7 +47,7 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // interleaved in groups of 64 (tile t = gate columns 64t.. | up columns 64t..), and the epilogue writes
 // silu(gate) * up [rows][N/2] -- LlamaMLP's activation without a launch, a 2N-wide intermediate or its re-read.
 template <typename TT, int RT, int EPI>
-__global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
+__global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 2 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                         float *__restrict__ partial, typename TT::elem *__restrict__ out,
                                                         int K, int N, int n_chunks, int n_splits) {
     typedef typename TT::elem E;
@@ -116,13 +116,24 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, GEMM_WAVES / 2) void k_gemm_skinny
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             const uint32_t u0 = (uint32_t)((8 * b + 2 * g) ^ n) * 16, u1 = (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;   // rows 16 mt + n: (row & 15) == n
+            // all row tiles of this k block in one LDS round trip (row tile mt sits 16 rows = 8 KiB further: immediate offsets)
+            const uint32_t a0 = xbase + u0, a1 = xbase + u1;
+            u32x4 r[RT][2];
+            if constexpr (RT == 1)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]) : "v"(a0), "v"(a1));
+            else if constexpr (RT == 2)
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:8192\n\t"
+                             "s_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]) : "v"(a0), "v"(a1));
+            else
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %9 offset:8192\n\t"
+                             "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %9 offset:16384\n\tds_read_b128 %6, %8 offset:24576\n\t"
+                             "ds_read_b128 %7, %9 offset:24576\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1])
+                             : "v"(a0), "v"(a1));
 #pragma unroll
             for (int mt = 0; mt < RT; mt++) {
-                u32x4 r0, r1;
-                const uint32_t row = xbase + (uint32_t)mt * (16 * GEMM_KC * 2);
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(row + u0), "v"(row + u1));
-                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r0), __builtin_bit_cast(V8, cur[b][0]), acc[mt]);
-                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r1), __builtin_bit_cast(V8, cur[b][1]), acc[mt]);
+                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][0]), __builtin_bit_cast(V8, cur[b][0]), acc[mt]);
+                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][1]), __builtin_bit_cast(V8, cur[b][1]), acc[mt]);
             }
         }
         if (c + 2 < c1) { load_w(cur, c + 2); stage_x(c + 2, buf == 0 ? 2 : buf - 1); }
