@@ -281,8 +281,8 @@ class LlamaRunner:
         N = ids.numel()
         if N < 1 or N > self.max_len:
             raise SamdError(f"prompt of {N} tokens does not fit max_cache_len {self.max_len}")
-        if on_chunk is None and N >= 2 * MAX_DRAFT and os.environ.get("SAMD_PREFILL", "wide") != "chunked":
-            return self._prefill_wide(session, ids)
+        if N >= 2 * MAX_DRAFT and os.environ.get("SAMD_PREFILL", "wide") != "chunked":
+            return self._prefill_wide(session, ids, on_chunk)
         v = session.device_views()
         b = None
         for c0 in range(0, N, MAX_DRAFT):
@@ -298,10 +298,11 @@ class LlamaRunner:
         session.set_start_token(b["argmax"][(N - 1) % MAX_DRAFT:])
         return b["logits"][(N - 1) % MAX_DRAFT]
 
-    def _prefill_wide(self, session: Session, ids):
+    def _prefill_wide(self, session: Session, ids, on_chunk=None):
         """the whole prompt in one pass: compute-bound, so the GEMMs go to the library (N x K x N_out at full MFMA rate) and
-        the causal attention to PyTorch's fused SDPA; norm / RoPE + K/V write / SiLU*up / arg-max stay our kernels.  Used
-        when no per-chunk consumer (Token Recycle, EAGLE-2) needs the prompt's logits or hidden states."""
+        the causal attention to PyTorch's fused SDPA; norm / RoPE + K/V write / SiLU*up / arg-max stay our kernels.  A
+        per-chunk consumer (Token Recycle: the prompt's logits, EAGLE: its last hidden states) gets them afterwards in
+        64-row slices of one [N, V] lm_head product."""
         L, s, dt, st, N = lib(), self.shape, self.dt, current_stream(), ids.numel()
         dev, ty = self.device, self.dtype
         z = lambda *sz: torch.empty(sz, dtype=ty, device=dev)
@@ -330,7 +331,14 @@ class LlamaRunner:
             delta = d
         check(L.samd_rmsnorm(_ptr(x), _ptr(delta), _ptr(self.w["norm"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
         b = self._buffers(1)
-        torch.mm(h[N - 1:N], self.w["lm_head"].t(), out=b["logits"][:1])
+        if on_chunk is None:
+            torch.mm(h[N - 1:N], self.w["lm_head"].t(), out=b["logits"][:1])
+        else:
+            logits = torch.mm(h, self.w["lm_head"].t())
+            for c0 in range(0, N, MAX_DRAFT):
+                n = min(MAX_DRAFT, N - c0)
+                on_chunk(ids[c0:c0 + n], logits[c0:c0 + n], n, h[c0:c0 + n])
+            b["logits"][:1].copy_(logits[N - 1:N])
         check(L.samd_argmax_rows(_ptr(b["logits"]), dt, 1, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
         session.set_cache_length(N)
         session.set_start_token(b["argmax"])

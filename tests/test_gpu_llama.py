@@ -397,8 +397,21 @@ def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
         last = runner.prefill(sess, ids)
         torch.cuda.synchronize()
         outs[mode] = (last.float().clone(), runner.kv[:, :, :, :200].float().clone(), sess.get_cache_length())
+        # the same prompt with a per-chunk consumer (what Token Recycle / EAGLE see): all logits and last hidden states
+        seen = []
+        sess2 = samd_hip.Session(1024)
+        runner.prefill(sess2, ids, lambda t, lg, n, h: seen.append((t[:n].clone(), lg[:n].float().clone(), h[:n].float().clone())))
+        torch.cuda.synchronize()
+        outs[mode] += (torch.cat([x[0] for x in seen]), torch.cat([x[1] for x in seen]), torch.cat([x[2] for x in seen]))
     with torch.no_grad():
         ref = lm(input_ids=ids).logits[0, -1]
     assert outs["wide"][2] == outs["chunked"][2] == 200
     assert (outs["wide"][0] - ref).abs().max().item() < TOL and (outs["chunked"][0] - ref).abs().max().item() < TOL
     assert (outs["wide"][1] - outs["chunked"][1]).abs().max().item() < 2e-2          # same K/V rows up to fp16 GEMM rounding
+    with torch.no_grad():
+        full = lm(input_ids=ids, output_hidden_states=True)
+    for mode in ("wide", "chunked"):
+        toks, logits, hidden = outs[mode][3:]
+        assert toks.tolist() == prompt and logits.shape == (200, 512) and hidden.shape == (200, 256)
+        assert (logits - full.logits[0]).abs().max().item() < TOL
+    assert (outs["wide"][5] - outs["chunked"][5]).abs().max().item() < 3e-2          # final-norm hidden states of every prompt token
