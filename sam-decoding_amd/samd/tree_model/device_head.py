@@ -44,6 +44,16 @@ class DeviceHead:
                                   packed_lm_head=base_runner.wp["lm_head"] if base_runner.wp else None)
         self.runner.draft_head = True
         self.fc_w, self.fc_b = c(head.fc_w), (c(head.fc_b) if head.fc_b is not None else None)
+        # fc([embed ; hidden]) on the streaming GEMM too (K = 2 * hidden): packed weight, zero-padded operand rows, fp32 partials
+        import samd_hip
+        self._lib, self._dt = samd_hip.lib(), base_runner.dt
+        n_fc, k_fc = self.fc_w.shape
+        self.fc_packed = None
+        if n_fc % 128 == 0 and k_fc % 256 == 0 and k_fc >= 512:
+            self.fc_packed = torch.empty_like(self.fc_w)
+            samd_hip.check(self._lib.samd_gemm_pack_weights(samd_hip._ptr(self.fc_w), samd_hip._ptr(self.fc_packed), n_fc, k_fc, samd_hip.current_stream()))
+            self.fc_in = torch.zeros((MAX_ROWS, k_fc), dtype=dt, device=dev)
+            self.fc_part = torch.zeros((8, MAX_ROWS, n_fc), dtype=torch.float32, device=dev)
         self.embed = weights["embed"]
         self.L = torch.zeros(1, dtype=torch.int32, device=dev)
         self.n = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -63,7 +73,22 @@ class DeviceHead:
         self.L.zero_()
 
     def _x(self, ids: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
-        return F.linear(torch.cat((self.embed[ids], hidden.to(self.embed.dtype)), dim=-1), self.fc_w, self.fc_b)
+        """fc([embed(ids) ; hidden]) -> [n, H] (eagle2_model.py:739-741)"""
+        n = ids.numel()
+        if self.fc_packed is None or n > MAX_ROWS:
+            return F.linear(torch.cat((self.embed[ids], hidden.to(self.embed.dtype)), dim=-1), self.fc_w, self.fc_b)
+        import samd_hip
+        H = self.embed.shape[1]
+        rp = 16 if n <= 16 else (32 if n <= 32 else 64)
+        self.fc_in[:n, :H] = self.embed[ids]
+        self.fc_in[:n, H:] = hidden.to(self.embed.dtype)
+        n_fc, k_fc = self.fc_w.shape
+        sp = max(2, min(8, self._lib.samd_gemm_splits(n_fc, k_fc, rp), k_fc // 256))
+        part = self.fc_part.view(-1)[:sp * rp * n_fc].view(sp, rp, n_fc)            # the kernel's [splits][rows_pad][N] layout
+        samd_hip.check(self._lib.samd_gemm_skinny(samd_hip._ptr(self.fc_in), samd_hip._ptr(self.fc_packed), rp, n_fc, k_fc, sp, samd_hip._ptr(part),
+                                                  None, self._dt, samd_hip.current_stream()))
+        x = part[:, :n].sum(0)
+        return (x + self.fc_b.float() if self.fc_b is not None else x).to(self.embed.dtype)
 
     def _forward(self, x: torch.Tensor, relpos: torch.Tensor, mask: torch.Tensor):
         """one head forward over n <= 64 rows.  Inputs are staged into fixed buffers and the launch sequence of the row
