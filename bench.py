@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     args = ap.parse_args()
 
+    import samd_hip                                      # first: sets the spin-wait device flag before a HIP context exists
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))

@@ -11,6 +11,7 @@ The sequence is captured once per row bucket R into a hipGraph; the host replays
 (accepted tokens, next draft size) to apply the reference's stopping rules.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
