@@ -373,6 +373,12 @@ def main():
         next(it)
     for v in model.lookup_stats.values():
         v[0] = v[1] = 0
+    # setup, not a timed step: the hipGraph of every row bucket exists before the timed region (a bucket first met inside it
+    # would add its one-off capture, ~20 ms, to a 0.7 s measurement; capture records the launches without executing them)
+    if model.engine.use_graphs:
+        for R in runner.BUCKETS:
+            if R not in model.engine._graphs and (args.variant == "sam_only" or R == runner.BUCKETS[-1]):
+                model.engine._capture(R)
 
     def fence():
         torch.cuda.synchronize()

@@ -59,6 +59,10 @@ typedef struct samd_recycle samd_recycle_t; /* Token-Recycle [V,8] successor tab
 
 const char *samd_last_error(void);
 int samd_device_count(void);
+/* make host waits on this process's device spin instead of yield (hipDeviceScheduleSpin): the decode loop waits for one
+ * report per step, and the wake-up latency is ~25 us of a 3.4 ms step.  Only effective before the process creates its HIP
+ * context; device < 0 = the current device.  No reference counterpart. */
+int samd_host_wait_spin(int32_t device);
 /* library + device facts: out[0]=ABI version, out[1]=CU count, out[2]=wavefront size, out[3]=LDS bytes/CU */
 int samd_device_info(int64_t out[4]);
 

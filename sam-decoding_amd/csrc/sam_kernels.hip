@@ -250,6 +250,13 @@ int samd_device_count(void) {
     return n;
 }
 
+int samd_host_wait_spin(int32_t device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return SAMD_E_NODEVICE;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return SAMD_E_HIP;
+    return hipSetDeviceFlags(hipDeviceScheduleSpin) == hipSuccess ? SAMD_OK : SAMD_E_HIP;
+}
+
 int samd_device_info(int64_t out[4]) {
     if (!out) return SAMD_E_INVALID;
     out[0] = SAMD_ABI_VERSION; out[1] = out[2] = out[3] = 0;

@@ -51,6 +51,7 @@ _VP, _I32, _I64, _F32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _PROTOS = {
     "samd_last_error": (C.c_char_p, []),
     "samd_device_count": (C.c_int, []),
+    "samd_host_wait_spin": (C.c_int, [_I32]),
     "samd_device_info": (C.c_int, [_VP]),
     "samd_static_build": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _VP]),
     "samd_static_from_tables": (C.c_int, [_I32, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I64, _VP]),
@@ -142,20 +143,17 @@ def host_waits_by_spinning(device_index=None):
     """The host waits for the decode step's report once per step; letting that wait spin instead of yield
     (hipDeviceScheduleSpin) takes ~25 us off every step (3.48 -> 3.45 ms, measured A/B in bench.py) at the price of one busy
     host core per GPU process.  The flag only takes effect when it is set BEFORE the process creates its HIP context, so this
-    runs when the package is imported (usually before any device work) and bench.py calls it first thing with its local rank.
+    runs when the package is imported (usually before any device work); bench.py imports the package first thing.
+    torch is imported first on purpose: the process must keep using the HIP runtime torch was built with (its wheel bundles
+    one); libsamd_hip.so binds to whichever libamdhip64.so.7 is already loaded, and samd_host_wait_spin goes through it.
     SAMD_SPIN_WAIT=0 keeps the runtime's default."""
-    if os.environ.get("SAMD_SPIN_WAIT", "1") == "0":
+    if os.environ.get("SAMD_SPIN_WAIT", "1") == "0" or not os.path.exists(LIB_PATH):
         return False
     try:
-        hip = C.CDLL("libamdhip64.so")
-    except OSError:
+        import torch  # noqa: F401
+        return lib().samd_host_wait_spin(-1 if device_index is None else int(device_index)) == 0
+    except (ImportError, OSError, AttributeError):
         return False
-    n = C.c_int(0)
-    if hip.hipGetDeviceCount(C.byref(n)) != 0 or n.value < 1:
-        return False
-    if device_index is not None:
-        hip.hipSetDevice(C.c_int(int(device_index)))
-    return hip.hipSetDeviceFlags(C.c_uint(1)) == 0          # hipDeviceScheduleSpin
 
 
 def require_gpu():
