@@ -268,8 +268,8 @@ def cpu_baseline(flat, off, docs, cfg, toks_walk, wall_budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000, help="timed decode steps; the default spans ~8 requests of 512 new tokens (a 200-step run sees only the first request of the seeded stream)")
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--corpus-tokens", type=int, default=1 << 22)
     ap.add_argument("--acceptance", choices=["scripted", "natural"], default="scripted")
     ap.add_argument("--variant", choices=["sam_only", "token_recycle", "eagle2", "eagle"], default="sam_only",
