@@ -265,6 +265,51 @@ def cpu_baseline(flat, off, docs, cfg, toks_walk, wall_budget_s=12.0):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def launch_command(n_gpus, argv, port=None):
+    """the torch.distributed.run command line for N ranks of this script on one node (one process per GPU, RCCL over xGMI)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    rest = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + rest
+
+
+def launch_ranks(n_gpus, argv, dry=False):
+    import subprocess
+    cmd = launch_command(n_gpus, argv)
+    if dry:
+        print(json.dumps({"launch": cmd, "n_gpus": n_gpus}), flush=True)
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in child.stdout:                              # rank 0 prints the one JSON line; everything else passes through too
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def launch_selftest(args):
+    """the N-rank plumbing without a GPU (tests/test_bench_launch_cpu.py): every rank joins a gloo group, contributes
+    made-up (tokens, seconds), rank 0 prints a line of the bench's shape.  Nothing here is a measurement."""
+    import torch.distributed as dist
+    from samd_hip import parallel
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if os.environ.get("SAMD_SELFTEST_FAIL_RANK") == str(rank):
+        raise SystemExit(3)                                 # the launcher must surface a rank's failure
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    total, dt_max, per_rank = parallel.reduce_throughput(100 * (rank + 1), 1.0 + rank)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "gpus_flag": args.gpus, "value": total / dt_max, "per_rank": per_rank}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,9 +328,23 @@ def main():
     ap.add_argument("--walk-tokens", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--launch-selftest", action="store_true", help="CPU check of the N-rank plumbing (gloo): spawn, rendezvous, reduce, relay; no GPU work")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 outside a launcher: print the child command as JSON and exit")
     args = ap.parse_args()
 
-    import samd_hip                                      # first: sets the spin-wait device flag before a HIP context exists
+    # --gpus N > 1 outside torch.distributed.run: start the N ranks as a CHILD process (never exec: this process may not be
+    # replaced once anything touched the GPU, and nothing below has yet), relay rank 0's JSON line, exit with the child's code.
+    # The reference does the same split with Ray actors on contiguous question chunks (evaluation/eval_vicuna.py:39-68).
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], dry=args.dry_launch))
+    if args.dry_launch:
+        print(json.dumps({"launch": None, "reason": "single process: --gpus 1 or already inside a launcher"}), flush=True)
+        return
+    if args.launch_selftest:
+        return launch_selftest(args)
+
+    import samd_hip
+    samd_hip.host_waits_by_spinning(os.environ.get("LOCAL_RANK"))   # before the HIP context exists (see its docstring)
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -297,7 +356,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    import samd_hip
     import samd_sam_only as SO
     from samd_hip.engine import ScriptedAcceptance
     from samd_hip.llama import LlamaRunner
@@ -395,12 +453,7 @@ def main():
     dt = time.perf_counter() - t0
     stats = {k: list(v) for k, v in model.lookup_stats.items()}
 
-    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tok_all = torch.tensor([tokens], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tok_all, op=dist.ReduceOp.SUM)
-    dt_max, tokens_total = float(t_all.item()), float(tok_all.item())
+    tokens_total, dt_max, per_rank = parallel.reduce_throughput(tokens, dt)      # SUM of tokens, MAX of time over ranks
 
     out = None
     if rank == 0:
@@ -458,6 +511,7 @@ def main():
                        "hipgraphs": not args.no_graphs},
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
+            "per_rank": per_rank,
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
             "step_breakdown_by_rows": breakdown,
             # SURVEY.md 8(d) end-to-end proxy: speed-up = accepted tokens x T_AR / T_step with THIS run's measured step times

@@ -40,6 +40,8 @@ def main():
     from samd import DraftModel, SamdConfig, SamdModel, load_sam
     from evaluation import run_eval
     local = int(os.environ.get("LOCAL_RANK", 0))
+    import samd_hip
+    samd_hip.host_waits_by_spinning(local)                 # opt-in, before the HIP context exists (SAMD_SPIN_WAIT=0 disables)
     torch.cuda.set_device(local)
     if int(os.environ.get("WORLD_SIZE", 1)) > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))

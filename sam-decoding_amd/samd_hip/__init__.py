@@ -140,20 +140,28 @@ def check(rc):
 
 
 def host_waits_by_spinning(device_index=None):
-    """The host waits for the decode step's report once per step; letting that wait spin instead of yield
-    (hipDeviceScheduleSpin) takes ~25 us off every step (3.48 -> 3.45 ms, measured A/B in bench.py) at the price of one busy
-    host core per GPU process.  The flag only takes effect when it is set BEFORE the process creates its HIP context, so this
-    runs when the package is imported (usually before any device work); bench.py imports the package first thing.
-    torch is imported first on purpose: the process must keep using the HIP runtime torch was built with (its wheel bundles
-    one); libsamd_hip.so binds to whichever libamdhip64.so.7 is already loaded, and samd_host_wait_spin goes through it.
-    SAMD_SPIN_WAIT=0 keeps the runtime's default."""
-    if os.environ.get("SAMD_SPIN_WAIT", "1") == "0" or not os.path.exists(LIB_PATH):
+    """Opt-in, called by entry points (bench.py, the evaluation drivers and CLIs) -- importing the package has no side effect.
+    The host waits for the decode step's report once per step; letting that wait spin instead of yield (hipDeviceScheduleSpin)
+    takes ~25 us off every step (3.48 -> 3.45 ms, measured A/B in bench.py) at the price of one busy host core per GPU process.
+    The flag only takes effect when it is set BEFORE the process creates its HIP context, so call this before any device work.
+    It applies to the CURRENT device unless `device_index` is given (then that device also becomes current, as
+    hipSetDeviceFlags works on the current device).  torch is imported first on purpose: the process must keep using the HIP
+    runtime torch was built with; libsamd_hip.so binds to whichever libamdhip64.so.7 is already loaded.
+    SAMD_SPIN_WAIT=0 keeps the runtime's default.  Returns True when the flag was applied; a failure is logged, not hidden."""
+    if os.environ.get("SAMD_SPIN_WAIT", "1") == "0":
         return False
+    import logging
+    log = logging.getLogger("samd_hip")
     try:
         import torch  # noqa: F401
-        return lib().samd_host_wait_spin(-1 if device_index is None else int(device_index)) == 0
-    except (ImportError, OSError, AttributeError):
+        rc = lib().samd_host_wait_spin(-1 if device_index is None else int(device_index))
+    except (ImportError, OSError, AttributeError, SamdError) as e:
+        log.warning("host_waits_by_spinning: not applied (%s)", e)
         return False
+    if rc != 0:
+        msg = lib().samd_last_error()
+        log.warning("host_waits_by_spinning: not applied (rc %d: %s)", rc, msg.decode() if msg else "")
+    return rc == 0
 
 
 def require_gpu():
@@ -467,5 +475,3 @@ class TokenRecycleTable:
         check(lib().samd_recycle_export(self._h, _ptr(table), _ptr(present), current_stream()))
         return table, present
 
-
-host_waits_by_spinning(os.environ.get("LOCAL_RANK"))

@@ -74,3 +74,17 @@ def gather_results(rows, pad=-1, device=None):
         o = out[w].cpu().numpy()
         res.append([o[i, 1:1 + o[i, 0]].tolist() for i in range(int(dims[w][0]))])
     return res
+
+
+def reduce_throughput(tokens, seconds):
+    """bench.py's whole-job figure: tokens summed over ranks, wall time = MAX over ranks, plus what every rank did.
+    -> (tokens_total, seconds_max, [{"rank", "tokens", "seconds"}]).  Works without a process group (world size 1)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(tokens), float(seconds), [{"rank": 0, "tokens": int(tokens), "seconds": round(float(seconds), 4)}]
+    use_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
+    mine = torch.tensor([float(tokens), float(seconds)], dtype=torch.float64, device=dev)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    per_rank = [{"rank": r, "tokens": int(v[0].item()), "seconds": round(float(v[1].item()), 4)} for r, v in enumerate(parts)]
+    return float(sum(v[0].item() for v in parts)), float(max(v[1].item() for v in parts)), per_rank
