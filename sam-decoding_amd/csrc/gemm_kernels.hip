@@ -205,14 +205,16 @@ extern "C" {
 // 5.47 TB/s, lm_head 250 x 16 5.92 TB/s; QKV 96 x 2 splits 5.15 TB/s vs 4.9 with 4 or 8) -- so: the largest split count
 // that keeps columns x splits <= 256 and leaves every split at least one chunk.  Fewer splits also mean fewer fp32
 // partials for the consumer to add up; capped at 8 (whole forward at 64 rows: 4.47 ms with cap 8, 4.56 with 6, 4.64 with 4).
+// The two tuning knobs (SAMD_GEMM_SPLIT_CAP, SAMD_GEMM_SPLITS) are read ONCE, at the first call: callers size their fp32
+// partial-sum workspaces from this function's answer, so the answer for a shape must not change during the process.
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad) {
+    static const int env_cap = [] { const char *e = getenv("SAMD_GEMM_SPLIT_CAP"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+    static const int env_fixed = [] { const char *e = getenv("SAMD_GEMM_SPLITS"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 8 ? 8 : v); }();
     const int cols = N / GEMM_COLS, chunks = K / GEMM_KC;
-    int cap = 8;
     (void)rows_pad;
-    if (const char *e = getenv("SAMD_GEMM_SPLIT_CAP")) cap = atoi(e);
-    if (const char *e = getenv("SAMD_GEMM_SPLITS")) { int v = atoi(e); return v < 1 ? 1 : (v > chunks ? chunks : v); }
+    if (env_fixed) return env_fixed > chunks ? (chunks < 1 ? 1 : chunks) : env_fixed;
     int s = 256 / (cols > 0 ? cols : 1);
-    if (s > cap) s = cap;
+    if (s > env_cap) s = env_cap;
     if (s > chunks) s = chunks;
     return s < 1 ? 1 : s;
 }

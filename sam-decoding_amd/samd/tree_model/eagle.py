@@ -133,7 +133,7 @@ class EagleHead(Eagle2Head):
         logits = F.linear(prev, head_weight)
         rows, past = [], kv
         for lvl in self._levels:
-            top = torch.topk(logits, k, dim=-1).indices
+            top = self._topk(logits, k).indices
             rows.append(top)
             ids = top.reshape(-1)[lvl["select"]]
             hidden_in = torch.repeat_interleave(prev[:lvl["repeat"].numel()], lvl["repeat"], dim=0)
@@ -141,7 +141,7 @@ class EagleHead(Eagle2Head):
                                       tree_mask=lvl["mask"])
             pos_len += 1
             logits = F.linear(prev, head_weight)
-        rows.append(torch.topk(logits, k, dim=-1).indices)
+        rows.append(self._topk(logits, k).indices)
         return torch.cat(rows, dim=0)
 
 
@@ -159,7 +159,7 @@ class EagleHead(Eagle2Head):
         x_rows = torch.empty((0, self.hidden), dtype=prev.dtype, device=dev)
         depth = torch.empty(0, dtype=torch.int32, device=dev)
         for i, lvl in enumerate(self._levels):
-            top = torch.topk(logits, k, dim=-1).indices
+            top = self._topk(logits, k).indices
             rows.append(top)
             ids = top.reshape(-1)[lvl["select"]]
             hidden_in = torch.repeat_interleave(prev[:lvl["repeat"].numel()], lvl["repeat"], dim=0, output_size=int(ids.numel()))
@@ -168,7 +168,7 @@ class EagleHead(Eagle2Head):
             depth = torch.cat((depth, torch.full((ids.numel(),), i, dtype=torch.int32, device=dev)))
             out_all, logits_all = dh.tree(x_rows, depth, self._anc[i])
             prev, logits = out_all[n0:].clone(), logits_all[n0:].clone()
-        rows.append(torch.topk(logits, k, dim=-1).indices)
+        rows.append(self._topk(logits, k).indices)
         return torch.cat(rows, dim=0)
 
 

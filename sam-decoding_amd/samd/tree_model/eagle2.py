@@ -83,6 +83,15 @@ class Eagle2Head(torch.nn.Module):
     def reset(self):
         self.stable_kv = None
 
+    trace = None          # set to a list to record every top-k decision of an expansion as (values, indices): parity tests follow
+
+    def _topk(self, x, k):
+        """torch.topk(x, k, dim=-1); the reference's expansion is a sequence of exactly these calls (eagle2_model.py:848-905)"""
+        top = torch.topk(x, k, dim=-1)
+        if self.trace is not None:
+            self.trace.append((top.values.detach().float().cpu(), top.indices.detach().cpu()))
+        return top
+
     # ---- one forward of the head (eagle2_model.py:704-814) --------------------------------------------------------------
     def forward(self, hidden_states, input_ids, past=None, position_ids=None, tree_mask=None):
         """hidden_states [T, H], input_ids [T] -> (out [T, H], (K, V) incl. past, each [H_kv, L+T, D])."""
@@ -135,7 +144,7 @@ class Eagle2Head(torch.nn.Module):
         pos_len = kv[0].shape[1]
         last_hidden = out[-1:]
         logp = torch.log_softmax(F.linear(last_hidden, head_weight).float(), dim=-1)      # fp32: no -inf ties in half precision
-        top = torch.topk(logp, top_k, dim=-1)
+        top = self._topk(logp, top_k)
         scores = top.values[0]
         scores_list, parents_list, tokens_list = [scores[None]], [torch.zeros(1, dtype=torch.long, device=dev)], [top.indices]
         ids = top.indices[0]
@@ -149,9 +158,9 @@ class Eagle2Head(torch.nn.Module):
             bias = 1 + top_k ** 2 * max(0, i - 1) + (top_k if i > 0 else 0)
             parents_list.append(cs_index + bias)
             logp = torch.log_softmax(F.linear(out, head_weight).float(), dim=-1)
-            top = torch.topk(logp, top_k, dim=-1)
+            top = self._topk(logp, top_k)
             cu = top.values + scores[:, None]
-            best = torch.topk(cu.view(-1), top_k, dim=-1)
+            best = self._topk(cu.view(-1), top_k)
             cs_index, scores = best.indices, best.values
             rows = cs_index // top_k
             in_hidden = out[rows]
@@ -161,7 +170,7 @@ class Eagle2Head(torch.nn.Module):
             tree_mask = torch.cat((tree_mask[rows], torch.eye(top_k, device=dev)), dim=1)
         all_scores = torch.cat(scores_list, dim=0).view(-1)
         all_tokens = torch.cat(tokens_list, dim=0).view(-1)
-        keep = torch.sort(torch.topk(all_scores, self.total_tokens, dim=-1).indices).values
+        keep = torch.sort(self._topk(all_scores, self.total_tokens).indices).values
         draft_tokens = torch.cat((sample_token, all_tokens[keep]), dim=0)
         draft_parents = torch.cat(parents_list, dim=0)[keep // top_k].long()
         mask_index = torch.searchsorted(keep, draft_parents - 1, right=False)
@@ -185,7 +194,7 @@ class Eagle2Head(torch.nn.Module):
         """the level loop of topk_generate on device tensors only (fixed shapes, no host round trip): capturable"""
         top_k, dev = self.top_k, last_hidden.device
         logp = torch.log_softmax(last_logits.float(), dim=-1)
-        top = torch.topk(logp, top_k, dim=-1)
+        top = self._topk(logp, top_k)
         scores = top.values[0]
         scores_list, parents_list, tokens_list = [scores[None]], [torch.zeros(1, dtype=torch.long, device=dev)], [top.indices]
         ids = top.indices[0]
@@ -208,9 +217,9 @@ class Eagle2Head(torch.nn.Module):
             bias = 1 + top_k ** 2 * max(0, i - 1) + (top_k if i > 0 else 0)
             parents_list.append(cs_index + bias)
             logp = torch.log_softmax(logits.float(), dim=-1)
-            top = torch.topk(logp, top_k, dim=-1)
+            top = self._topk(logp, top_k)
             cu = top.values + scores[:, None]
-            best = torch.topk(cu.view(-1), top_k, dim=-1)
+            best = self._topk(cu.view(-1), top_k)
             cs_index, scores = best.indices, best.values
             rows = cs_index // top_k
             in_hidden = out[rows]
@@ -220,7 +229,7 @@ class Eagle2Head(torch.nn.Module):
             level_mask = torch.cat((level_mask[rows], torch.eye(top_k, device=dev)), dim=1)
         all_scores = torch.cat(scores_list, dim=0).view(-1)
         all_tokens = torch.cat(tokens_list, dim=0).view(-1)
-        keep = torch.sort(torch.topk(all_scores, self.total_tokens, dim=-1).indices).values
+        keep = torch.sort(self._topk(all_scores, self.total_tokens).indices).values
         draft_tokens = torch.cat((sample_token, all_tokens[keep]), dim=0)
         draft_parents = torch.cat(parents_list, dim=0)[keep // top_k].long()
         mask_index = torch.searchsorted(keep, draft_parents - 1, right=False)

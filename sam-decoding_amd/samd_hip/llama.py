@@ -82,7 +82,6 @@ class LlamaRunner:
         self.dt = torch_dtype_code(dtype)
         if self.dt not in (F16, BF16):
             raise SamdError("LlamaRunner computes in fp16 or bf16")
-        self.max_len = int(max_cache_len)
         s = shape
         self.w = weights
         # samd_gemm_skinny streams the weights itself where the shape allows (N % 128 == 0, K % 256 == 0); a projection that
@@ -111,16 +110,27 @@ class LlamaRunner:
         if not self.native_gemm:
             self.wp = None
         self.fused_mlp = self.wp is not None and all(l["wgu"] is not None for l in self.wp["layers"])
+        self.scale = 1.0 / math.sqrt(s.head_dim)
+        self._length_state(max_cache_len, kv)
+
+    def _length_state(self, max_cache_len, kv=None):
+        """everything that depends on max_cache_len: KV storage, rotary tables, row buffers, prefill staging.  The weights
+        (row-major + packed) do not, so a different max_cache_len between generate() calls re-runs only this."""
+        s, dtype = self.shape, self.dtype
+        self.max_len = int(max_cache_len)
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
+        self.kv = self.kv_ptrs = None
         self.bind_cache(kv if kv is not None else
                         torch.zeros((s.layers, 2, s.kv_heads, self.max_len, s.head_dim), dtype=dtype, device=self.device))
         # rotary tables, fp32 [max_pos][D/2]
         max_pos = max(s.max_pos, self.max_len)
-        ang = torch.outer(torch.arange(max_pos, dtype=torch.float64), s.inv_freq())
-        self.cos = ang.cos().float().to(self.device).contiguous()
-        self.sin = ang.sin().float().to(self.device).contiguous()
-        self.rope_rows = max_pos
-        self.scale = 1.0 / math.sqrt(s.head_dim)
+        if getattr(self, "rope_rows", 0) != max_pos:
+            ang = torch.outer(torch.arange(max_pos, dtype=torch.float64), s.inv_freq())
+            self.cos = ang.cos().float().to(self.device).contiguous()
+            self.sin = ang.sin().float().to(self.device).contiguous()
+            self.rope_rows = max_pos
+        if hasattr(self, "_buf"):
+            return                                            # row buffers and prefill staging do not depend on the length
         self._buf = {}
         # prefill staging (chunks of MAX_DRAFT rows with a causal chain mask)
         self.pf_tokens = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
@@ -128,6 +138,11 @@ class LlamaRunner:
         rows = [(1 << (i + 1)) - 1 for i in range(MAX_DRAFT)]
         self.pf_mask = torch.tensor([r - (1 << 64) if r >= (1 << 63) else r for r in rows], dtype=torch.int64, device=self.device)
         self.pf_n = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def resize_cache(self, max_cache_len, storage=None):
+        """new max_cache_len (and KV storage) under the same weights; captured hipGraphs of the old buffers are the caller's
+        to drop (SamdModel.set_cache rebuilds its engine)."""
+        self._length_state(max_cache_len, storage)
 
     def bind_cache(self, storage):
         """use `storage` [layers, 2, H_kv, max_len, D] (e.g. SamdStaticCache.storage) as the KV cache."""

@@ -48,9 +48,9 @@ def tree_attention(q, k_cache, v_cache, tree_attn_mask, cache_length: int, n: in
     return out[:n]
 
 
-def _runner_for(lm, max_cache_len, dtype, device):
+def _runner_for(lm, max_cache_len, dtype, device, **kw):
     from samd_hip.llama import LlamaRunner
-    return LlamaRunner.from_hf(lm, max_cache_len, dtype, device)
+    return LlamaRunner.from_hf(lm, max_cache_len, dtype, device, **kw)
 
 
 def _tables():

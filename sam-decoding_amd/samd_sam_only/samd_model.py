@@ -12,6 +12,7 @@ forms share one device state:
 `lm` may be a transformers LlamaForCausalLM (its weights are walked by samd_hip.llama.LlamaRunner), a LlamaRunner, or
 any verifier object with prefill/verify/compact/bucket (samd_hip.engine.ScriptedVerifier in tests).
 """
+import os
 from collections import namedtuple
 from typing import Dict, Optional, Union
 
@@ -70,6 +71,7 @@ class SamdModel(nn.Module):
         self.forward_state = ForwardState(None)
         self.mask_state = MaskState(None)
         self.verifier = lm if _is_verifier(lm) else None
+        self._runner: LlamaRunner = None                    # built from an HF module on first set_cache, kept across cache sizes
         self.engine: DecodeEngine = None
         self.lookup_stats = {"sequence": [0, 0], "tree": [0, 0]}      # type -> [steps, accepted tokens]
 
@@ -117,14 +119,26 @@ class SamdModel(nn.Module):
                 kw = dict(config=cfg, max_cache_len=max_len, device=self.device, dtype=self.dtype)
                 self.cache = cls(**kw) if cls is SamdCache else cls(cfg, batch_size=1, max_cache_len=max_len, device=self.device,
                                                                     dtype=self.dtype, hf_device_map=getattr(self.lm, "hf_device_map", None))
-                self.verifier = self._runner_factory(self.lm, max_len, self.dtype, self.device)
-                self.verifier.bind_cache(self.cache.storage)
+                if self._runner is None:
+                    self._runner = self._runner_factory(self.lm, max_len, self.dtype, self.device, kv=self.cache.storage)
+                    if os.environ.get("SAMD_RELEASE_HF_WEIGHTS", "0") == "1":
+                        self.lm.to("cpu")               # the runner owns its own copies (row-major + packed); opt-in because
+                        torch.cuda.empty_cache()        # callers may keep using the HF module on the GPU (tests do)
+                else:
+                    self._runner.resize_cache(max_len, self.cache.storage)     # same weights; only KV / rope tables change
+                self.verifier = self._runner
                 self.engine = None
             else:
                 self.cache.reset()
-        elif isinstance(self.verifier, LlamaRunner) and self.cache is None:
-            r = self.verifier
-            self.cache = _RunnerCacheView(r)
+        else:
+            # a ready-made runner / verifier was built for ITS max_len: K/V rows past it would be dropped and keys clamped, so a
+            # longer generation_config is an error here, not a silent truncation
+            r = self.verifier if isinstance(self.verifier, LlamaRunner) else getattr(self.verifier, "runner", None)
+            limit = getattr(r, "max_len", None)
+            if limit is not None and max_len > limit:
+                raise samd_hip.SamdError(f"generation_config.max_cache_len {max_len} exceeds the runner's max_cache_len {limit}")
+            if isinstance(self.verifier, LlamaRunner) and self.cache is None:
+                self.cache = _RunnerCacheView(self.verifier)
         session = self.draft.ensure_capacity(max_len + samd_hip.MAX_DRAFT)
         if self.engine is None or self.engine.session is not session:
             self.engine = self._make_engine(session)
