@@ -202,16 +202,19 @@ def lm_roofline(runner, iters=10):
 
 
 def cpu_baseline(flat, off, docs, cfg, toks_walk, wall_budget_s=12.0):
-    """the C oracle (single thread, like the reference's Python) on the same request process as rank 0: per step
-    lookup -> draft(+buffers) -> greedy accept against the continuation -> update; and the batched walk's CPU twin.
-    Runs requests until ~wall_budget_s of wall time is spent; only the oracle's C calls are counted as CPU work (the
-    scripted verdict between them is Python bookkeeping that stands in for the LM)."""
+    """the C oracle (single thread, like the reference's Python) on the same request process as rank 0 and on an automaton
+    built from the SAME full corpus the GPU walks: per step lookup -> draft(+buffers) -> greedy accept against the
+    continuation -> update; and the batched walk's CPU twin.  Runs requests until ~wall_budget_s of wall time is spent; only the
+    oracle's C calls are counted as CPU work (the scripted verdict between them is Python bookkeeping that stands in for the
+    LM).  `reference_cpython` = the reference's own Python on the same generators, timed in the dev container
+    (tests/golden/ref_timings.json, made by tests/golden/make_ref_timings.py) -- its Python cannot travel to this box."""
     from oracle import sam_oracle as O
     t0 = time.perf_counter()
-    n_build = min(len(off) - 1, 4096 + VOCAB)           # bounded corpus sample for the CPU automaton
-    keep = np.r_[0:4096, len(off) - 1 - VOCAB:len(off) - 1] if len(off) - 1 > n_build else np.arange(len(off) - 1)
-    docs_list = [flat[off[i]:off[i + 1]].tolist() for i in keep]
-    st = O.StaticSAM.build(docs_list, EOS)
+    st = O.StaticSAM()
+    fa, fp = O._i32(flat)
+    oa, op = O._i64(off)
+    O.lib().osam_add_batch(st._h, fp, op, len(off) - 1, EOS)         # StaticSAM.build over every document (static_sam.py:131-135)
+    st.init_topk_next()
     build_s = time.perf_counter() - t0
     dm = O.DraftModel(cfg["max_predicts"], cfg["alpha"], cfg["K"], cfg["len_bias"], sam_static=st)
     rng = np.random.default_rng(1000)
@@ -249,19 +252,87 @@ def cpu_baseline(flat, off, docs, cfg, toks_walk, wall_budget_s=12.0):
             tokens += len(acc)
     # CPU twin of the batched walk (transitions/s, one thread)
     T, B = toks_walk.shape
-    nb = min(B, 4096)
+    nb = min(B, 65536)
+    cols = np.ascontiguousarray(toks_walk[:, :nb].T)
     t = time.perf_counter()
     for b in range(nb):
         st.reset()
-        st.transfer_tokens(toks_walk[:, b])
+        st.transfer_tokens(cols[b])
     walk_s = time.perf_counter() - t
+    ref = None
+    try:
+        ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_timings.json")))
+    except (OSError, ValueError):
+        pass
     return dict(value=round(tokens / max(spent, 1e-9), 1), unit="tokens/s", cores=1, kind="port",
                 sample=f"oracle/sam_oracle.c DraftModel loop (lookup+draft+buffers+update, no LM forward) over {steps} steps of {n_req} "
                        f"requests of rank 0's request process ({time.perf_counter() - t_wall:.0f} s wall incl. the scripted verdict in Python, "
-                       f"{spent:.2f} s inside the oracle), static automaton from {len(docs_list)} documents ({build_s:.1f} s build); "
-                       f"walk twin: {nb} streams x {T} tokens",
-                steps=steps, us_per_step=round(spent / max(steps, 1) * 1e6, 2), host_cores_available=os.cpu_count(),
-                walk_transitions_per_s=round(nb * T / max(walk_s, 1e-9), 1))
+                       f"{spent:.2f} s inside the oracle), static automaton = the GPU's: all {len(off) - 1} documents, {st.num_states} states "
+                       f"({build_s:.1f} s oracle build, once); walk twin: {nb} streams x {T} tokens of the GPU's batch (incl. ctypes call overhead)",
+                steps=steps, us_per_step=round(spent / max(steps, 1) * 1e6, 2), mean_accept=round(tokens / max(steps, 1), 3),
+                host_cores_available=os.cpu_count(), oracle_build_s=round(build_s, 2), static_states=int(st.num_states),
+                walk_transitions_per_s=round(nb * T / max(walk_s, 1e-9), 1), reference_cpython=ref)
+
+
+def named_breakdown(model, lm, prompt, n_steps=48):
+    """one request decoded UNGRAPHED with the granular entry points, every piece bracketed by HIP events on the launch stream,
+    reported under the step names the reference profiles (profile_utils.py:21-34; decorator sites samd_sam_only/draft.py:44-61,
+    samd_model.py:96-158, cache.py:17): mean microseconds per step and share of the step.  The product step runs accept +
+    update + lookup as ONE kernel inside a hipGraph; this decomposition exists for attribution only (ungraphed launches carry
+    their launch latency, so the small pieces are upper bounds)."""
+    import torch
+    import samd_hip
+    from samd_hip.engine import StepReport
+    eng = model.engine
+    sess, static, params, views = eng.session, eng.static, eng.params, eng._views
+    runner = getattr(lm, "runner", lm)
+    shp = runner.shape
+    names = ["LM verify forward [SamdModel.decode's lm() call, samd_model.py:134-138]",
+             "arg-max over the logits [gen_candidates utils.py:86 + eval_posterior utils.py:131]",
+             "eval_posterior [utils.py:127-141]",
+             "DraftModel.update [draft.py:62-67]",
+             "DraftModel.lookup incl. gen_draft + gen_buffers [draft.py:50-59]",
+             "SamdCache.select_indices [cache.py:118-133]",
+             "report D2H + host sync [the .item()/.tolist() syncs of samd_model.py:158-174]"]
+    tot = [0.0] * len(names)
+    scratch = torch.zeros(64, dtype=torch.int32, device="cuda")
+    rep = eng.start(torch.tensor([prompt], dtype=torch.long, device="cuda"))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+    done = 0
+    for _ in range(n_steps):
+        if rep.n < 1:
+            break
+        R = lm.bucket(rep.n)
+        lm.verify(sess, R)                                  # untimed first pass of this draft (buffers, library handles)
+        torch.cuda.synchronize()
+        ev[0].record()
+        b = lm.verify(sess, R)                              # idempotent on a fixed draft: the same K/V rows are rewritten
+        ev[1].record()
+        samd_hip.check(samd_hip.lib().samd_argmax_rows(samd_hip._ptr(b["logits"]), runner.dt, R, shp.vocab, shp.vocab, None,
+                                                       samd_hip._ptr(scratch), samd_hip.current_stream()))     # the verify already ran one
+        ev[2].record()
+        sess.accept(b["argmax"])
+        ev[3].record()
+        sess.commit(static)
+        ev[4].record()
+        sess.draft(static, params, views["start_token"])
+        ev[5].record()
+        lm.compact(sess)
+        ev[6].record()
+        sess.report_async(eng.report_buf)
+        torch.cuda.current_stream().synchronize()
+        ev[7].record()
+        torch.cuda.synchronize()
+        rep = StepReport(eng._report_np)
+        d = [ev[k].elapsed_time(ev[k + 1]) * 1e3 for k in range(len(names))]
+        d[0] -= d[1]                                        # the forward's own arg-max launch is reported on its own line
+        for k in range(len(names)):
+            tot[k] += d[k]
+        done += 1
+    step_us = sum(tot) / max(done, 1)
+    return {"steps": done, "graphs": False, "step_us": round(step_us, 1),
+            "pieces": {nm: {"us": round(t / max(done, 1), 2), "share": round(t / max(sum(tot), 1e-9), 4)} for nm, t in zip(names, tot)},
+            "non_lm_share": round(1.0 - tot[0] / max(sum(tot), 1e-9), 4)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -375,7 +446,7 @@ def main():
     dtype = torch.float16 if args.model == "vicuna-7b" else torch.bfloat16
     if args.layers:
         mcfg["num_hidden_layers"] = args.layers
-    max_len = min(mcfg["max_position_embeddings"], 2048)      # requests are 512 + 512 tokens; the cache guard uses this length
+    max_len = mcfg["max_position_embeddings"]                 # 2048 (Vicuna) / 8192 (Llama-3): evaluation/inference_samd.py:152-163
     runner = LlamaRunner.random_init(mcfg, max_len, dtype, seed=0)
     lm = ScriptedAcceptance(runner, VOCAB, max_len) if args.acceptance == "scripted" else runner
 
@@ -490,6 +561,11 @@ def main():
         torch.cuda.synchronize()
         ar_tps = ar_tokens / (time.perf_counter() - ta)
 
+        named = None
+        if args.variant == "sam_only":
+            if args.acceptance == "scripted":
+                lm.set_target(req_log[0][1])
+            named = named_breakdown(model, lm, req_log[0][0])
         roof, toks_walk = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20, args.corpus_tokens)
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(flat, off, docs, cfg, toks_walk)    # rank 0 at N = 1 only
 
@@ -504,7 +580,7 @@ def main():
                                     + ("LM arg-max replaced after the full forward by each request's continuation stream"
                                        if args.acceptance == "scripted" else "the random-init model's own arg-max"),
             "config": {"workload": "BASELINE.json configs[1]: samd_sam_only, Vicuna-7B-v1.3 shape fp16, bs=1, max_predicts 60, alpha 4, "
-                                   "len_bias 0, K 8; prompts 512 tokens, max_new_tokens 512, max_cache_len 2048",
+                                   f"len_bias 0, K 8; prompts 512 tokens, max_new_tokens 512, max_cache_len {max_len}",
                        "model_shape": args.model, "layers": mcfg["num_hidden_layers"], "corpus_tokens": int(args.corpus_tokens),
                        "static_sam_states": int(sam_info["n_states"]), "static_sam_bytes": int(sam_info["device_bytes"]),
                        "acceptance": args.acceptance, "variant": args.variant, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
@@ -513,7 +589,7 @@ def main():
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
             "per_rank": per_rank,
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
-            "step_breakdown_by_rows": breakdown,
+            "step_breakdown_by_rows": breakdown, "step_breakdown_named": named,
             # SURVEY.md 8(d) end-to-end proxy: speed-up = accepted tokens x T_AR / T_step with THIS run's measured step times
             # (16- and 64-row buckets) and the mean accepted tokens the reference publishes (README.md:53-57) -- a projection,
             # not a measurement of those configurations
