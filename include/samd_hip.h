@@ -283,6 +283,26 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                         const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
 
+/* The attention block of one decoder layer in ONE launch: RoPE on q and k, the K/V row write of SamdStaticCache.update
+ * (SO/cache.py:103-115) at [write_pos, write_pos + n), tree-mask attention (SO/model_patch/llama.py:82-96 + SDPA) and the
+ * merge of the KV splits -- what samd_rope_kv_write + samd_tree_attention do in three launches.
+ *   d_qkv: the q|k|v projection's output [rows >= n_q_pad][(H + 2 H_kv) * D] of `dtype`, or (n_partials > 0) the streaming
+ *          GEMM's fp32 partial sums [n_partials][partial_stride] of the same layout (summed, then rounded to dtype);
+ *   d_cs:  float [n_q_pad][D]: cos (first D/2) and sin (last D/2) of every row's position -- samd_rope_rows, once per forward;
+ *   visibility: keys < *d_visible_len are visible to every row; key *d_visible_len + j is visible to row i iff bit j of
+ *          d_mask[i] is set.  d_visible_len == NULL means *d_write_pos (the base model's verify: bit j = new row j).  A draft
+ *          head's tree level keeps the rows of earlier levels in its cache: visible_len = accepted length, write_pos beyond it.
+ *   d_workspace: samd_tree_attention_fused_workspace() bytes; its first 1024 bytes are per-head arrival counters that must be
+ *          ZERO before the first launch (every launch leaves them zero).
+ * out [n_q_pad][H][D], rows >= n zeroed.  head_dim 128, f16 / bf16, n_q_pad <= 64, H <= 256. */
+int64_t samd_tree_attention_fused_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim);
+int samd_rope_rows(const int32_t *d_rel_pos, const int32_t *d_base, const float *d_cos, const float *d_sin, float *d_cs, int32_t rows,
+                   int32_t head_dim, int32_t max_pos, void *stream);
+int samd_tree_attention_fused(const void *d_qkv, int32_t n_partials, int64_t partial_stride, const float *d_cs, void *d_k_cache, void *d_v_cache,
+                              void *d_out, int32_t dtype, int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                              const uint64_t *d_mask, const int32_t *d_write_pos, const int32_t *d_visible_len, const int32_t *d_n, float scale,
+                              void *d_workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- memory-bound glue of the verify forward (between the library GEMMs).  The arithmetic of the
  * forward lives in HuggingFace transformers in the reference (third party, not vendored; call sites
  * SO/samd_model.py:102-106 and :134-138); these follow LlamaDecoderLayer's operators and take every

@@ -124,6 +124,23 @@ private:
     }
 };
 
+// SAMD_RUN flags (samd_common.h): run[s] = number of consecutive states s, s + 1, ... whose rank-0 successor is the next state
+// in memory (capped at 8); state i gets the flag when run[e0.dst] >= 2.  Idempotent; every path that produces a host image
+// ends here, so images written before the flag existed are upgraded on load.
+static void finalize_runs(samd_static_t *s) {
+    const int64_t n = s->n_states;
+    std::vector<uint8_t> run((size_t)n + 1, 0);
+    for (int64_t i = n - 1; i >= 0; i--) {
+        const SamNode &nd = s->h_nodes[i];
+        run[i] = (nd.e0_tok >= 0 && nd.e0_dst == i + 1) ? (uint8_t)std::min<int>(8, run[i + 1] + 1) : 0;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        SamNode &nd = s->h_nodes[i];
+        nd.length &= ~SAMD_RUN;
+        if (nd.e0_tok >= 0 && nd.e0_dst >= 0 && nd.e0_dst < n && run[nd.e0_dst] >= 2) nd.length |= SAMD_RUN;
+    }
+}
+
 struct Ranked { int32_t tok, dst, key, order; };
 
 // tables (dict-order edges) -> 64-byte node image
@@ -156,7 +173,7 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
     for (int64_t i = 0; i < n_states; i++) {
         const int32_t d = deg[i];
         SamNode &nd = s->h_nodes[i];
-        if (length[i] < 0 || length[i] >= SAMD_SINGLE) { samd_static_free(s); samd_set_error("state length out of range"); return SAMD_E_CAPACITY; }
+        if (length[i] < 0 || length[i] > SAMD_LEN_MASK) { samd_static_free(s); samd_set_error("state length out of range"); return SAMD_E_CAPACITY; }
         nd.link = link[i]; nd.length = length[i] | (d <= 1 ? SAMD_SINGLE : 0); nd.aux = aux[i]; nd.deg = d; nd.spill = -1; nd.reserved = 0;
         int32_t *words = reinterpret_cast<int32_t *>(&nd);
         for (int j = 0; j < SAMD_INLINE_EDGES; j++) { words[SAMD_EDGE_WORD(j)] = -1; words[SAMD_EDGE_WORD(j) + 1] = -1; }
@@ -192,6 +209,7 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
         }
         ebase += d;
     }
+    finalize_runs(s);
     *out = s;
     return SAMD_OK;
 }
@@ -250,6 +268,7 @@ void samd_static_free(samd_static_t *s) {
         if (s->d_spill) (void)hipFree(s->d_spill);
         if (s->d_text) (void)hipFree(s->d_text);
     }
+    if (s->d_chain) (void)hipFree(s->d_chain);
     free(s);
 }
 
@@ -268,7 +287,7 @@ int samd_static_export(const samd_static_t *s, int32_t *h_link, int32_t *h_lengt
     for (int64_t i = 0; i < s->n_states; i++) {
         const SamNode &nd = s->h_nodes[i];
         if (h_link) h_link[i] = nd.link;
-        if (h_length) h_length[i] = nd.length & ~SAMD_SINGLE;
+        if (h_length) h_length[i] = nd.length & SAMD_LEN_MASK;
         if (h_aux) h_aux[i] = nd.aux;
         if (h_deg) h_deg[i] = nd.deg;
         if (!h_edge_tok || !h_edge_dst) continue;
@@ -368,6 +387,7 @@ int samd_static_load(const char *path, samd_static_t **out) {
     if (!ok) { samd_static_free(s); samd_set_error("%s: truncated image", path); return SAMD_E_IO; }
     const char *why = "";
     if (!image_is_sane(s, &why)) { samd_static_free(s); samd_set_error("%s: damaged image (%s)", path, why); return SAMD_E_IO; }
+    finalize_runs(s);
     *out = s;
     return SAMD_OK;
 }
@@ -393,7 +413,7 @@ int samd_static_upload(samd_static_t *s) {
     if (s->n_spill) HIPCHK(hipMemcpy(s->d_spill, s->h_spill, (size_t)s->n_spill * 8, hipMemcpyHostToDevice));
     if (s->n_text) HIPCHK(hipMemcpy(s->d_text, s->h_text, (size_t)s->n_text * 4, hipMemcpyHostToDevice));
     s->uploaded = 1;
-    return SAMD_OK;
+    return samd_static_derive_chain(s, nullptr);
 }
 
 int samd_static_device_image(const samd_static_t *s, void *out_ptrs[4], int64_t out_bytes[4]) {
@@ -437,6 +457,7 @@ int samd_static_from_host_image(const int64_t info[8], const void *const h_ptrs[
     if (s->n_text && h_ptrs[3]) memcpy(s->h_text, h_ptrs[3], (size_t)s->n_text * 4);
     const char *why = "";
     if (!image_is_sane(s, &why)) { samd_static_free(s); samd_set_error("samd_static_from_host_image: damaged image (%s)", why); return SAMD_E_INVALID; }
+    finalize_runs(s);
     *out = s;
     return SAMD_OK;
 }
@@ -447,6 +468,8 @@ int samd_static_adopt_device(const int64_t info[8], void *const d_ptrs[4], samd_
     if (!s) { samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }
     s->d_nodes = (SamNode *)d_ptrs[0]; s->d_root = (int32_t *)d_ptrs[1]; s->d_spill = (SamEdge *)d_ptrs[2]; s->d_text = (int32_t *)d_ptrs[3];
     s->uploaded = 1; s->borrowed = 1;
+    const int rc = samd_static_derive_chain(s, nullptr);      // the caller's four regions are filled before they are adopted
+    if (rc) { samd_static_free(s); return rc; }
     *out = s;
     return SAMD_OK;
 }

@@ -51,9 +51,72 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
         }
         const int4 *np = reinterpret_cast<const int4 *>(S.nodes + idx);
         const int4 w0 = np[0];
-        if (hopped) len = w0.y & ~SAMD_SINGLE;     // length <- states[link].length (static_sam.py:101)
+        if (hopped) len = w0.y & SAMD_LEN_MASK;    // length <- states[link].length (static_sam.py:101)
         int nx = (w0.z == tok) ? w0.w : -1;
         if (nx < 0 && !(w0.y & SAMD_SINGLE)) {
+            const int4 w1 = np[1], w2 = np[2], w3 = np[3];
+            nx = (w1.z == tok) ? w1.w : nx;
+            nx = (w2.x == tok) ? w2.y : nx;
+            nx = (w2.z == tok) ? w2.w : nx;
+            nx = (w3.x == tok) ? w3.y : nx;
+            if (nx < 0 && w1.y > SAMD_INLINE_EDGES)
+                nx = spill_search(S.spill + w3.z + SAMD_SPILL_HEAD, w1.y, tok);
+        }
+        if (nx >= 0) { idx = nx; len += 1; return visited; }
+        idx = w0.x; hopped = true;
+        if (idx == 0) len = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same transition for a cursor that may hold a CHAIN WORD (samd_common.h): `cw` = the rank-0 tokens of the non-branching
+// run that starts at the cursor's state, next one in the low bits, all-ones once exhausted.  A token that equals the word's
+// next token IS the transition "edge found -> follow, length + 1" of transfer_state (the word repeats what the nodes say), so
+// it costs no memory access; anything else drops the word and goes through the nodes exactly as st_transfer does.  After
+// following a rank-0 edge whose source carries SAMD_RUN the word of the new state is fetched (one 16-byte load that then
+// serves up to W transitions).  W = 8 (u16 tokens) or 4 (u32).  Results are identical to st_transfer's by construction;
+// tests/test_gpu_sam.py and test_gpu_fullsize.py compare both with the oracle.
+// ------------------------------------------------------------------------------------------------
+struct ChainWord { unsigned long long lo, hi; };
+__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = ~0ull; return c; }
+
+template <int W>
+__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, ChainWord &cw) {
+    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); return 1; }
+    {   // register path
+        const unsigned next = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+        const unsigned term = W == 8 ? 0xFFFFu : 0xFFFFFFFFu;
+        if (next != term && next == (unsigned)tok) {
+            idx += 1; len += 1;
+            if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
+            else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
+            return 1;
+        }
+    }
+    cw = chain_none();
+    int visited = 0;
+    bool hopped = false;
+    for (;;) {
+        visited++;
+        if (idx == 0) {
+            int nx = (tok < S.vocab) ? S.root_next[tok] : -1;
+            if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
+            return visited;
+        }
+        const int4 *np = reinterpret_cast<const int4 *>(S.nodes + idx);
+        const int4 w0 = np[0];
+        if (hopped) len = w0.y & SAMD_LEN_MASK;
+        if (w0.z == tok) {                                   // rank-0 edge
+            idx = w0.w; len += 1;
+            if (w0.y & SAMD_RUN) {
+                const uint4 c = S.chain[idx];
+                cw.lo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
+                cw.hi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
+            }
+            return visited;
+        }
+        int nx = -1;
+        if (!(w0.y & SAMD_SINGLE)) {
             const int4 w1 = np[1], w2 = np[2], w3 = np[3];
             nx = (w1.z == tok) ? w1.w : nx;
             nx = (w2.x == tok) ? w2.y : nx;

@@ -15,6 +15,7 @@ static inline StaticDev static_view(const samd_static_t *s) {
     if (!s) { memset(&v, 0, sizeof(v)); return v; }
     v.nodes = s->d_nodes; v.root_next = s->d_root; v.spill = s->d_spill; v.text = s->d_text;
     v.n_states = (int32_t)s->n_states; v.vocab = (int32_t)s->vocab; v.n_text = (int32_t)s->n_text; v.kind = s->kind;
+    v.chain = (const uint4 *)s->d_chain; v.chain_w = s->vocab < 65535 ? 8 : 4;
     return v;
 }
 
@@ -27,6 +28,7 @@ static inline StaticDev static_view(const samd_static_t *s) {
 // one-visit-per-iteration state machine with LDS-staged tokens and a lane-quad variant (4 lanes x 16 B per node) were
 // measured and are not faster once the kernel is request-bound; the simple nesting stays.
 // ================================================================================================
+template <int W, bool CHAIN>
 __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__restrict__ cursors,
                                                      const int32_t *__restrict__ tokens, int B, int T, int commit,
                                                      int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total) {
@@ -36,9 +38,11 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
         int2 c = reinterpret_cast<const int2 *>(cursors)[b];
         int idx = c.x, len = c.y;
         int tok = tokens[b];
+        ChainWord cw = chain_none();
         for (int t = 0; t < T; t++) {
             const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;
-            visited += st_transfer(S, idx, len, tok);
+            if (CHAIN) visited += st_transfer_chain<W>(S, idx, len, tok, cw);
+            else visited += st_transfer(S, idx, len, tok);
             if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(idx, len);
             tok = nxt;
         }
@@ -48,6 +52,27 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
         for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
         if ((threadIdx.x & 63) == 0 && visited) atomicAdd(visited_total, visited);
     }
+}
+
+// chain words from the node image: one thread per state (samd_common.h, CHAIN WORDS)
+template <int W>
+__global__ __launch_bounds__(256) void k_build_chain(const SamNode *__restrict__ nodes, long long n, uint4 *__restrict__ chain) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    unsigned tokw[W];
+    bool alive = true;
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        tokw[j] = W == 8 ? 0xFFFFu : 0xFFFFFFFFu;
+        if (alive && s + j < n) {
+            const int4 w0 = reinterpret_cast<const int4 *>(nodes + s + j)[0];
+            if (w0.z >= 0 && (long long)w0.w == s + j + 1) tokw[j] = (unsigned)w0.z; else alive = false;
+        } else alive = false;
+    }
+    uint4 o;
+    if constexpr (W == 8) { o.x = tokw[0] | (tokw[1] << 16); o.y = tokw[2] | (tokw[3] << 16); o.z = tokw[4] | (tokw[5] << 16); o.w = tokw[6] | (tokw[7] << 16); }
+    else { o.x = tokw[0]; o.y = tokw[1]; o.z = tokw[2]; o.w = tokw[3]; }
+    chain[s] = o;
 }
 
 // ================================================================================================
@@ -269,14 +294,34 @@ int samd_device_info(int64_t out[4]) {
     return SAMD_OK;
 }
 
+// SAMD_WALK_CHAIN=0 (read once) keeps every transition on the nodes: the A/B switch of profiles/r02_walk_pmc.md
+static void launch_walk(const samd_static_t *sam, int blocks, int threads, hipStream_t st, int32_t *d_cursors, const int32_t *d_tokens, int B, int T,
+                        int commit, int32_t *d_trace, unsigned long long *d_visited) {
+    static const bool use_chain = [] { const char *e = getenv("SAMD_WALK_CHAIN"); return !(e && e[0] == '0'); }();
+    const StaticDev v = static_view(sam);
+    if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, false>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
+    else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, true>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
+    else hipLaunchKernelGGL((k_static_walk<4, true>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
+}
+
+int samd_static_derive_chain(samd_static_t *s, void *stream) {
+    if (!s || !s->uploaded || !s->d_nodes) return SAMD_E_INVALID;
+    if (!s->d_chain && hipMalloc(&s->d_chain, (size_t)s->n_states * 16) != hipSuccess) { s->d_chain = nullptr; samd_set_error("hipMalloc(chain words) failed"); return SAMD_E_HIP; }
+    const unsigned blocks = (unsigned)((s->n_states + 255) / 256);
+    if (s->vocab < 65535) hipLaunchKernelGGL(k_build_chain<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
+    else hipLaunchKernelGGL(k_build_chain<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
+    LAUNCHCHK();
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { samd_set_error("chain-word derivation failed"); return SAMD_E_HIP; }
+    return SAMD_OK;
+}
+
 int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
                      int32_t commit, int32_t *d_trace, void *stream) {
     if (!sam || !sam->uploaded || B < 0 || T < 0) { samd_set_error("samd_static_walk: invalid argument"); return SAMD_E_INVALID; }
     if (B == 0 || T == 0) return SAMD_OK;                 // empty batch / no tokens: nothing to do
     if (!d_cursors || !d_tokens) { samd_set_error("samd_static_walk: null pointer"); return SAMD_E_INVALID; }
     const int threads = 256, blocks = (B + threads - 1) / threads;
-    hipLaunchKernelGGL(k_static_walk, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, static_view(sam), d_cursors, d_tokens,
-                       B, T, commit, d_trace, (unsigned long long *)nullptr);
+    launch_walk(sam, blocks, threads, (hipStream_t)stream, d_cursors, d_tokens, B, T, commit, d_trace, (unsigned long long *)nullptr);
     LAUNCHCHK();
     return SAMD_OK;
 }
@@ -287,8 +332,7 @@ int samd_static_walk_counted(const samd_static_t *sam, int32_t *d_cursors, const
                              int32_t commit, uint64_t *d_visited, void *stream) {
     if (!sam || !sam->uploaded || !d_cursors || !d_tokens || B <= 0 || T <= 0 || !d_visited) return SAMD_E_INVALID;
     const int threads = 256, blocks = (B + threads - 1) / threads;
-    hipLaunchKernelGGL(k_static_walk, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, static_view(sam), d_cursors, d_tokens,
-                       B, T, commit, (int32_t *)nullptr, (unsigned long long *)d_visited);
+    launch_walk(sam, blocks, threads, (hipStream_t)stream, d_cursors, d_tokens, B, T, commit, (int32_t *)nullptr, (unsigned long long *)d_visited);
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -23,6 +23,14 @@
 // empty = (-1,-1).  A high-degree state (short context) is resolved in ~1.5 probes of one or two adjacent lines;
 // a sorted block would cost log2(deg) DEPENDENT loads, which is what a wavefront then waits for (profiles/).
 #define SAMD_SINGLE 0x40000000     // flag bit in `length`: the state has at most one outgoing edge
+#define SAMD_RUN 0x20000000        // flag bit in `length`: the chain word of e0.dst holds >= 2 tokens (worth loading after following e0)
+#define SAMD_LEN_MASK 0x1FFFFFFF   // the length itself
+// CHAIN WORDS (device-only, derived from the node image at upload): chain[s] = the rank-0 tokens of the non-branching run that
+// starts at s -- token j is e0.tok of state s + j as long as e0.dst of every state s .. s + j is the NEXT state in memory
+// (the builder numbers states in creation order, which makes a corpus position's successor state the next index: 93 % of
+// the states of the bench automaton) -- as 8 x u16 (vocab < 65535) or 4 x u32, terminator all-ones.  A cursor that holds
+// chain[s] follows up to 8 matching tokens WITHOUT touching memory (st_transfer_chain, sam_device.h): the batched walk runs at
+// the memory system's request rate, and this removes ~0.37 of its requests (scripts/walk_chain_sim.py).
 struct __attribute__((aligned(64))) SamNode {
     int32_t link, length, e0_tok, e0_dst;
     int32_t aux, deg, e1_tok, e1_dst;
@@ -57,6 +65,8 @@ struct StaticDev {
     const SamEdge *spill;
     const int32_t *text;        // KIND_ENDPOS: input_ids with the -1 sentinel at [0]
     int32_t n_states, vocab, n_text, kind;
+    const uint4 *chain;         // chain words (may be null: every transition then goes through the nodes)
+    int32_t chain_w;            // tokens per chain word: 8 (u16) or 4 (u32)
 };
 
 // ---- session (per request) -------------------------------------------------------------------
@@ -118,6 +128,13 @@ struct samd_static {
     int32_t *d_text;
     int uploaded;
     int borrowed;               // device image owned by the caller (samd_static_adopt_device)
+    void *d_chain;              // chain words, derived on the device from d_nodes (always owned by the handle)
 };
+
+// sam_kernels.hip: (re)derive the chain words from the device image; called by upload / adopt and lazily by the walks
+#ifdef __cplusplus
+extern "C"
+#endif
+int samd_static_derive_chain(struct samd_static *s, void *stream);
 
 void samd_set_error(const char *fmt, ...);

@@ -88,6 +88,7 @@ class LlamaRunner:
         # does not fit (say a fine-tune's 32001-row lm_head) goes to the library GEMM on its own, the others keep the kernel
         streams = lambda t: bool(native_gemm) and t.shape[0] % 128 == 0 and t.shape[1] % 256 == 0
         self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 64))     # tuning knob; see forward_rows
+        self.fused_attention = os.environ.get("SAMD_FUSED_ATTENTION", "1") != "0"            # A/B knob: 0 = rope / attention / merge as three launches
         # second copy of the projection weights in the streaming kernel's packed layout (samd_gemm_pack_weights): the
         # row-major originals stay for the wide prefill's library GEMMs.  2 x 13.5 GB for a 7B model -- HBM capacity
         # (288 GB) is not what this path is short of, bandwidth is.
@@ -210,7 +211,7 @@ class LlamaRunner:
             s, dt, dev = self.shape, self.dtype, self.device
             RP = max(R, 16) if self.native_gemm else R           # the skinny GEMM reads 16 / 32 / 64 rows (pad rows are zero)
             z = lambda r, *sz: torch.zeros((max(r, RP),) + sz, dtype=dt, device=dev)
-            ws_bytes = lib().samd_tree_attention_workspace(R, s.heads, s.head_dim)
+            ws_bytes = max(lib().samd_tree_attention_workspace(R, s.heads, s.head_dim), lib().samd_tree_attention_fused_workspace(R, s.heads, s.head_dim))
             part_elems = 0
             if self.native_gemm:
                 qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
@@ -221,7 +222,8 @@ class LlamaRunner:
                                 gu=z(R, 2 * s.inter), act=z(R, s.inter), d=z(R, s.hidden), logits=z(R, s.vocab),
                                 argmax=torch.zeros(MAX_DRAFT, dtype=torch.int32, device=dev), rows_pad=RP,
                                 part=torch.zeros(max(part_elems, 1), dtype=torch.float32, device=dev),
-                                ws=torch.zeros(ws_bytes, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes)
+                                ws=torch.zeros(ws_bytes, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes,
+                                cs=torch.zeros((MAX_DRAFT, s.head_dim), dtype=torch.float32, device=dev))
         return self._buf[R]
 
     def bucket(self, n):
@@ -230,7 +232,7 @@ class LlamaRunner:
                 return b
         raise SamdError(f"draft of {n} nodes exceeds {MAX_DRAFT}")
 
-    def forward_rows(self, R, d_tokens, d_relpos, d_mask, d_L, d_n, x_in=None):
+    def forward_rows(self, R, d_tokens, d_relpos, d_mask, d_L, d_n, x_in=None, d_vis=None):
         """one forward over R rows; all of d_* are device pointers (ints / tensors).  Returns the buffers of bucket R
         (logits [R, V], argmax int32[64] with rows < n valid).  x_in [R, hidden]: the rows' input states instead of the
         token embedding (EAGLE draft heads feed fc([embed ; hidden])).  With `self.draft_head` the decoder is an EAGLE head:
@@ -256,6 +258,12 @@ class LlamaRunner:
             rows_in = min(R, x_in.shape[0])
             b["x"][:rows_in].copy_(x_in[:rows_in])                # rows past d_n are never consumed
         head = getattr(self, "draft_head", False)
+        fused = self.fused_attention
+        if fused:
+            # cos / sin of every row's position (visible length + relative position), once per forward: the attention launches of
+            # all layers read them without first having to wait for L
+            check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_vis if d_vis is not None else d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R,
+                                   s.head_dim, self.rope_rows, st))
         delta, dn, dstride = None, 0, 0
         packed = self.wp["layers"] if self.wp else [{}] * len(self.w["layers"])
         for li, w in enumerate(self.w["layers"]):
@@ -265,12 +273,20 @@ class LlamaRunner:
             else:
                 check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
             src, n_p, stride = gemm(b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
-            check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
-                                       _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
-                                       s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
-            check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
-                                        s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
-                                        _ptr(b["ws"]), b["ws_bytes"], st))
+            if fused:
+                # RoPE + K/V row write + tree attention + split merge in one launch (samd_tree_attention_fused)
+                check(L.samd_tree_attention_fused(_ptr(src), n_p, stride, _ptr(b["cs"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R,
+                                                  s.heads, s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_vis), _ptr(d_n), self.scale,
+                                                  _ptr(b["ws"]), b["ws_bytes"], st))
+            else:
+                if d_vis is not None:
+                    raise SamdError("a visible length different from the write position needs the fused attention kernel")
+                check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
+                                           _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
+                                           s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
+                check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
+                                            s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                                            _ptr(b["ws"]), b["ws_bytes"], st))
             src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"])
             check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride, st))
             if self.fused_mlp and RP <= self.native_gemm_max_rows:

@@ -1,29 +1,34 @@
 #!/bin/bash
-# PMC + trace passes for the SAM traversal kernel at bench.py's roofline configuration (run on the GPU box).
-# Counters are collected in their own runs; FETCH_SIZE and WRITE_SIZE in separate passes (TCC slot budget).
+# PMC + trace passes for the SAM traversal kernel at bench.py's roofline configuration (run on the GPU box):
+#   scripts/pmc_walk.sh [tag]        tag = output sub-directory under gpurun_out/ (default pmc_r2); SAMD_WALK_CHAIN=0 in the
+#                                    environment profiles the node-only variant (the A/B of profiles/r02_walk_pmc.md)
+# Counters are collected in their own runs (never together with --sys-trace etc.); FETCH_SIZE and WRITE_SIZE in separate passes.
+# The summary (walk_summary.json) is what profiles/walk_pmc.json -- bench.py's `roofline.traffic` -- is refreshed from.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_r1
+OUT=gpurun_out/${1:-pmc_r2}
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/walk_trace -o w -- python3 scripts/walk_probe.py > $OUT/walk_trace.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY TCP_TCC_READ_REQ_sum"; do
   tag=$(echo $c | tr ' ' '+')
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/walk_$tag -o w -- python3 scripts/walk_probe.py > $OUT/walk_$tag.txt 2>&1
 done
-python3 - <<'PY'
-import csv, glob, collections, json
-out = {}
-for f in glob.glob("gpurun_out/pmc_r1/walk_*/*counter_collection.csv"):
+python3 - "$OUT" <<'PY'
+import csv, glob, collections, json, sys
+out, d = {}, sys.argv[1]
+for f in glob.glob(d + "/walk_*/*counter_collection.csv"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "k_static_walk" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c, v in agg.items():
         out[c] = v[-1]
-for f in glob.glob("gpurun_out/pmc_r1/walk_trace/*kernel_stats.csv"):
+for f in glob.glob(d + "/walk_trace/*kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if "k_static_walk" in r["Name"]:
-            out["kernel_stats"] = {k: r[k] for k in ("Calls", "AverageNs", "MinNs", "MaxNs")}
+            out["kernel_stats"] = {k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")}
+for line in open(d + "/walk_trace.txt"):
+    if line.startswith("{'bound'"):
+        out["bench_roofline"] = eval(line)
 print(json.dumps(out))
-json.dump(out, open("gpurun_out/pmc_r1/walk_summary.json", "w"), indent=1)
+json.dump(out, open(d + "/walk_summary.json", "w"), indent=1)
 PY
-tail -1 $OUT/walk_trace.txt

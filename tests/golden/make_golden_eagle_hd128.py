@@ -8,8 +8,10 @@ Half precision moves logits by a few 1e-4 relative, which can swap two near-equa
 decisions per expansion over random weights some decision is always close.  So (a) every torch.topk call of the reference is
 recorded -- values, indices and the runner-up value (the margin of the last kept entry) -- which lets the GPU test follow the
 device head decision by decision and accept a difference only where the reference's own margin is below the stated fp16
-tolerance; (b) the seed is the first one whose drafts survive 8 runs of the reference with 5e-4 relative noise on its
-hidden states and head logits, so that most recorded calls are expected to match end to end.  Dev-container only (needs
+tolerance; (b) the seed is the first one (of 400; else the most robust one seen -- EAGLE-2: seed 86 survives 2 of 8) whose drafts survive 8 runs of the reference with 2e-3 relative noise on its
+hidden states and head logits -- for EAGLE-2 as a TREE (the set of root->node token paths: a swap of two near-equal
+candidates inside a row renumbers nodes without changing the tree), for EAGLE v1 exactly (there the rank decides which child
+slot a token fills) -- so that most recorded calls are expected to match.  Dev-container only (needs
 /root/reference).
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_eagle_hd128.py
@@ -38,9 +40,9 @@ from samd.tree_model.eagle.eagle_model import EagleModel                # noqa: 
 from samd.tree_model.eagle.eagle import Eagle                           # noqa: E402
 from eagle_fixture_weights import CFG, call_inputs, head_state, lm_head_weight   # noqa: E402
 
-SEEDS = dict(eagle2=335, std=1, odd=1)    # results of the search below, so that regenerating takes seconds (delete an entry to search again)
+SEEDS = dict(eagle2=86, std=15, odd=7)    # results of the search below, so that regenerating takes seconds (delete an entry to search again)
 STEPS = [13, 1, 4]          # prompt, then accepted-token counts of later steps (the head's KV cache grows)
-NOISE, TRIALS = 5e-4, 8
+NOISE, TRIALS = 2e-3, 8
 
 
 class TopkTrace:
@@ -130,11 +132,24 @@ def eagle_run(seed, choices, noise=0.0, trial=0, want_trace=False):
     return (outs, buf, traces) if want_trace else (outs, buf)
 
 
+def path_set(toks, mask, pos):
+    """the draft as a set of root->node token paths: what verification sees, whatever the node numbering"""
+    out = set()
+    for i in range(len(toks)):
+        anc = sorted(np.nonzero(mask[i])[0].tolist(), key=lambda j: int(pos[j]))
+        out.add(tuple(int(toks[j]) for j in anc))
+    return out
+
+
+def same_tree(a, b):
+    return all(path_set(ca[0], ca[1], ca[2]) == path_set(cb[0], cb[1], cb[2]) for ca, cb in zip(a, b))
+
+
 def same(a, b):
     return all(all(np.array_equal(x, y) for x, y in zip(ca, cb)) if isinstance(ca, tuple) else np.array_equal(ca, cb) for ca, cb in zip(a, b))
 
 
-def pick_seed(run, limit=400, known=None):
+def pick_seed(run, limit=400, known=None, same=same):
     """first seed whose outputs survive TRIALS noisy runs of the reference; else the most robust one seen.  `known` = the seed
     an earlier run of this search found (SEEDS below): it is re-checked instead of searched for."""
     best = (-1, None)
@@ -156,7 +171,7 @@ def put_trace(out, prefix, calls):
 
 def main():
     # ---- EAGLE-2 ------------------------------------------------------------------------------------------------
-    seed, ok = pick_seed(lambda s, n, t: eagle2_run(s, n, t), known=SEEDS.get("eagle2"))
+    seed, ok = pick_seed(lambda s, n, t: eagle2_run(s, n, t), known=SEEDS.get("eagle2"), same=same_tree)
     base, traces = eagle2_run(seed, want_trace=True)
     out = {"seed": seed, "steps": np.array(STEPS), "noise": NOISE, "trials": TRIALS, "robust_trials": ok}
     for ci, (toks, mask, pos, ret) in enumerate(base):

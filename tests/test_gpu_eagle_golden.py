@@ -13,10 +13,14 @@ Two layers:
     write, tree attention) on the head_dim-128 fixtures eagle2_hd128.npz / eagle_hd128.npz (fp16-representable seeded weights,
     reference run in fp32).  Integer results must be identical wherever the reference's decision is decided by more than the
     fp16 tolerance below: every torch.topk call of the reference was recorded (values, indices, runner-up), the device path
-    records the same sequence, and they are compared call by call.  A difference is accepted only at a position whose recorded
-    margin (value[p] - value[p+1]) is <= 2 * TOL_FP16; before that position values agree within TOL_FP16.  The fixtures' seeds
-    were chosen so that the recorded drafts survive 5e-4 relative noise, so most calls match end to end; the test requires at
-    least one fully identical call per fixture and prints what happened to the others.
+    records the same sequence, and they are compared call by call.  Every recorded call must end in one of three ways:
+      (a) identical: same tokens, same parent numbering, same mask / positions / retrieve rows;
+      (b) EAGLE-2 only -- the same TREE (set of root->node token paths) under another node numbering: two near-equal candidates
+          inside one row swapped ranks, which renumbers nodes but changes nothing the verify step can see;
+      (c) a different draft whose FIRST differing top-k decision is a near-tie of the reference: recorded margin
+          (value[p] - value[p+1]) <= 2 * TOL_FP16, with all values before it within TOL_FP16.
+    Anything else fails.  The fixtures' seeds were chosen so that the recorded drafts survive 2e-3 relative noise (as trees for
+    EAGLE-2, exactly for EAGLE v1), so (a)/(b) is the expected outcome; at least one call per fixture must end in (a) or (b).
 
 TOL_FP16 = 0.1 absolute on head logits / log-probabilities.  The head's logits reach |x| ~ 64-128 here, where fp16 values are
 0.0625 apart (the device head's logits are fp16 GEMM outputs), and its output states carry ~1e-3 relative error on top."""
@@ -157,29 +161,42 @@ def device_head_for(seed, head_cls):
     return head, runner, DeviceHead(head, runner)
 
 
+def path_set(tokens, mask, pos):
+    """the draft as a set of root->node token paths: what verification sees, whatever the node numbering"""
+    out = set()
+    for i in range(len(tokens)):
+        anc = sorted(np.nonzero(np.asarray(mask)[i])[0].tolist(), key=lambda j: int(pos[j]))
+        out.add(tuple(int(tokens[j]) for j in anc))
+    return out
+
+
 def test_eagle2_device_head_follows_recorded_reference():
     from samd.tree_model.eagle2 import Eagle2Head
     z = np.load(os.path.join(HERE, "golden", "eagle2_hd128.npz"))
     seed = int(z["seed"])
     head, runner, dh = device_head_for(seed, Eagle2Head)
     dh.reset()
-    exact, notes = 0, []
+    good, notes = 0, []
     for ci, t in enumerate(z["steps"].tolist()):
         hs, ids = call_inputs(seed, ci, t)
         head.trace = []
         toks, parents = head.topk_generate_device(dh, torch.from_numpy(hs).cuda().half(), torch.from_numpy(ids).cuda())
         torch.cuda.synchronize()
         dev_calls, head.trace = head.trace, None
-        where = follow(ref_trace(z, f"c{ci}"), dev_calls, last_is_a_set=True)
-        if where is not None:
-            notes.append(f"call {ci}: near-tie at top-k call {where[0]} row {where[1]} pos {where[2]} (recorded margin {where[3]:.4f})")
-            continue
-        assert toks.tolist() == z[f"c{ci}:tokens"].tolist()
         mask, pos, ret = tree_buffers(parents.tolist())
-        assert mask.tolist() == z[f"c{ci}:mask"].tolist() and pos.tolist() == z[f"c{ci}:pos"].tolist() and ret.tolist() == z[f"c{ci}:retrieve"].tolist()
-        exact += 1
-    print(f"eagle2 device head: {exact}/{len(z['steps'])} recorded calls identical end to end; " + "; ".join(notes))
-    assert exact >= 1
+        if (toks.tolist() == z[f"c{ci}:tokens"].tolist() and mask.tolist() == z[f"c{ci}:mask"].tolist() and pos.tolist() == z[f"c{ci}:pos"].tolist()
+                and ret.tolist() == z[f"c{ci}:retrieve"].tolist()):
+            notes.append(f"call {ci}: identical")
+            good += 1
+        elif path_set(toks.tolist(), mask, pos) == path_set(z[f"c{ci}:tokens"], z[f"c{ci}:mask"], z[f"c{ci}:pos"]):
+            notes.append(f"call {ci}: same tree, other numbering")
+            good += 1
+        else:
+            where = follow(ref_trace(z, f"c{ci}"), dev_calls, last_is_a_set=True)       # asserts that the first difference is a near-tie
+            assert where is not None, f"call {ci}: drafts differ although every recorded decision matches"
+            notes.append(f"call {ci}: near-tie at top-k call {where[0]} row {where[1]} pos {where[2]} (recorded margin {where[3]:.4f})")
+    print(f"eagle2 device head vs recorded reference: " + "; ".join(notes))
+    assert good >= 1
 
 
 @pytest.mark.parametrize("name", ["std", "odd"])
@@ -200,11 +217,12 @@ def test_eagle_v1_device_head_follows_recorded_reference(name):
         draft, _ = plug.gen_draft(int(ids[t]))
         torch.cuda.synchronize()
         dev_calls, head.trace = head.trace, None
-        where = follow(ref_trace(z, f"{name}:c{ci}"), dev_calls)
-        if where is not None:
-            notes.append(f"call {ci}: near-tie at top-k call {where[0]} row {where[1]} pos {where[2]} (recorded margin {where[3]:.4f})")
+        if draft == z[f"{name}:c{ci}:draft"].tolist():
+            notes.append(f"call {ci}: identical")
+            exact += 1
             continue
-        assert draft == z[f"{name}:c{ci}:draft"].tolist()
-        exact += 1
-    print(f"eagle v1 [{name}] device head: {exact}/{len(z['steps'])} recorded calls identical end to end; " + "; ".join(notes))
+        where = follow(ref_trace(z, f"{name}:c{ci}"), dev_calls)                          # asserts that the first difference is a near-tie
+        assert where is not None, f"call {ci}: drafts differ although every recorded decision matches"
+        notes.append(f"call {ci}: near-tie at top-k call {where[0]} row {where[1]} pos {where[2]} (recorded margin {where[3]:.4f})")
+    print(f"eagle v1 [{name}] device head vs recorded reference: " + "; ".join(notes))
     assert exact >= 1

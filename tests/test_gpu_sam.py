@@ -48,7 +48,7 @@ def test_static_walk_golden(golden):
         assert cur[0].cpu().tolist() == case["walk"][-1]
 
 
-@pytest.mark.parametrize("vocab,B,T", [(6, 300, 40), (200, 1000, 64), (5000, 4096, 32)])
+@pytest.mark.parametrize("vocab,B,T", [(6, 300, 40), (200, 1000, 64), (5000, 4096, 32), (70000, 2048, 32)])   # >= 65535: 4-token chain words
 def test_static_walk_batched_vs_oracle(vocab, B, T):
     rng = np.random.default_rng(vocab)
     docs = [markov_stream(rng, 300, vocab=vocab) for _ in range(30)] + [[i] for i in range(vocab)]
@@ -79,6 +79,35 @@ def test_static_walk_batched_vs_oracle(vocab, B, T):
     before = cur.clone()
     prod.walk(cur, dev(toks), commit=False)
     assert torch.equal(cur, before)
+
+
+@pytest.mark.parametrize("base", [3, 66000])
+def test_static_walk_long_runs_use_chain_words(base):
+    """a document of all-distinct tokens is one non-branching run: a copied query is served from chain words (8 u16 / 4 u32 tokens
+    per 16-byte load, csrc/samd_common.h) with reloads at word boundaries; mismatches in the middle of a word, at its first and
+    last token, and ids that collide with the word's terminator must fall back to the nodes.  Every (index, length) vs the oracle."""
+    doc = list(range(base, base + 400))
+    docs = [doc, doc[100:180] + doc[20:60], [base + 7, base + 9, base + 8]]
+    prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    ora = O.StaticSAM.build(docs, 2)
+    rng = np.random.default_rng(base)
+    streams = []
+    for off in range(0, 24):
+        q = doc[5 + off:5 + off + 70]
+        for bad in (off % 9, 8 + off % 11, 31, 32 + off % 7):          # mismatches at assorted phases of the 8- / 4-token words
+            q[bad] = [base + 399, 65535, 0xFFFF_FFFF - (1 << 32), -5, base + 1000][(off + bad) % 5]
+        streams.append(q)
+    toks = np.array(streams, dtype=np.int64).astype(np.int32).T.copy()      # [T, B]
+    T, B = toks.shape
+    cur = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    trace = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    prod.walk(cur, dev(toks), commit=True, trace=trace)
+    got = trace.cpu().numpy()
+    for b in range(B):
+        i, l = 0, 0
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[t, b]))
+            assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (b, t)
 
 
 def test_static_walk_empty_and_ragged():
