@@ -283,25 +283,36 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                         const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
 
-/* The attention block of one decoder layer in ONE launch: RoPE on q and k, the K/V row write of SamdStaticCache.update
- * (SO/cache.py:103-115) at [write_pos, write_pos + n), tree-mask attention (SO/model_patch/llama.py:82-96 + SDPA) and the
- * merge of the KV splits -- what samd_rope_kv_write + samd_tree_attention do in three launches.
+/* The attention block of one decoder layer in ONE launch (csrc/attn_kernels.hip): RoPE on q and k, the K/V row write of
+ * SamdStaticCache.update (SO/cache.py:103-115) at [write_pos, write_pos + n), tree-mask attention (SO/model_patch/llama.py:82-96 +
+ * SDPA) and the merge of the per-tile partial softmaxes -- what samd_rope_kv_write + samd_tree_attention do in three launches.
  *   d_qkv: the q|k|v projection's output [rows >= n_q_pad][(H + 2 H_kv) * D] of `dtype`, or (n_partials > 0) the streaming
  *          GEMM's fp32 partial sums [n_partials][partial_stride] of the same layout (summed, then rounded to dtype);
- *   d_cs:  float [n_q_pad][D]: cos (first D/2) and sin (last D/2) of every row's position -- samd_rope_rows, once per forward;
+ *   d_cs:  float [n_q_pad][D]: cos (first D/2) and sin (last D/2) of every row's position -- samd_rope_rows, once per forward
+ *          (position of row r = *d_base + d_rel_pos[r], clamped to the table);
+ *   d_k_cache [H_kv][max_len][D];  d_vt_cache [H_kv][D][max_len] -- V is cached TRANSPOSED (samd_rope_kv_write_vt and
+ *          samd_kv_compact*_vt write / compact that layout); max_len must be a multiple of 8;
  *   visibility: keys < *d_visible_len are visible to every row; key *d_visible_len + j is visible to row i iff bit j of
  *          d_mask[i] is set.  d_visible_len == NULL means *d_write_pos (the base model's verify: bit j = new row j).  A draft
  *          head's tree level keeps the rows of earlier levels in its cache: visible_len = accepted length, write_pos beyond it.
- *   d_workspace: samd_tree_attention_fused_workspace() bytes; its first 1024 bytes are per-head arrival counters that must be
- *          ZERO before the first launch (every launch leaves them zero).
- * out [n_q_pad][H][D], rows >= n zeroed.  head_dim 128, f16 / bf16, n_q_pad <= 64, H <= 256. */
-int64_t samd_tree_attention_fused_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim);
+ * out [n_q_pad][H][D], rows >= n zeroed.  head_dim 128, f16 / bf16, n_q_pad <= 64. */
 int samd_rope_rows(const int32_t *d_rel_pos, const int32_t *d_base, const float *d_cos, const float *d_sin, float *d_cs, int32_t rows,
                    int32_t head_dim, int32_t max_pos, void *stream);
-int samd_tree_attention_fused(const void *d_qkv, int32_t n_partials, int64_t partial_stride, const float *d_cs, void *d_k_cache, void *d_v_cache,
-                              void *d_out, int32_t dtype, int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
-                              const uint64_t *d_mask, const int32_t *d_write_pos, const int32_t *d_visible_len, const int32_t *d_n, float scale,
-                              void *d_workspace, int64_t workspace_bytes, void *stream);
+int samd_attention_block(const void *d_qkv, int32_t n_partials, int64_t partial_stride, const float *d_cs, void *d_k_cache, void *d_vt_cache,
+                         void *d_out, int32_t dtype, int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                         const uint64_t *d_mask, const int32_t *d_write_pos, const int32_t *d_visible_len, const int32_t *d_n, float scale,
+                         void *stream);
+/* samd_rope_kv_write with the V cache transposed ([H_kv][D][max_len]); d_vt_cache may be NULL (q and K only).
+ * samd_kv_compact / samd_kv_compact_indices over a pointer table whose LAST n_transposed tensors are transposed (2-byte elements):
+ * select_indices (SO/cache.py:118-133) for the K tensors followed by the V^T tensors. */
+int samd_rope_kv_write_vt(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                          const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_vt_cache, int32_t rows,
+                          int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
+                          int32_t n_partials, int64_t partial_stride, void *stream);
+int samd_kv_compact_vt(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_transposed, int32_t n_heads, int64_t max_len,
+                       int32_t head_dim, int32_t elem_bytes, void *stream);
+int samd_kv_compact_indices_vt(void *const *d_tensors, int32_t n_tensors, int32_t n_transposed, int32_t n_heads, int64_t max_len, int32_t head_dim,
+                               int32_t elem_bytes, int32_t start, const int32_t *d_indices, int32_t accept, void *stream);
 
 /* ---- memory-bound glue of the verify forward (between the library GEMMs).  The arithmetic of the
  * forward lives in HuggingFace transformers in the reference (third party, not vendored; call sites

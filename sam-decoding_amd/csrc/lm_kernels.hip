@@ -124,7 +124,7 @@ template <typename T>
 __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel_pos, const int *__restrict__ d_L,
                           const int *__restrict__ d_n, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
                           T *__restrict__ q_out, T *__restrict__ k_cache, T *__restrict__ v_cache, int H, int Hkv, int D,
-                          long long max_len, int max_pos, int n_part, long long part_stride) {
+                          long long max_len, int max_pos, int n_part, long long part_stride, int v_transposed) {
     const int r = blockIdx.x, hh = blockIdx.y, j = threadIdx.x, half = D >> 1;
     // the operand loads do not depend on n / L: they are issued first, together with the scalars and this row's relative
     // position, so that the kernel is two memory round trips (operands + scalars, then cos/sin) instead of four
@@ -149,9 +149,15 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
     }
     if (r >= n) return;
     if (L + r >= max_len) return;                              // never write past the cache (the host guard breaks earlier)
-    if (hh >= H + Hkv) {                                       // V: plain copy
-        T *dst = v_cache + ((size_t)(hh - H - Hkv) * max_len + L + r) * D;
-        dst[j] = (T)x1; dst[j + half] = (T)x2;
+    if (hh >= H + Hkv) {                                       // V: plain copy (row-major cache, or the transposed one of samd_attention_block)
+        if (!v_cache) return;
+        if (v_transposed) {
+            T *dst = v_cache + (size_t)(hh - H - Hkv) * D * max_len + L + r;
+            dst[(size_t)j * max_len] = (T)x1; dst[(size_t)(j + half) * max_len] = (T)x2;
+        } else {
+            T *dst = v_cache + ((size_t)(hh - H - Hkv) * max_len + L + r) * D;
+            dst[j] = (T)x1; dst[j + half] = (T)x2;
+        }
         return;
     }
     int pos = L + rel; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
@@ -214,19 +220,36 @@ int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_o
     return SAMD_OK;
 }
 
+static int rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                         const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
+                         int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
+                         int32_t n_partials, int64_t partial_stride, int32_t v_transposed, void *stream) {
+    if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || !d_cos || !d_sin || !d_q_out || !d_k_cache || (!d_v_cache && !v_transposed) || rows < 1 ||
+        head_dim % 2 != 0 || head_dim > 2048) { samd_set_error("samd_rope_kv_write: invalid argument"); return SAMD_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(rows, n_heads + 2 * n_kv_heads), block(head_dim / 2);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed);
+    else { samd_set_error("samd_rope_kv_write: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
 int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
                        const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
                        int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
                        int32_t n_partials, int64_t partial_stride, void *stream) {
-    if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || !d_cos || !d_sin || !d_q_out || !d_k_cache || !d_v_cache || rows < 1 ||
-        head_dim % 2 != 0 || head_dim > 2048) { samd_set_error("samd_rope_kv_write: invalid argument"); return SAMD_E_INVALID; }
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(rows, n_heads + 2 * n_kv_heads), block(head_dim / 2);
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride);
-    else { samd_set_error("samd_rope_kv_write: dtype must be f16/bf16"); return SAMD_E_INVALID; }
-    LAUNCHCHK();
-    return SAMD_OK;
+    return rope_kv_write(d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, d_q_out, d_k_cache, d_v_cache, rows, n_heads, n_kv_heads, head_dim, max_len,
+                         max_pos, dtype, n_partials, partial_stride, 0, stream);
+}
+
+// the same with the V cache transposed ([H_kv][D][max_len], the layout samd_attention_block reads); d_vt_cache may be NULL (q and K only)
+int samd_rope_kv_write_vt(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                          const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_vt_cache, int32_t rows,
+                          int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
+                          int32_t n_partials, int64_t partial_stride, void *stream) {
+    return rope_kv_write(d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, d_q_out, d_k_cache, d_vt_cache, rows, n_heads, n_kv_heads, head_dim, max_len,
+                         max_pos, dtype, n_partials, partial_stride, 1, stream);
 }
 
 int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,

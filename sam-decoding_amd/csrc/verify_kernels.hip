@@ -68,14 +68,33 @@ __global__ __launch_bounds__(1024) void k_argmax_rows(const T *__restrict__ logi
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_kv_compact(void *const *__restrict__ tensors, const int *__restrict__ verdict,
                                                     const int *__restrict__ kv_index, int n_heads, long long max_len, int row_bytes,
-                                                    int h_start, int h_accept) {
+                                                    int h_start, int h_accept, int n_row_major) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int a = h_accept, start = h_start;
     if (verdict) {                                         // device-side verdict of the fused step
         if (!verdict[V_IS_TREE]) return;                   // sequence drafts keep their rows in place
         a = verdict[V_ACCEPT]; start = verdict[V_KV_START];
     }
-    unsigned char *base = (unsigned char *)tensors[blockIdx.x / n_heads] + (size_t)(blockIdx.x % n_heads) * max_len * row_bytes;
+    const int t = blockIdx.x / n_heads;
+    unsigned char *base = (unsigned char *)tensors[t] + (size_t)(blockIdx.x % n_heads) * max_len * row_bytes;
+    if (t >= n_row_major) {
+        // a TRANSPOSED tensor [head][D][max_len] of 2-byte elements (the V cache of samd_attention_block): "row" start + idx[j] is
+        // the column of every one of the D lines; gather all of them first, then scatter (same overlap rule as below)
+        const int D = row_bytes >> 1, total = a * D;
+        unsigned short *lds = reinterpret_cast<unsigned short *>(smem);
+        unsigned short *col = reinterpret_cast<unsigned short *>(base);
+        for (int c = threadIdx.x; c < total; c += blockDim.x) {
+            const int d = c / a, j = c - d * a;
+            lds[c] = col[(size_t)d * max_len + start + kv_index[j]];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < total; c += blockDim.x) {
+            const int d = c / a, j = c - d * a;
+            if (kv_index[j] == j) continue;
+            col[(size_t)d * max_len + start + j] = lds[c];
+        }
+        return;
+    }
     const int chunks = row_bytes >> 4, total = a * chunks;
     uint4 *lds = reinterpret_cast<uint4 *>(smem);
     for (int c = threadIdx.x; c < total; c += blockDim.x) {
@@ -103,7 +122,6 @@ __global__ __launch_bounds__(256) void k_kv_compact(void *const *__restrict__ te
 #define ATT_D 128
 #define VT_STRIDE (ATT_TILE + 8)      // halfs per Vt row: 144 B keeps 16-B alignment, spreads banks
 #define P_STRIDE (ATT_TILE + 8)
-#define KS_STRIDE (ATT_D + 8)         // halfs per Ks row: 272 B, 16 rows of one ds_read_b128 land in different banks
 
 template <typename TT> struct Mfma;
 template <> struct Mfma<F16> {
@@ -321,438 +339,6 @@ __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ 
 }
 
 // ================================================================================================
-// Fused form of the attention block (what LlamaAttention.forward does between q/k/v_proj and o_proj under the reference's
-// patched mask, SO/model_patch/llama.py:82-96, with SamdStaticCache.update, SO/cache.py:103-115): ONE launch per layer does
-//   RoPE on q and k, the K/V row write at [Lw, Lw + n), tree-mask attention over the cached keys + the n new ones, and the
-//   merge of the KV splits -- instead of k_rope_kv + k_tree_attention + k_attn_combine (three launches, two of them one
-//   memory round trip long).
-// * q/k/v come straight from the q|k|v projection's output (a T tensor, or the streaming GEMM's fp32 split-K partials).
-// * cos/sin of every row's position are prepared once per forward (k_rope_rows), so nothing here waits for L before it can
-//   load them.
-// * The n new keys are one extra tile (index ceil(Lw / 64)) whose K fragments / V rows are built from the projection output
-//   in registers; the workgroups of the first query head of each KV group also store them to the cache.  Tiles over cached
-//   keys never see rows >= Lw (masked / zeroed), so nobody reads what another workgroup is writing.
-// * Split merge: every (head, split) workgroup writes its partial (m, l, O) with agent-scope stores (write-through: the eight
-//   XCD L2s are not coherent with each other), then bumps a per-head arrival counter; the workgroup that arrives last reads
-//   all partials of its head with agent-scope loads, merges them and resets the counter.  No fence, no second launch.
-// * Visible prefix: keys < Lvis are visible to every row; key Lvis + j is visible to row i iff bit j of mask[i] is set.
-//   The base model's verify has Lvis = Lw = L (bit j = new row j).  A draft head's tree level has Lvis = accepted length and
-//   Lw = Lvis + rows of the earlier levels, which stay in its cache (bits address earlier-level rows and the new ones alike).
-// ================================================================================================
-template <typename E>
-__global__ __launch_bounds__(256) void k_rope_rows(const int *__restrict__ rel_pos, const int *__restrict__ d_base, const float *__restrict__ cos_t,
-                                                   const float *__restrict__ sin_t, float *__restrict__ cs, int rows, int max_pos) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = i >> 6, j = i & 63;
-    if (r >= rows) return;
-    int pos = d_base[0] + rel_pos[r];
-    pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
-    cs[r * ATT_D + j] = cos_t[(size_t)pos * 64 + j];
-    cs[r * ATT_D + 64 + j] = sin_t[(size_t)pos * 64 + j];
-}
-
-__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-#define ATT_SLOTS (ATT_SPLITS + 1)    // partial-result slots per head: ATT_SPLITS splits over the cached keys + the tile of the new keys
-
-// merge of the partial (m, l, O) of one head's slots: 8 rows per pass, 32 threads per row, 4 output columns per thread; all loads
-// of a pass are in flight together.  AGENT = read with agent-scope loads (the in-kernel merge: the partials were written by
-// other workgroups of the same launch and the XCD L2s are not coherent with each other).
-template <typename E, bool AGENT>
-__device__ __forceinline__ void merge_head(const float *__restrict__ wsh, E *__restrict__ out, int h, int tid, int n, int n_q_pad, int n_heads,
-                                           int used_c, bool has_fresh) {
-    for (int r0 = 0; r0 < n_q_pad; r0 += 8) {
-        const int row = r0 + (tid >> 5), d0 = 4 * (tid & 31);
-        if (row >= n_q_pad) continue;
-        E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d0;
-        if (row >= n) { *reinterpret_cast<uint2 *>(dst) = make_uint2(0, 0); continue; }
-        float mv[ATT_SLOTS], lv[ATT_SLOTS], pv[ATT_SLOTS][4];
-#pragma unroll
-        for (int sp = 0; sp < ATT_SLOTS; sp++) {
-            const bool live = sp < ATT_SPLITS ? sp < used_c : has_fresh;
-            if (!live) continue;
-            const float *p = wsh + ((size_t)sp * n_q_pad + row) * (ATT_D + 2);
-            if (AGENT) {
-                mv[sp] = ld_agent(p + ATT_D); lv[sp] = ld_agent(p + ATT_D + 1);
-#pragma unroll
-                for (int i = 0; i < 4; i++) pv[sp][i] = ld_agent(p + d0 + i);
-            } else {
-                const float2 ml = *reinterpret_cast<const float2 *>(p + ATT_D);
-                const float4 v = *reinterpret_cast<const float4 *>(p + d0);          // (ATT_D + 2) * 4 bytes per row keeps 8-byte alignment only
-                mv[sp] = ml.x; lv[sp] = ml.y; pv[sp][0] = v.x; pv[sp][1] = v.y; pv[sp][2] = v.z; pv[sp][3] = v.w;
-            }
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int sp = 0; sp < ATT_SLOTS; sp++) { const bool live = sp < ATT_SPLITS ? sp < used_c : has_fresh; if (live) M = fmaxf(M, mv[sp]); }
-        float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
-#pragma unroll
-        for (int sp = 0; sp < ATT_SLOTS; sp++) {
-            const bool live = sp < ATT_SPLITS ? sp < used_c : has_fresh;
-            if (!live || mv[sp] == -INFINITY) continue;
-            const float wgt = exp2f(mv[sp] - M);
-            den += wgt * lv[sp];
-#pragma unroll
-            for (int i = 0; i < 4; i++) num[i] += wgt * pv[sp][i];
-        }
-        E e[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) e[i] = (E)(den > 0.f ? num[i] / den : 0.f);
-        *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(&e[0]);
-    }
-}
-
-// grid (heads, ATT_SPLITS + 1): split s < ATT_SPLITS owns the 64-key tiles s, s + ATT_SPLITS, ... of the CACHED keys [0, Lw);
-// split ATT_SPLITS owns the n new keys.  Which workgroup handles the new keys is thus known from the block index, so its
-// source rows (the projection output) are requested at kernel entry like every other first tile -- not after L has arrived.
-template <typename TT, bool PART, bool MERGE, bool FRESH>
-__device__ __forceinline__ void attn_fused_body(const typename TT::elem *__restrict__ qkv, int n_part, long long part_stride,
-                                                const float *__restrict__ cs, typename TT::elem *__restrict__ kc,
-                                                typename TT::elem *__restrict__ vc, float *__restrict__ ws,
-                                                unsigned *__restrict__ counters, typename TT::elem *__restrict__ out,
-                                                int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
-                                                const unsigned long long *__restrict__ mask, const int *__restrict__ d_Lw,
-                                                const int *__restrict__ d_Lvis, const int *__restrict__ d_n, float scale_log2,
-                                                typename TT::elem *Vt, typename TT::elem *Pw, typename TT::elem *Ks, int &s_last) {
-    typedef typename TT::elem E;
-    typedef typename TT::vec8 V8;
-    const int h = blockIdx.x, split = blockIdx.y;
-    constexpr bool fresh = FRESH;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lg = l >> 4;
-    const int row_base = 16 * w;
-    const int group = n_heads / n_kv_heads, kvh = h / group;
-    const int W = (n_heads + 2 * n_kv_heads) * ATT_D;                 // elements per row of the projection output
-    const float *part = reinterpret_cast<const float *>(qkv);
-
-    // 8 consecutive values of the projection output at element offset `off`, as floats of T-rounded values
-    auto ld8 = [&](size_t off, float (&x)[8]) {
-        if constexpr (!PART) {
-            const uint4 raw = *reinterpret_cast<const uint4 *>(qkv + off);
-            const E *e = reinterpret_cast<const E *>(&raw);
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = (float)e[i];
-        } else {
-            float acc[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) acc[i] = 0.f;
-            const float *p0 = part + off;
-            const unsigned pst = (unsigned)part_stride;
-            for (int s0 = 0; s0 < n_part; s0 += 2) {                 // 4 loads in flight per group
-                float4 a[2], b[2];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    if (s0 + k >= n_part) continue;
-                    a[k] = *reinterpret_cast<const float4 *>(p0 + (unsigned)(s0 + k) * pst);
-                    b[k] = *reinterpret_cast<const float4 *>(p0 + (unsigned)(s0 + k) * pst + 4);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    if (s0 + k >= n_part) continue;
-                    acc[0] += a[k].x; acc[1] += a[k].y; acc[2] += a[k].z; acc[3] += a[k].w;
-                    acc[4] += b[k].x; acc[5] += b[k].y; acc[6] += b[k].z; acc[7] += b[k].w;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = (float)(E)acc[i];      // rounded like the GEMM's own output (k_rope_kv does the same)
-        }
-    };
-    // RoPE of 8 elements with their partners 64 further on (HF rotate_half; arithmetic identical to k_rope_kv): cr = the row's
-    // cos values at the elements' indices (sin 64 floats further)
-    auto rope8 = [&](const float (&x1)[8], const float (&x2)[8], const float *cr, uint4 &lo_out, uint4 &hi_out) {
-        const float4 c0 = *reinterpret_cast<const float4 *>(cr), c1 = *reinterpret_cast<const float4 *>(cr + 4);
-        const float4 s0 = *reinterpret_cast<const float4 *>(cr + 64), s1 = *reinterpret_cast<const float4 *>(cr + 68);
-        const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        E lo[8], hi[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            lo[i] = (E)(x1[i] * c[i] - x2[i] * sn[i]);
-            hi[i] = (E)(x2[i] * c[i] + x1[i] * sn[i]);
-        }
-        lo_out = *reinterpret_cast<const uint4 *>(&lo[0]);
-        hi_out = *reinterpret_cast<const uint4 *>(&hi[0]);
-    };
-
-    // ---- loads that need neither L nor n: mask rows, this workgroup's first tile, this wave's rotated Q
-    unsigned long long mrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) mrow[r] = mask[row_base + 4 * lg + r];
-    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
-    const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
-    const bool may_be_active = row_base < n_q_pad;
-    uint4 kraw[4][4], vra[2], vrb[2];
-    auto load_k = [&](int key0) {
-#pragma unroll
-        for (int st = 0; st < 4; st++) {
-            int key = key0 + 16 * st + lr;
-            key = key < (int)max_len ? key : (int)max_len - 1;
-            const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) kraw[st][kk] = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
-        }
-    };
-    auto load_v = [&](int key0) {
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
-            int ka = key0 + 2 * p, kb = ka + 1;
-            ka = ka < (int)max_len ? ka : (int)max_len - 1; kb = kb < (int)max_len ? kb : (int)max_len - 1;
-            vra[it] = *reinterpret_cast<const uint4 *>(vbase + (size_t)ka * ATT_D + d0);
-            vrb[it] = *reinterpret_cast<const uint4 *>(vbase + (size_t)kb * ATT_D + d0);
-        }
-    };
-    // the fresh split's K rows: thread (j = tid / 4, e0 = 16 (tid % 4)) rotates elements e0 .. + 16 of new row j with their partners
-    const int fj = tid >> 2, fe0 = 16 * (tid & 3);
-    uint4 fk_lo[2], fk_hi[2];                               // rotated K of row fj: elements e0..+8, e0+8..+8 and the same + 64
-    if (!fresh) {
-        if (may_be_active) load_k(split * ATT_TILE);
-        load_v(split * ATT_TILE);
-    } else {
-        if (fj < n_q_pad) {
-            const size_t base = (size_t)fj * W + (n_heads + kvh) * ATT_D + fe0;
-#pragma unroll
-            for (int v8 = 0; v8 < 2; v8++) {
-                float x1[8], x2[8];
-                ld8(base + 8 * v8, x1); ld8(base + 64 + 8 * v8, x2);
-                rope8(x1, x2, cs + fj * ATT_D + fe0 + 8 * v8, fk_lo[v8], fk_hi[v8]);
-            }
-        } else { fk_lo[0] = fk_lo[1] = fk_hi[0] = fk_hi[1] = make_uint4(0, 0, 0, 0); }
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int j = 2 * p + half;
-                uint4 raw = make_uint4(0, 0, 0, 0);
-                if (j < n_q_pad) {
-                    float x[8];
-                    ld8((size_t)j * W + (n_heads + n_kv_heads + kvh) * ATT_D + d0, x);
-                    E e[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) e[i] = (E)x[i];
-                    raw = *reinterpret_cast<const uint4 *>(&e[0]);
-                }
-                if (half == 0) vra[it] = raw; else vrb[it] = raw;
-            }
-        }
-    }
-    uint4 qraw[4];
-    {
-        const int qrow = row_base + lr;
-        if (qrow < n_q_pad) {
-#pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                float x1[8], x2[8];
-                ld8((size_t)qrow * W + h * ATT_D + 32 * kk + 8 * lg, x1);
-                ld8((size_t)qrow * W + h * ATT_D + 32 * kk + 8 * lg + 64, x2);
-                rope8(x1, x2, cs + qrow * ATT_D + 32 * kk + 8 * lg, qraw[kk], qraw[kk + 2]);
-            }
-        } else { qraw[0] = qraw[1] = qraw[2] = qraw[3] = make_uint4(0, 0, 0, 0); }
-    }
-    const int Lw = d_Lw[0];
-    const int Lvis = d_Lvis ? d_Lvis[0] : Lw;
-    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
-    const int voff = Lw - Lvis;                          // mask bit of new row j is voff + j
-    const int ntc = (Lw + ATT_TILE - 1) / ATT_TILE;      // tiles over the cached keys
-    const bool has_fresh = n > 0;
-    const int used_c = ntc < 1 ? (has_fresh ? 0 : 1) : (ntc < ATT_SPLITS ? ntc : ATT_SPLITS);   // with nothing at all to do split 0 still runs, so every head has a merger
-    if (fresh ? !has_fresh : split >= used_c) return;
-    const bool active = row_base < n;
-#pragma unroll
-    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) mrow[r] = 0ull;
-    const bool writer = (h % group) == 0;
-
-    float m_run[4], l_run[4];
-    floatx4 o[8];
-#pragma unroll
-    for (int r = 0; r < 4; r++) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
-#pragma unroll
-    for (int dt = 0; dt < 8; dt++) o[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
-    E *Pmine = Pw + w * 16 * P_STRIDE;
-
-    const int t_end = fresh ? 1 : ntc;
-    for (int t = fresh ? 0 : split; t < t_end; t += ATT_SPLITS) {
-        const int key0 = fresh ? Lw : t * ATT_TILE;
-        if (!fresh) {
-            if (t != split && active) load_k(key0);
-        } else {
-            // the new keys' rotated K rows: to the cache (first query head of the KV group) and to Ks for the MFMA fragments
-            const bool live_row = fj < n;
-            if (!live_row) { fk_lo[0] = fk_lo[1] = fk_hi[0] = fk_hi[1] = make_uint4(0, 0, 0, 0); }
-            if (writer && live_row && (long long)Lw + fj < max_len) {
-                E *kp = kc + ((size_t)kvh * max_len + Lw + fj) * ATT_D + fe0;
-                *reinterpret_cast<uint4 *>(kp) = fk_lo[0]; *reinterpret_cast<uint4 *>(kp + 8) = fk_lo[1];
-                *reinterpret_cast<uint4 *>(kp + 64) = fk_hi[0]; *reinterpret_cast<uint4 *>(kp + 72) = fk_hi[1];
-            }
-            E *kd = Ks + fj * KS_STRIDE + fe0;
-            *reinterpret_cast<uint4 *>(kd) = fk_lo[0]; *reinterpret_cast<uint4 *>(kd + 8) = fk_lo[1];
-            *reinterpret_cast<uint4 *>(kd + 64) = fk_hi[0]; *reinterpret_cast<uint4 *>(kd + 72) = fk_hi[1];
-        }
-        __syncthreads();                                   // previous tile's Vt / Pw reads are done; Ks is written
-        if (!fresh) {
-            if (t != split) load_v(key0);
-        } else {
-#pragma unroll
-            for (int st = 0; st < 4; st++)
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++)
-                    kraw[st][kk] = *reinterpret_cast<const uint4 *>(Ks + (16 * st + lr) * KS_STRIDE + 32 * kk + 8 * lg);
-            if (writer) {
-#pragma unroll
-                for (int it = 0; it < 2; it++) {
-                    const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
-                    if (2 * p < n && (long long)Lw + 2 * p < max_len) *reinterpret_cast<uint4 *>(vc + ((size_t)kvh * max_len + Lw + 2 * p) * ATT_D + d0) = vra[it];
-                    if (2 * p + 1 < n && (long long)Lw + 2 * p + 1 < max_len) *reinterpret_cast<uint4 *>(vc + ((size_t)kvh * max_len + Lw + 2 * p + 1) * ATT_D + d0) = vrb[it];
-                }
-            }
-        }
-        // ---- stage V^T (key pairs packed per dword); keys beyond the tile's live range are zero
-        const int live = fresh ? n : (Lw - key0 < ATT_TILE ? Lw - key0 : ATT_TILE);
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
-            const uint4 ra = 2 * p < live ? vra[it] : make_uint4(0, 0, 0, 0), rb = 2 * p + 1 < live ? vrb[it] : make_uint4(0, 0, 0, 0);
-            const unsigned short *ea = reinterpret_cast<const unsigned short *>(&ra);
-            const unsigned short *eb = reinterpret_cast<const unsigned short *>(&rb);
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                *reinterpret_cast<unsigned int *>(&Vt[(d0 + j) * VT_STRIDE + 2 * p]) = (unsigned int)ea[j] | ((unsigned int)eb[j] << 16);
-        }
-        floatx4 s[4];
-        if (active) {
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kk = 0; kk < 4; kk++) acc = Mfma<TT>::run(__builtin_bit_cast(V8, qraw[kk]), __builtin_bit_cast(V8, kraw[st][kk]), acc);
-                s[st] = acc;
-            }
-            float tmax[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) tmax[r] = -INFINITY;
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                const int jl = 16 * st + lr;                // key index inside the tile
-                const int key = key0 + jl;
-                // bit of this key in the u64 rows, or -1 for "visible to every row" / -2 for "not a key"
-                int bit;
-                if (fresh) bit = jl < n ? voff + jl : -2;
-                else bit = key >= Lw ? -2 : (key < Lvis ? -1 : key - Lvis);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool ok = bit == -1 || (bit >= 0 && bit < 64 && ((mrow[r] >> bit) & 1ull));
-                    const float v = ok ? s[st][r] * scale_log2 : -INFINITY;
-                    s[st][r] = v;
-                    tmax[r] = fmaxf(tmax[r], v);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = tmax[r];
-                v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-                v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
-                const float m_new = fmaxf(m_run[r], v);
-                const float m_use = m_new == -INFINITY ? 0.f : m_new;
-                const float alpha = exp2f(m_run[r] - m_use);
-                float psum = 0.f;
-#pragma unroll
-                for (int st = 0; st < 4; st++) {
-                    const float p = exp2f(s[st][r] - m_use);
-                    psum += p;
-                    Pmine[(4 * lg + r) * P_STRIDE + 16 * st + lr] = (E)p;
-                }
-                psum += __shfl_xor(psum, 1); psum += __shfl_xor(psum, 2);
-                psum += __shfl_xor(psum, 4); psum += __shfl_xor(psum, 8);
-                l_run[r] = l_run[r] * alpha + psum;
-                m_run[r] = m_new;
-#pragma unroll
-                for (int dt = 0; dt < 8; dt++) o[dt][r] *= alpha;
-            }
-        }
-        __syncthreads();                                   // Vt staged, Pw written
-        if (active) {
-            V8 pa[2];
-#pragma unroll
-            for (int kcx = 0; kcx < 2; kcx++)
-                pa[kcx] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4 *>(&Pmine[lr * P_STRIDE + 32 * kcx + 8 * lg]));
-#pragma unroll
-            for (int dt = 0; dt < 8; dt++) {
-#pragma unroll
-                for (int kcx = 0; kcx < 2; kcx++) {
-                    const uint4 raw = *reinterpret_cast<const uint4 *>(&Vt[(16 * dt + lr) * VT_STRIDE + 32 * kcx + 8 * lg]);
-                    o[dt] = Mfma<TT>::run(pa[kcx], __builtin_bit_cast(V8, raw), o[dt]);
-                }
-            }
-        }
-    }
-    // ---- partial result: ws[h][slot][row][0..127] = O, [128] = m, [129] = l
-    float *wsh = ws + (size_t)h * ATT_SLOTS * n_q_pad * (ATT_D + 2);
-    if (active) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = row_base + 4 * lg + r;
-            float *dst = wsh + ((size_t)split * n_q_pad + row) * (ATT_D + 2);
-            if (row < n) {
-                if (MERGE) {                                // agent-scope (write-through) stores: read by another workgroup of this launch
-#pragma unroll
-                    for (int dt = 0; dt < 8; dt++) st_agent(dst + 16 * dt + lr, o[dt][r]);
-                    if (lr == 0) { st_agent(dst + ATT_D, m_run[r]); st_agent(dst + ATT_D + 1, l_run[r]); }
-                } else {
-#pragma unroll
-                    for (int dt = 0; dt < 8; dt++) dst[16 * dt + lr] = o[dt][r];
-                    if (lr == 0) { dst[ATT_D] = m_run[r]; dst[ATT_D + 1] = l_run[r]; }
-                }
-            }
-        }
-    }
-    if (!MERGE) return;                                    // k_attn_merge (next launch) combines the slots
-    __syncthreads();                                       // every wave's stores have completed (the barrier's release waits for them)
-    if (tid == 0) {
-        const unsigned expected = (unsigned)(used_c + (has_fresh ? 1 : 0));
-        const unsigned prev = __hip_atomic_fetch_add(counters + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == expected - 1;
-        if (s_last) __hip_atomic_store(counters + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    merge_head<E, true>(wsh, out, h, tid, n, n_q_pad, n_heads, used_c, has_fresh);
-}
-
-// the two kinds of workgroup are separate instantiations of the body (each with its own register allocation)
-template <typename TT, bool PART, bool MERGE>
-__global__ __launch_bounds__(256, 2) void k_tree_attention_fused(const typename TT::elem *__restrict__ qkv, int n_part, long long part_stride,
-                                                              const float *__restrict__ cs, typename TT::elem *__restrict__ kc,
-                                                              typename TT::elem *__restrict__ vc, float *__restrict__ ws,
-                                                              unsigned *__restrict__ counters, typename TT::elem *__restrict__ out,
-                                                              int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
-                                                              const unsigned long long *__restrict__ mask, const int *__restrict__ d_Lw,
-                                                              const int *__restrict__ d_Lvis, const int *__restrict__ d_n, float scale_log2) {
-    typedef typename TT::elem E;
-    __shared__ __attribute__((aligned(16))) E Vt[ATT_D * VT_STRIDE];
-    __shared__ __attribute__((aligned(16))) E Pw[4 * 16 * P_STRIDE];
-    __shared__ __attribute__((aligned(16))) E Ks[ATT_TILE * KS_STRIDE];    // rotated K rows of the new keys (fresh split only)
-    __shared__ int s_last;
-    if (blockIdx.y == ATT_SPLITS)
-        attn_fused_body<TT, PART, MERGE, true>(qkv, n_part, part_stride, cs, kc, vc, ws, counters, out, n_q_pad, n_heads, n_kv_heads, max_len, mask, d_Lw, d_Lvis, d_n,
-                                               scale_log2, Vt, Pw, Ks, s_last);
-    else
-        attn_fused_body<TT, PART, MERGE, false>(qkv, n_part, part_stride, cs, kc, vc, ws, counters, out, n_q_pad, n_heads, n_kv_heads, max_len, mask, d_Lw, d_Lvis, d_n,
-                                                scale_log2, Vt, Pw, Ks, s_last);
-}
-
-// the slots' merge as its own launch (one workgroup per head): the alternative to the in-kernel merge above
-template <typename E>
-__global__ __launch_bounds__(256) void k_attn_merge(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
-                                                    const int *__restrict__ d_Lw, const int *__restrict__ d_n) {
-    const int h = blockIdx.x;
-    const int Lw = d_Lw[0];
-    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
-    const int ntc = (Lw + ATT_TILE - 1) / ATT_TILE;
-    const bool has_fresh = n > 0;
-    const int used_c = ntc < 1 ? (has_fresh ? 0 : 1) : (ntc < ATT_SPLITS ? ntc : ATT_SPLITS);
-    merge_head<E, false>(ws + (size_t)h * ATT_SLOTS * n_q_pad * (ATT_D + 2), out, h, threadIdx.x, n, n_q_pad, n_heads, used_c, has_fresh);
-}
-
-// ================================================================================================
 // Token Recycle (S/tree_model/token_recycle/token_recycle.py:33-60)
 // ================================================================================================
 struct samd_recycle {
@@ -871,34 +457,49 @@ int samd_argmax_rows(const void *d_logits, int32_t dtype, int32_t rows, int64_t 
     return SAMD_OK;
 }
 
-int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len,
-                    int32_t head_dim, int32_t elem_bytes, void *stream) {
-    if (!s || !d_tensors || n_tensors < 1 || n_heads < 1 || head_dim < 1 || (head_dim * elem_bytes) % 16 != 0) {
-        samd_set_error("samd_kv_compact: invalid argument (row bytes must be a multiple of 16)"); return SAMD_E_INVALID;
+static int kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_transposed, int32_t n_heads, int64_t max_len,
+                      int32_t head_dim, int32_t elem_bytes, int32_t start, const int32_t *d_indices, int32_t accept, void *stream) {
+    if (!d_tensors || n_tensors < 1 || n_transposed < 0 || n_transposed > n_tensors || n_heads < 1 || head_dim < 1 || (head_dim * elem_bytes) % 16 != 0 ||
+        (n_transposed > 0 && elem_bytes != 2)) {
+        samd_set_error("samd_kv_compact: invalid argument (row bytes must be a multiple of 16; transposed tensors hold 2-byte elements)"); return SAMD_E_INVALID;
     }
     const int row_bytes = head_dim * elem_bytes;
     const size_t lds = (size_t)SAMD_MAX_DRAFT * row_bytes;
     if (lds > 64 * 1024) { samd_set_error("samd_kv_compact: row too large"); return SAMD_E_INVALID; }
-    hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, s->dev.verdict,
-                       s->dev.kv_index, n_heads, (long long)max_len, row_bytes, 0, 0);
+    if (s) hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, s->dev.verdict, s->dev.kv_index, n_heads,
+                              (long long)max_len, row_bytes, 0, 0, n_tensors - n_transposed);
+    else hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, (const int *)nullptr, d_indices, n_heads,
+                            (long long)max_len, row_bytes, start, accept, n_tensors - n_transposed);
     LAUNCHCHK();
     return SAMD_OK;
 }
 
+int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len,
+                    int32_t head_dim, int32_t elem_bytes, void *stream) {
+    if (!s) { samd_set_error("samd_kv_compact: null session"); return SAMD_E_INVALID; }
+    return kv_compact(s, d_tensors, n_tensors, 0, n_heads, max_len, head_dim, elem_bytes, 0, nullptr, 0, stream);
+}
+
 int samd_kv_compact_indices(void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len, int32_t head_dim,
                             int32_t elem_bytes, int32_t start, const int32_t *d_indices, int32_t accept, void *stream) {
-    if (!d_tensors || !d_indices || n_tensors < 1 || n_heads < 1 || head_dim < 1 || (head_dim * elem_bytes) % 16 != 0 || start < 0 ||
-        accept < 0 || accept > SAMD_MAX_DRAFT || start + accept > max_len) {
-        samd_set_error("samd_kv_compact_indices: invalid argument"); return SAMD_E_INVALID;
-    }
+    if (!d_indices || start < 0 || accept < 0 || accept > SAMD_MAX_DRAFT || start + accept > max_len) { samd_set_error("samd_kv_compact_indices: invalid argument"); return SAMD_E_INVALID; }
     if (accept == 0) return SAMD_OK;
-    const int row_bytes = head_dim * elem_bytes;
-    const size_t lds = (size_t)SAMD_MAX_DRAFT * row_bytes;
-    if (lds > 64 * 1024) { samd_set_error("samd_kv_compact_indices: row too large"); return SAMD_E_INVALID; }
-    hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, (const int *)nullptr,
-                       d_indices, n_heads, (long long)max_len, row_bytes, start, accept);
-    LAUNCHCHK();
-    return SAMD_OK;
+    return kv_compact(nullptr, d_tensors, n_tensors, 0, n_heads, max_len, head_dim, elem_bytes, start, d_indices, accept, stream);
+}
+
+// the same over a pointer table whose LAST n_transposed tensors are transposed ([head][D][max_len], 2-byte elements): the K tensors
+// followed by the V^T tensors of a cache that samd_attention_block reads
+int samd_kv_compact_vt(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_transposed, int32_t n_heads, int64_t max_len,
+                       int32_t head_dim, int32_t elem_bytes, void *stream) {
+    if (!s) { samd_set_error("samd_kv_compact_vt: null session"); return SAMD_E_INVALID; }
+    return kv_compact(s, d_tensors, n_tensors, n_transposed, n_heads, max_len, head_dim, elem_bytes, 0, nullptr, 0, stream);
+}
+
+int samd_kv_compact_indices_vt(void *const *d_tensors, int32_t n_tensors, int32_t n_transposed, int32_t n_heads, int64_t max_len, int32_t head_dim,
+                               int32_t elem_bytes, int32_t start, const int32_t *d_indices, int32_t accept, void *stream) {
+    if (!d_indices || start < 0 || accept < 0 || accept > SAMD_MAX_DRAFT || start + accept > max_len) { samd_set_error("samd_kv_compact_indices_vt: invalid argument"); return SAMD_E_INVALID; }
+    if (accept == 0) return SAMD_OK;
+    return kv_compact(nullptr, d_tensors, n_tensors, n_transposed, n_heads, max_len, head_dim, elem_bytes, start, d_indices, accept, stream);
 }
 
 int64_t samd_tree_attention_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim) {
@@ -929,49 +530,6 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
         hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n);
     }
-    LAUNCHCHK();
-    return SAMD_OK;
-}
-
-int64_t samd_tree_attention_fused_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim) {
-    return 1024 + (int64_t)ATT_SLOTS * n_q_pad * n_heads * (head_dim + 2) * 4;        // [0, 1024): per-head arrival counters (zero them once)
-}
-
-int samd_rope_rows(const int32_t *d_rel_pos, const int32_t *d_base, const float *d_cos, const float *d_sin, float *d_cs, int32_t rows,
-                   int32_t head_dim, int32_t max_pos, void *stream) {
-    if (!d_rel_pos || !d_base || !d_cos || !d_sin || !d_cs || rows < 1 || rows > SAMD_MAX_DRAFT || head_dim != ATT_D || max_pos < 1) {
-        samd_set_error("samd_rope_rows: invalid argument (head_dim must be 128, rows <= 64)"); return SAMD_E_INVALID;
-    }
-    hipLaunchKernelGGL(k_rope_rows<float>, dim3((rows * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rel_pos, d_base, d_cos, d_sin, d_cs, rows, max_pos);
-    LAUNCHCHK();
-    return SAMD_OK;
-}
-
-int samd_tree_attention_fused(const void *d_qkv, int32_t n_partials, int64_t partial_stride, const float *d_cs, void *d_k_cache, void *d_v_cache,
-                              void *d_out, int32_t dtype, int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
-                              const uint64_t *d_mask, const int32_t *d_write_pos, const int32_t *d_visible_len, const int32_t *d_n, float scale,
-                              void *d_workspace, int64_t workspace_bytes, void *stream) {
-    if (!d_qkv || !d_cs || !d_k_cache || !d_v_cache || !d_out || !d_mask || !d_write_pos || !d_n || !d_workspace) { samd_set_error("samd_tree_attention_fused: null pointer"); return SAMD_E_INVALID; }
-    if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_heads > 256 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || n_partials < 0 ||
-        (dtype != SAMD_F16 && dtype != SAMD_BF16) || workspace_bytes < samd_tree_attention_fused_workspace(n_q_pad, n_heads, head_dim)) {
-        samd_set_error("samd_tree_attention_fused: unsupported shape (head_dim must be 128, n_q_pad <= 64, heads <= 256, f16/bf16) or workspace too small");
-        return SAMD_E_INVALID;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    const float scale_log2 = scale * 1.4426950408889634f;
-    unsigned *counters = (unsigned *)d_workspace;
-    float *ws = (float *)((char *)d_workspace + 1024);
-    // SAMD_ATTN_MERGE=0 (read once): merge the KV slots in a second launch (k_attn_merge) instead of by the last-arriving workgroup
-    static const bool in_kernel_merge = [] { const char *e = getenv("SAMD_ATTN_MERGE"); return !(e && e[0] == '0'); }();
-#define GO(TT, PART, MERGE, ET) hipLaunchKernelGGL((k_tree_attention_fused<TT, PART, MERGE>), dim3(n_heads, ATT_SLOTS), dim3(256), 0, st, (const ET *)d_qkv, n_partials, \
-        (long long)partial_stride, d_cs, (ET *)d_k_cache, (ET *)d_v_cache, ws, counters, (ET *)d_out, n_q_pad, n_heads, n_kv_heads, (long long)max_len, \
-        (const unsigned long long *)d_mask, d_write_pos, d_visible_len, d_n, scale_log2)
-#define GO2(TT, ET) do { if (in_kernel_merge) { if (n_partials) GO(TT, true, true, ET); else GO(TT, false, true, ET); } \
-        else { if (n_partials) GO(TT, true, false, ET); else GO(TT, false, false, ET); \
-               hipLaunchKernelGGL(k_attn_merge<ET>, dim3(n_heads), dim3(256), 0, st, ws, (ET *)d_out, n_q_pad, n_heads, d_write_pos, d_n); } } while (0)
-    if (dtype == SAMD_F16) GO2(F16, _Float16); else GO2(BF16, __bf16);
-#undef GO2
-#undef GO
     LAUNCHCHK();
     return SAMD_OK;
 }

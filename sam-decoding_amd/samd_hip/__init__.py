@@ -100,10 +100,11 @@ _PROTOS = {
     "samd_tree_attention_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_tree_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
                                       _VP, _I64, _VP]),
-    "samd_tree_attention_fused_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_rope_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
-    "samd_tree_attention_fused": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _F32,
-                                            _VP, _I64, _VP]),
+    "samd_attention_block": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _F32, _VP]),
+    "samd_rope_kv_write_vt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
+    "samd_kv_compact_vt": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
+    "samd_kv_compact_indices_vt": (C.c_int, [_VP, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_embed_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "samd_rmsnorm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _I32, _I64, _VP]),
     "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
@@ -417,8 +418,9 @@ class Session:
         check(lib().samd_session_get_cache_length(self._h, C.byref(out), current_stream()))
         return out.value
 
-    def kv_compact(self, d_tensor_ptrs, n_tensors, n_heads, max_len, head_dim, elem_bytes):
-        check(lib().samd_kv_compact(self._h, _ptr(d_tensor_ptrs), n_tensors, n_heads, max_len, head_dim, elem_bytes, current_stream()))
+    def kv_compact(self, d_tensor_ptrs, n_tensors, n_heads, max_len, head_dim, elem_bytes, n_transposed=0):
+        """n_transposed: the last that many tensors of the table are V^T ([head][D][max_len], samd_attention_block's layout)"""
+        check(lib().samd_kv_compact_vt(self._h, _ptr(d_tensor_ptrs), n_tensors, n_transposed, n_heads, max_len, head_dim, elem_bytes, current_stream()))
 
     def device_views(self):
         """raw device pointers of the draft/verdict block (see include/samd_hip.h)."""

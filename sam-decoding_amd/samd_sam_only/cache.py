@@ -5,6 +5,9 @@ Semantics of samd_sam_only/cache.py:37-133: one pre-allocated [1, H_kv, max_cach
 `select_indices` keeps the accepted rows (start + idx[j] -> start + j) and advances cache_length, rejected rows are
 overwritten by the next step.  Storage is a single HBM allocation [layers, 2, H_kv, max_len, D]; compaction of all
 2 x layers tensors is one kernel launch over a pointer table (samd_kv_compact_indices / samd_kv_compact).
+When the cache backs a LlamaRunner (SamdModel.set_cache) the V half of every layer is kept TRANSPOSED in the same bytes
+([H_kv][D][max_len], the operand layout of samd_attention_block); `value_cache` then holds transposed views, so `update`,
+`select_indices` and anything that indexes value_cache[l][0, head, position] behave as before.
 The layout is contiguous, not paged: at bs=1 with max_cache_len <= 8192 a request's whole cache is <= 4 GiB of the
 288 GB HBM, and contiguous rows keep the attention kernel's K/V tile loads fully coalesced.
 """
@@ -36,11 +39,22 @@ class SamdStaticCache:
         dev = torch.device(device if device is not None else "cuda")
         self.storage = torch.zeros((self.num_layers, 2, self.num_key_value_heads, self.max_cache_len, self.head_dim), dtype=dtype, device=dev)
         self.key_cache: List[torch.Tensor] = [self.storage[l, 0].unsqueeze(0) for l in range(self.num_layers)]
+        self.v_transposed = False
         self.value_cache: List[torch.Tensor] = [self.storage[l, 1].unsqueeze(0) for l in range(self.num_layers)]
         self._ptrs = torch.tensor([self.storage[l, j].data_ptr() for j in (0, 1) for l in range(self.num_layers)],
                                   dtype=torch.int64, device=dev)
         self.last_length = 0
         self.cache_length = 0
+
+    def set_v_transposed(self, flag=True):
+        """keep V as [H_kv][D][max_len] inside the same storage (only on an empty cache)"""
+        assert self.cache_length == 0 and self.last_length == 0, "the V layout can only change while the cache is empty"
+        self.v_transposed = bool(flag)
+        H, L, D = self.num_key_value_heads, self.max_cache_len, self.head_dim
+        if flag:
+            self.value_cache = [self.storage[l, 1].view(H, D, L).transpose(1, 2).unsqueeze(0) for l in range(self.num_layers)]
+        else:
+            self.value_cache = [self.storage[l, 1].unsqueeze(0) for l in range(self.num_layers)]
 
     def reset(self):
         self.cache_length = 0
@@ -70,9 +84,9 @@ class SamdStaticCache:
         start = self.cache_length
         if indices is not None and accept_length > 0:
             idx = indices.reshape(-1).to(device=self.storage.device, dtype=torch.int32).contiguous()
-            samd_hip.check(samd_hip.lib().samd_kv_compact_indices(
-                samd_hip._ptr(self._ptrs), 2 * self.num_layers, self.num_key_value_heads, self.max_cache_len, self.head_dim,
-                self.storage.element_size(), start, samd_hip._ptr(idx), int(accept_length), samd_hip.current_stream()))
+            samd_hip.check(samd_hip.lib().samd_kv_compact_indices_vt(
+                samd_hip._ptr(self._ptrs), 2 * self.num_layers, self.num_layers if self.v_transposed else 0, self.num_key_value_heads, self.max_cache_len,
+                self.head_dim, self.storage.element_size(), start, samd_hip._ptr(idx), int(accept_length), samd_hip.current_stream()))
         self.cache_length += int(accept_length)
 
 

@@ -1,7 +1,7 @@
 """attn_bench.py -- the attention block of one decoder layer, x32 layers in one hipGraph (Vicuna-7B head geometry, fp16, q|k|v from
 2 fp32 split-K partials as the streaming GEMM leaves them): microseconds per layer of
    unfused  samd_rope_kv_write + samd_tree_attention (+ its combine launch)          -- three launches
-   fused    samd_tree_attention_fused (SAMD_ATTN_MERGE=1: in-kernel merge, =0: + k_attn_merge launch; read once per process)
+   block    samd_attention_block (V cached transposed; one workgroup per head and 16 rows)                          -- one launch
 usage: python scripts/attn_bench.py [L]"""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ W = (H + 2 * Hkv) * D
 Lib = lib()
 kv = torch.randn((layers, 2, Hkv, max_len, D), device="cuda").half()
 cos = torch.rand((max_len, 64), device="cuda"); sin = torch.rand((max_len, 64), device="cuda")
-for R in (16, 64):
+for R in (8, 16, 32, 64):
     n = R - 3
     RP = max(R, 16)
     part = torch.randn((2, RP, W), device="cuda", dtype=torch.float32)
@@ -26,7 +26,7 @@ for R in (16, 64):
     rel = torch.arange(64, dtype=torch.int32, device="cuda")
     mask = torch.tensor([(1 << (i + 1)) - 1 if i < 63 else -1 for i in range(64)], dtype=torch.int64, device="cuda")
     d_L = torch.tensor([L0], dtype=torch.int32, device="cuda"); d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
-    ws = torch.zeros(max(Lib.samd_tree_attention_workspace(R, H, D), Lib.samd_tree_attention_fused_workspace(R, H, D)), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(Lib.samd_tree_attention_workspace(R, H, D), dtype=torch.uint8, device="cuda")
     cs = torch.zeros((64, D), dtype=torch.float32, device="cuda")
     scale = 1.0 / math.sqrt(D)
 
@@ -42,15 +42,15 @@ for R in (16, 64):
         st = current_stream()
         check(Lib.samd_rope_rows(_ptr(rel), _ptr(d_L), _ptr(cos), _ptr(sin), _ptr(cs), R, D, max_len, st))
         for li in range(layers):
-            check(Lib.samd_tree_attention_fused(_ptr(part), 2, RP * W, _ptr(cs), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, Hkv, D, max_len,
-                                                _ptr(mask), _ptr(d_L), None, _ptr(d_n), scale, _ptr(ws), ws.numel(), st))
+            check(Lib.samd_attention_block(_ptr(part), 2, RP * W, _ptr(cs), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, Hkv, D, max_len,
+                                           _ptr(mask), _ptr(d_L), None, _ptr(d_n), scale, st))
 
     res = {}
-    for name, fn in (("unfused", unfused), ("fused", fused)):
+    for name, fn in (("unfused", unfused), ("block", fused)):
         ws.zero_()
         fn(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fn()
         res[name] = hip_time_ms(g.replay, 20) * 1e3 / layers
-    print(f"R={R} n={n} L={L0} SAMD_ATTN_MERGE={os.environ.get('SAMD_ATTN_MERGE', '1')}: " + "  ".join(f"{k} {v:.2f} us/layer" for k, v in res.items()), flush=True)
+    print(f"R={R} n={n} L={L0}: " + "  ".join(f"{k} {v:.2f} us/layer" for k, v in res.items()), flush=True)

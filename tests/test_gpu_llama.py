@@ -396,7 +396,7 @@ def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
         sess = samd_hip.Session(1024)
         last = runner.prefill(sess, ids)
         torch.cuda.synchronize()
-        outs[mode] = (last.float().clone(), runner.kv[:, :, :, :200].float().clone(), sess.get_cache_length())
+        outs[mode] = (last.float().clone(), torch.stack([t.float() for t in runner.kv_rows(200)]), sess.get_cache_length())
         # the same prompt with a per-chunk consumer (what Token Recycle / EAGLE see): all logits and last hidden states
         seen = []
         sess2 = samd_hip.Session(1024)
