@@ -41,7 +41,7 @@ class DeviceHead:
                        layers=[dict(ln1=ones, wqkv=torch.cat([c(head.q), c(head.k), c(head.v)], 0), wo=c(head.o), ln2=c(head.post_ln),
                                     wgu=torch.cat([c(head.gate), c(head.up)], 0), wdown=c(head.down))])
         self.runner = LlamaRunner(LlamaShape(cfg), weights, base_runner.max_len + MAX_ROWS, dt, dev,
-                                  packed_lm_head=base_runner.wp["lm_head"] if base_runner.wp else None)
+                                  packed_lm_head=base_runner.wp["lm_head"] if base_runner.wp else None, attention="block")
         self.runner.draft_head = True
         self.fc_w, self.fc_b = c(head.fc_w), (c(head.fc_b) if head.fc_b is not None else None)
         # fc([embed ; hidden]) on the streaming GEMM too (K = 2 * hidden): packed weight, zero-padded operand rows, fp32 partials

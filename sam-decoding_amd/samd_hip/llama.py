@@ -76,7 +76,8 @@ class LlamaRunner:
 
     BUCKETS = (1, 8, 16, 32, 64)
 
-    def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None, native_gemm=True, packed_lm_head=None):
+    def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None, native_gemm=True, packed_lm_head=None,
+                 attention=None):
         require_gpu()
         self.shape, self.dtype, self.device = shape, dtype, torch.device(device)
         self.dt = torch_dtype_code(dtype)
@@ -88,6 +89,15 @@ class LlamaRunner:
         # does not fit (say a fine-tune's 32001-row lm_head) goes to the library GEMM on its own, the others keep the kernel
         streams = lambda t: bool(native_gemm) and t.shape[0] % 128 == 0 and t.shape[1] % 256 == 0
         self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 64))     # tuning knob; see forward_rows
+        # the attention block of a layer: "split" = RoPE + K/V row write, tree attention over 16 KV splits, split merge (three launches,
+        # row-major V cache); "block" = samd_attention_block (one launch, V cached transposed, masks with a visible prefix).  Measured
+        # per layer at Vicuna-7B head geometry (profiles/r02_attention_variants.md): split 16.8 us vs block 22.8 us at L = 800 -- one
+        # workgroup per head pays a memory round trip per 512 keys where the splits run side by side -- so the base model's verify keeps
+        # "split"; a draft head's tree levels need the visible prefix and run "block" (one layer, short contexts).
+        self.attention = attention or os.environ.get("SAMD_ATTENTION", "split")
+        if self.attention not in ("split", "block"):
+            raise SamdError(f"unknown attention mode '{self.attention}'")
+        self.v_transposed = self.attention == "block"
         # second copy of the projection weights in the streaming kernel's packed layout (samd_gemm_pack_weights): the
         # row-major originals stay for the wide prefill's library GEMMs.  2 x 13.5 GB for a 7B model -- HBM capacity
         # (288 GB) is not what this path is short of, bandwidth is.
@@ -118,7 +128,7 @@ class LlamaRunner:
         (row-major + packed) do not, so a different max_cache_len between generate() calls re-runs only this."""
         s, dtype = self.shape, self.dtype
         self.max_len = int(max_cache_len)
-        if self.max_len < 8 or self.max_len % 8 != 0:
+        if self.v_transposed and (self.max_len < 8 or self.max_len % 8 != 0):
             raise SamdError(f"max_cache_len {self.max_len} must be a multiple of 8 (16-byte loads along the transposed V cache)")
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
         self.kv = self.kv_ptrs = None
@@ -148,8 +158,8 @@ class LlamaRunner:
 
     def bind_cache(self, storage):
         """use `storage` [layers, 2, H_kv, max_len, D] (e.g. SamdStaticCache.storage) as the KV cache.  storage[l, 0] holds K rows
-        [H_kv][max_len][D]; storage[l, 1] holds V TRANSPOSED, [H_kv][D][max_len] in the same bytes (what samd_attention_block reads
-        as its PV operand without staging; see kv_rows() for the logical view)."""
+        [H_kv][max_len][D]; storage[l, 1] holds V rows likewise, or -- attention mode "block" -- V TRANSPOSED, [H_kv][D][max_len] in
+        the same bytes (what samd_attention_block reads as its PV operand without staging; kv_rows() gives the logical view)."""
         s = self.shape
         if tuple(storage.shape) != (s.layers, 2, s.kv_heads, self.max_len, s.head_dim) or storage.dtype != self.dtype:
             raise SamdError(f"KV storage shape/dtype mismatch: {tuple(storage.shape)} {storage.dtype}")
@@ -162,6 +172,8 @@ class LlamaRunner:
         key_cache / value_cache contents (SO/cache.py:75-84)"""
         s = self.shape
         k = self.kv[:, 0, :, :n]
+        if not self.v_transposed:
+            return k, self.kv[:, 1, :, :n]
         v = self.kv[:, 1].reshape(s.layers, s.kv_heads, s.head_dim, self.max_len)[:, :, :, :n].transpose(2, 3)
         return k, v
 
@@ -269,10 +281,14 @@ class LlamaRunner:
             rows_in = min(R, x_in.shape[0])
             b["x"][:rows_in].copy_(x_in[:rows_in])                # rows past d_n are never consumed
         head = getattr(self, "draft_head", False)
-        # cos / sin of every row's position (visible length + relative position), once per forward: the attention launches of all
-        # layers read them without first having to wait for L
-        check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_vis if d_vis is not None else d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R,
-                               s.head_dim, self.rope_rows, st))
+        block = self.attention == "block"
+        if block:
+            # cos / sin of every row's position (visible length + relative position), once per forward: the attention launches of all
+            # layers read them without first having to wait for L
+            check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_vis if d_vis is not None else d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R,
+                                   s.head_dim, self.rope_rows, st))
+        elif d_vis is not None:
+            raise SamdError("a visible length different from the write position needs attention mode 'block'")
         delta, dn, dstride = None, 0, 0
         packed = self.wp["layers"] if self.wp else [{}] * len(self.w["layers"])
         for li, w in enumerate(self.w["layers"]):
@@ -282,9 +298,17 @@ class LlamaRunner:
             else:
                 check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
             src, n_p, stride = gemm(b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
-            # RoPE + K row / V^T column write + tree attention + merge of the tile partials: one launch (csrc/attn_kernels.hip)
-            check(L.samd_attention_block(_ptr(src), n_p, stride, _ptr(b["cs"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R,
-                                         s.heads, s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_vis), _ptr(d_n), self.scale, st))
+            if block:
+                # RoPE + K row / V^T column write + tree attention + merge of the tile partials: one launch (csrc/attn_kernels.hip)
+                check(L.samd_attention_block(_ptr(src), n_p, stride, _ptr(b["cs"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R,
+                                             s.heads, s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_vis), _ptr(d_n), self.scale, st))
+            else:
+                check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
+                                           _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
+                                           s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
+                check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
+                                            s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                                            _ptr(b["ws"]), b["ws_bytes"], st))
             src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"])
             check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride, st))
             if self.fused_mlp and RP <= self.native_gemm_max_rows:
@@ -345,12 +369,18 @@ class LlamaRunner:
         for li, w in enumerate(self.w["layers"]):
             check(L.samd_rmsnorm(_ptr(x), _ptr(delta), _ptr(w["ln1"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
             torch.mm(h, w["wqkv"].t(), out=qkv)
-            check(L.samd_rope_kv_write_vt(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
-                                          _ptr(self.kv[li, 0]), None, N, s.heads, s.kv_heads, s.head_dim, self.max_len,
-                                          self.rope_rows, dt, 0, 0, st))                                             # q and K rows
+            if self.v_transposed:
+                check(L.samd_rope_kv_write_vt(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
+                                              _ptr(self.kv[li, 0]), None, N, s.heads, s.kv_heads, s.head_dim, self.max_len,
+                                              self.rope_rows, dt, 0, 0, st))                                         # q and K rows
+                vv = qkv[:, (s.heads + s.kv_heads) * s.head_dim:].view(N, s.kv_heads, s.head_dim).transpose(0, 1)  # V straight from the projection
+                self.kv[li, 1].view(s.kv_heads, s.head_dim, self.max_len)[:, :, :N].copy_(vv.transpose(1, 2))        # V^T columns of the cache
+            else:
+                check(L.samd_rope_kv_write(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
+                                           _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), N, s.heads, s.kv_heads, s.head_dim, self.max_len,
+                                           self.rope_rows, dt, 0, 0, st))
+                vv = self.kv[li, 1][:, :N]
             kk = self.kv[li, 0][:, :N]
-            vv = qkv[:, (s.heads + s.kv_heads) * s.head_dim:].view(N, s.kv_heads, s.head_dim).transpose(0, 1)      # V straight from the projection
-            self.kv[li, 1].view(s.kv_heads, s.head_dim, self.max_len)[:, :, :N].copy_(vv.transpose(1, 2))            # V^T columns of the cache
             if s.kv_heads != s.heads:
                 kk, vv = kk.repeat_interleave(s.heads // s.kv_heads, dim=0), vv.repeat_interleave(s.heads // s.kv_heads, dim=0)
             att = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1)[None], kk[None], vv[None], is_causal=True, scale=self.scale)
@@ -410,4 +440,4 @@ class LlamaRunner:
     def compact(self, session: Session):
         """SamdStaticCache.select_indices (SO/cache.py:118-133) for all 2 x layers tensors in one launch."""
         s = self.shape
-        session.kv_compact(self.kv_ptrs, 2 * s.layers, s.kv_heads, self.max_len, s.head_dim, self.kv.element_size(), n_transposed=s.layers)
+        session.kv_compact(self.kv_ptrs, 2 * s.layers, s.kv_heads, self.max_len, s.head_dim, self.kv.element_size(), n_transposed=s.layers if self.v_transposed else 0)

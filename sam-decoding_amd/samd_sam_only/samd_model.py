@@ -119,7 +119,6 @@ class SamdModel(nn.Module):
                 kw = dict(config=cfg, max_cache_len=max_len, device=self.device, dtype=self.dtype)
                 self.cache = cls(**kw) if cls is SamdCache else cls(cfg, batch_size=1, max_cache_len=max_len, device=self.device,
                                                                     dtype=self.dtype, hf_device_map=getattr(self.lm, "hf_device_map", None))
-                self.cache.set_v_transposed(True)          # the runner's attention kernel reads V^T (samd_attention_block)
                 if self._runner is None:
                     self._runner = self._runner_factory(self.lm, max_len, self.dtype, self.device, kv=self.cache.storage)
                     if os.environ.get("SAMD_RELEASE_HF_WEIGHTS", "0") == "1":
@@ -127,6 +126,7 @@ class SamdModel(nn.Module):
                         torch.cuda.empty_cache()        # callers may keep using the HF module on the GPU (tests do)
                 else:
                     self._runner.resize_cache(max_len, self.cache.storage)     # same weights; only KV / rope tables change
+                self.cache.set_v_transposed(self._runner.v_transposed)     # attention mode "block" keeps V^T in the same storage
                 self.verifier = self._runner
                 self.engine = None
             else:
@@ -300,6 +300,7 @@ class _RunnerCacheView:
         self.storage, self.max_cache_len = runner.kv, runner.max_len
         self.cache_length = self.last_length = 0
         self._ptrs, self._dims = runner.kv_ptrs, (2 * s.layers, s.kv_heads, runner.max_len, s.head_dim, runner.kv.element_size())
+        self._n_vt = s.layers if runner.v_transposed else 0
 
     def reset(self):
         self.cache_length = self.last_length = 0
@@ -314,6 +315,6 @@ class _RunnerCacheView:
         if indices is not None and accept_length > 0:
             idx = indices.reshape(-1).to(device=self.storage.device, dtype=torch.int32).contiguous()
             n_t, hk, ml, hd, eb = self._dims
-            samd_hip.check(samd_hip.lib().samd_kv_compact_indices_vt(samd_hip._ptr(self._ptrs), n_t, n_t // 2, hk, ml, hd, eb, self.cache_length,
+            samd_hip.check(samd_hip.lib().samd_kv_compact_indices_vt(samd_hip._ptr(self._ptrs), n_t, self._n_vt, hk, ml, hd, eb, self.cache_length,
                                                                      samd_hip._ptr(idx), int(accept_length), samd_hip.current_stream()))
         self.cache_length += int(accept_length)

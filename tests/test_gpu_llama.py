@@ -34,11 +34,14 @@ def dev(a):
     return torch.as_tensor(np.asarray(a, dtype=np.int32)).cuda()
 
 
+@pytest.mark.parametrize("attention", ["split", "block"])
 @pytest.mark.parametrize("kv_heads", [2, 1])
-def test_prefill_and_tree_verify_match_hf(kv_heads):
+def test_prefill_and_tree_verify_match_hf(kv_heads, attention):
+    """both attention modes of the runner: "split" (RoPE / split attention / merge launches, row-major V cache) and "block"
+    (samd_attention_block: one launch, V cached transposed)"""
     from transformers import DynamicCache
     lm = tiny_llama(kv_heads)
-    runner = LlamaRunner.from_hf(lm, max_cache_len=256, dtype=torch.float16)
+    runner = LlamaRunner.from_hf(lm, max_cache_len=256, dtype=torch.float16, attention=attention)
     sess = samd_hip.Session(512)
     rng = np.random.default_rng(1)
     prompt = rng.integers(3, 512, 75).tolist()
@@ -390,9 +393,9 @@ def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
     prompt = rng.integers(3, 512, 200).tolist()
     ids = torch.tensor([prompt], device="cuda")
     outs = {}
-    for mode in ("wide", "chunked"):
-        monkeypatch.setenv("SAMD_PREFILL", mode)
-        runner = LlamaRunner.from_hf(lm, max_cache_len=512, dtype=torch.float16)
+    for mode in ("wide", "chunked", "wide-block"):
+        monkeypatch.setenv("SAMD_PREFILL", mode.split("-")[0])
+        runner = LlamaRunner.from_hf(lm, max_cache_len=512, dtype=torch.float16, attention="block" if mode.endswith("block") else "split")
         sess = samd_hip.Session(1024)
         last = runner.prefill(sess, ids)
         torch.cuda.synchronize()
@@ -408,9 +411,10 @@ def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
     assert outs["wide"][2] == outs["chunked"][2] == 200
     assert (outs["wide"][0] - ref).abs().max().item() < TOL and (outs["chunked"][0] - ref).abs().max().item() < TOL
     assert (outs["wide"][1] - outs["chunked"][1]).abs().max().item() < 2e-2          # same K/V rows up to fp16 GEMM rounding
+    assert torch.equal(outs["wide"][1], outs["wide-block"][1])                        # the transposed V cache holds the same values
     with torch.no_grad():
         full = lm(input_ids=ids, output_hidden_states=True)
-    for mode in ("wide", "chunked"):
+    for mode in ("wide", "chunked", "wide-block"):
         toks, logits, hidden = outs[mode][3:]
         assert toks.tolist() == prompt and logits.shape == (200, 512) and hidden.shape == (200, 256)
         assert (logits - full.logits[0]).abs().max().item() < TOL

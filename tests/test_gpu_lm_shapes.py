@@ -252,8 +252,10 @@ def test_llama3_shape_long_context_matches_hf_fp32():
         lm = hf_llama(cfg, seed=2)
     except Exception as e:
         pytest.skip(f"LlamaConfig(rope_parameters=...) unsupported: {e}")
-    runner = LlamaRunner.from_hf(lm, max_cache_len=8192, dtype=torch.bfloat16)
-    verify_against_hf(lm, runner, 6000, 63, 128256, tol=0.25, seed=3)
+    for attention in ("split", "block"):
+        runner = LlamaRunner.from_hf(lm, max_cache_len=8192, dtype=torch.bfloat16, attention=attention)
+        verify_against_hf(lm, runner, 6000, 63, 128256, tol=0.25, seed=3)
+        del runner
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
