@@ -302,6 +302,21 @@ int samd_attention_block(const void *d_qkv, int32_t n_partials, int64_t partial_
                          void *d_out, int32_t dtype, int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
                          const uint64_t *d_mask, const int32_t *d_write_pos, const int32_t *d_visible_len, const int32_t *d_n, float scale,
                          void *stream);
+/* samd_rope_kv_write with the rows' cos | sin taken from d_cs (float [rows][128], samd_rope_rows -- once per forward) instead of the
+ * position tables: one memory round trip instead of two (the table lookup depends on L and the row's position). */
+int samd_rope_kv_write_cs(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                          const float *d_cs, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
+                          int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype,
+                          int32_t n_partials, int64_t partial_stride, void *stream);
+/* samd_rope_kv_write + samd_tree_attention in TWO launches instead of three (row-major V cache, csrc/verify_kernels.hip
+ * k_tree_attention_rope): the 16 KV splits rotate their Q rows themselves, one more workgroup per head owns the n new keys (rotates
+ * k, writes the K / V rows at [L, L + n), attends to them), k_attn_combine_slots merges the 17 slots.  d_qkv / n_partials /
+ * partial_stride / d_cs as for samd_attention_block; mask bit j of row i = new key j (no visible-prefix form). */
+int64_t samd_tree_attention_rope_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim);
+int samd_tree_attention_rope(const void *d_qkv, int32_t n_partials, int64_t partial_stride, const float *d_cs, void *d_k_cache, void *d_v_cache,
+                             void *d_out, int32_t dtype, int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                             const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace,
+                             int64_t workspace_bytes, void *stream);
 /* samd_rope_kv_write with the V cache transposed ([H_kv][D][max_len]); d_vt_cache may be NULL (q and K only).
  * samd_kv_compact / samd_kv_compact_indices over a pointer table whose LAST n_transposed tensors are transposed (2-byte elements):
  * select_indices (SO/cache.py:118-133) for the K tensors followed by the V^T tensors. */

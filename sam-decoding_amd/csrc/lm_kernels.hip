@@ -124,8 +124,12 @@ template <typename T>
 __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel_pos, const int *__restrict__ d_L,
                           const int *__restrict__ d_n, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
                           T *__restrict__ q_out, T *__restrict__ k_cache, T *__restrict__ v_cache, int H, int Hkv, int D,
-                          long long max_len, int max_pos, int n_part, long long part_stride, int v_transposed) {
+                          long long max_len, int max_pos, int n_part, long long part_stride, int v_transposed, const float *__restrict__ cs) {
     const int r = blockIdx.x, hh = blockIdx.y, j = threadIdx.x, half = D >> 1;
+    // cs != null: this row's cos | sin were prepared by k_rope_rows (once per forward, [rows][D]); they are requested HERE, in the same
+    // round trip as the operands, instead of after L and the row's position are known (one dependent memory round trip less)
+    float c_pre = 0.f, s_pre = 0.f;
+    if (cs) { c_pre = cs[(size_t)r * D + j]; s_pre = cs[(size_t)r * D + half + j]; }
     // the operand loads do not depend on n / L: they are issued first, together with the scalars and this row's relative
     // position, so that the kernel is two memory round trips (operands + scalars, then cos/sin) instead of four
     const int rel = rel_pos[r], n = d_n[0], L = d_L[0];
@@ -160,8 +164,12 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
         }
         return;
     }
-    int pos = L + rel; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
-    const float c = cos_t[(size_t)pos * half + j], s = sin_t[(size_t)pos * half + j];
+    float c, s;
+    if (cs) { c = c_pre; s = s_pre; }
+    else {
+        int pos = L + rel; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+        c = cos_t[(size_t)pos * half + j]; s = sin_t[(size_t)pos * half + j];
+    }
     const T o1 = (T)(x1 * c - x2 * s), o2 = (T)(x2 * c + x1 * s);
     T *dst = hh < H ? q_out + ((size_t)r * H + hh) * D : k_cache + ((size_t)(hh - H) * max_len + L + r) * D;
     dst[j] = o1; dst[j + half] = o2;
@@ -223,13 +231,14 @@ int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_o
 static int rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
                          const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
                          int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
-                         int32_t n_partials, int64_t partial_stride, int32_t v_transposed, void *stream) {
-    if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || !d_cos || !d_sin || !d_q_out || !d_k_cache || (!d_v_cache && !v_transposed) || rows < 1 ||
+                         int32_t n_partials, int64_t partial_stride, int32_t v_transposed, const float *d_cs, void *stream) {
+    if (d_cs && head_dim != 128) { samd_set_error("samd_rope_kv_write_cs: head_dim must be 128"); return SAMD_E_INVALID; }
+    if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || ((!d_cos || !d_sin) && !d_cs) || !d_q_out || !d_k_cache || (!d_v_cache && !v_transposed) || rows < 1 ||
         head_dim % 2 != 0 || head_dim > 2048) { samd_set_error("samd_rope_kv_write: invalid argument"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(rows, n_heads + 2 * n_kv_heads), block(head_dim / 2);
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed, d_cs);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed, d_cs);
     else { samd_set_error("samd_rope_kv_write: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
@@ -240,7 +249,17 @@ int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_
                        int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
                        int32_t n_partials, int64_t partial_stride, void *stream) {
     return rope_kv_write(d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, d_q_out, d_k_cache, d_v_cache, rows, n_heads, n_kv_heads, head_dim, max_len,
-                         max_pos, dtype, n_partials, partial_stride, 0, stream);
+                         max_pos, dtype, n_partials, partial_stride, 0, nullptr, stream);
+}
+
+// the same with the rows' cos | sin taken from d_cs (float [rows][128], samd_rope_rows -- once per forward) instead of the tables:
+// the kernel is then one memory round trip long instead of two
+int samd_rope_kv_write_cs(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                          const float *d_cs, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
+                          int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype,
+                          int32_t n_partials, int64_t partial_stride, void *stream) {
+    return rope_kv_write(d_qkv, d_rel_pos, d_cache_length, d_n, nullptr, nullptr, d_q_out, d_k_cache, d_v_cache, rows, n_heads, n_kv_heads, head_dim, max_len,
+                         1, dtype, n_partials, partial_stride, 0, d_cs, stream);
 }
 
 // the same with the V cache transposed ([H_kv][D][max_len], the layout samd_attention_block reads); d_vt_cache may be NULL (q and K only)
@@ -249,7 +268,7 @@ int samd_rope_kv_write_vt(const void *d_qkv, const int32_t *d_rel_pos, const int
                           int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
                           int32_t n_partials, int64_t partial_stride, void *stream) {
     return rope_kv_write(d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, d_q_out, d_k_cache, d_vt_cache, rows, n_heads, n_kv_heads, head_dim, max_len,
-                         max_pos, dtype, n_partials, partial_stride, 1, stream);
+                         max_pos, dtype, n_partials, partial_stride, 1, nullptr, stream);
 }
 
 int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,

@@ -339,6 +339,332 @@ __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ 
 }
 
 // ================================================================================================
+// k_tree_attention with RoPE and the K/V row write folded in (the k_rope_kv launch disappears): same 16 KV splits over the
+// cached keys, plus ONE more workgroup per head (split ATT_SPLITS) that owns the n new keys.
+//  * all 256 threads of a workgroup first rotate the block's Q rows straight out of the q|k|v projection's output (a T tensor or
+//    the streaming GEMM's fp32 split-K partials) into LDS -- their loads go out in the same round trip as the first K/V tile and
+//    the two scalars; cos/sin per row come from k_rope_rows (once per forward), so nothing here waits for L;
+//  * the workgroup of the new keys is known from the block index, so it requests the new rows' k and v at entry as well, rotates
+//    k into LDS (and, for the first query head of a KV group, into the cache) and keeps v in the registers the V^T staging reads;
+//  * cached tiles never see rows >= L (masked / zeroed), so nobody reads what that workgroup is writing;
+//  * partial (m, l, O) per slot; k_attn_combine_slots merges the ATT_SPLITS + 1 slots (a second launch: the in-kernel merge by
+//    the last-arriving workgroup measured slower than the launch it saves, profiles/r02_attention_variants.md).
+// ================================================================================================
+#define ATT_SLOTS (ATT_SPLITS + 1)
+#define QS_STRIDE (ATT_D + 8)         // halfs per staged Q / new-K row: 272 B, 16 rows of one ds_read_b128 hit different banks
+
+template <typename TT, int NP>
+__global__ __launch_bounds__(256, 2) void k_tree_attention_rope(const typename TT::elem *__restrict__ qkv, int n_part_rt, long long part_stride,
+                                                               const float *__restrict__ cs, typename TT::elem *__restrict__ kc,
+                                                               typename TT::elem *__restrict__ vc, float *__restrict__ ws,
+                                                               int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
+                                                               const unsigned long long *__restrict__ mask, const int *__restrict__ d_L,
+                                                               const int *__restrict__ d_n, float scale_log2) {
+    typedef typename TT::elem E;
+    typedef typename TT::vec8 V8;
+    __shared__ __attribute__((aligned(16))) E Vt[ATT_D * VT_STRIDE];
+    __shared__ __attribute__((aligned(16))) E Pw[4 * 16 * P_STRIDE];
+    __shared__ __attribute__((aligned(16))) E Qs[ATT_TILE * QS_STRIDE];       // rotated Q rows; the fresh split reuses it for the new keys' K after its Q fragments are read
+
+    const int h = blockIdx.x, split = blockIdx.y;
+    const bool fresh = split == ATT_SPLITS;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lg = l >> 4;
+    const int row_base = 16 * w;
+    const int group = n_heads / n_kv_heads, kvh = h / group;
+    const int W = (n_heads + 2 * n_kv_heads) * ATT_D;
+    const float *part = reinterpret_cast<const float *>(qkv);
+
+    // 4 consecutive projection-output values at element offset off -> floats of T-rounded values
+    auto ld4 = [&](size_t off, float (&x)[4]) {
+        if constexpr (NP == 0) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(qkv + off);
+            const E *e = reinterpret_cast<const E *>(&raw);
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = (float)e[i];
+        } else if constexpr (NP > 0) {
+            float4 a[NP];
+            const unsigned pst = (unsigned)part_stride;
+#pragma unroll
+            for (int k = 0; k < NP; k++) a[k] = *reinterpret_cast<const float4 *>(part + off + (unsigned)k * pst);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NP; k++) { acc[0] += a[k].x; acc[1] += a[k].y; acc[2] += a[k].z; acc[3] += a[k].w; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = (float)(E)acc[i];      // rounded like the GEMM's own output (k_rope_kv does the same)
+        } else {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < n_part_rt; k++) {
+                const float4 a = *reinterpret_cast<const float4 *>(part + (size_t)k * part_stride + off);
+                acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = (float)(E)acc[i];
+        }
+    };
+    // up to 4 rope units of this thread, all loads first: unit u = (row r = u / 16, elements e = 4 (u % 16) .. + 4 and their partners
+    // 64 further on) of the projection rows [0, rows) at column col0; rotated values -> dst rows (LDS) and, for live rows of the
+    // writer, to the K cache at [L + r]  (HF rotate_half; arithmetic identical to k_rope_kv)
+    auto rope_units = [&](int rows, int col0, E *dst, bool to_cache, const int *pL, const int *pn) {
+        float x1[4][4], x2[4][4];
+        float4 c[4], sn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int u = tid + 256 * k;
+            if (u >= rows * 16) continue;                          // wave-uniform for k >= 1 (rows is a multiple of... any count: guarded again below)
+            const int r = u >> 4, e = 4 * (u & 15);
+            ld4((size_t)r * W + col0 + e, x1[k]);
+            ld4((size_t)r * W + col0 + e + 64, x2[k]);
+            c[k] = *reinterpret_cast<const float4 *>(cs + r * ATT_D + e);
+            sn[k] = *reinterpret_cast<const float4 *>(cs + r * ATT_D + 64 + e);
+        }
+        const int Lw = to_cache ? pL[0] : 0, nn = to_cache ? pn[0] : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int u = tid + 256 * k;
+            if (u >= rows * 16) continue;
+            const int r = u >> 4, e = 4 * (u & 15);
+            const float cc[4] = {c[k].x, c[k].y, c[k].z, c[k].w}, ss[4] = {sn[k].x, sn[k].y, sn[k].z, sn[k].w};
+            E lo[4], hi[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                lo[i] = (E)(x1[k][i] * cc[i] - x2[k][i] * ss[i]);
+                hi[i] = (E)(x2[k][i] * cc[i] + x1[k][i] * ss[i]);
+            }
+            *reinterpret_cast<uint2 *>(dst + r * QS_STRIDE + e) = *reinterpret_cast<const uint2 *>(&lo[0]);
+            *reinterpret_cast<uint2 *>(dst + r * QS_STRIDE + e + 64) = *reinterpret_cast<const uint2 *>(&hi[0]);
+            if (to_cache && r < nn && (long long)Lw + r < max_len) {
+                E *kdst = kc + ((size_t)kvh * max_len + Lw + r) * ATT_D;
+                *reinterpret_cast<uint2 *>(kdst + e) = *reinterpret_cast<const uint2 *>(&lo[0]);
+                *reinterpret_cast<uint2 *>(kdst + e + 64) = *reinterpret_cast<const uint2 *>(&hi[0]);
+            }
+        }
+    };
+
+    // ---- loads that need neither L nor n: mask rows, this workgroup's first tile (cached splits) or the new rows' v (fresh split)
+    unsigned long long mrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) mrow[r] = mask[row_base + 4 * lg + r];
+    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
+    const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
+    const bool may_be_active = row_base < n_q_pad;
+    uint4 kraw[4][4], vra[2], vrb[2];
+    auto load_k = [&](int key0) {
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            int key = key0 + 16 * st + lr;
+            key = key < (int)max_len ? key : (int)max_len - 1;
+            const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) kraw[st][kk] = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
+        }
+    };
+    auto load_v = [&](int key0) {
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+            int ka = key0 + 2 * p, kb = ka + 1;
+            ka = ka < (int)max_len ? ka : (int)max_len - 1; kb = kb < (int)max_len ? kb : (int)max_len - 1;
+            vra[it] = *reinterpret_cast<const uint4 *>(vbase + (size_t)ka * ATT_D + d0);
+            vrb[it] = *reinterpret_cast<const uint4 *>(vbase + (size_t)kb * ATT_D + d0);
+        }
+    };
+    const bool writer = (h % group) == 0;
+    if (!fresh) {
+        if (may_be_active) load_k(split * ATT_TILE);
+        load_v(split * ATT_TILE);
+    } else {
+        // the new rows' v: thread (p, ch) holds rows 2p, 2p + 1 x columns 8 ch .. + 8, exactly what the V^T staging below consumes
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int j = 2 * p + half;
+                uint4 raw = make_uint4(0, 0, 0, 0);
+                if (j < n_q_pad) {
+                    float xa[4], xb[4];
+                    const size_t off = (size_t)j * W + (n_heads + n_kv_heads + kvh) * ATT_D + d0;
+                    ld4(off, xa); ld4(off + 4, xb);
+                    E e[8];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { e[i] = (E)xa[i]; e[4 + i] = (E)xb[i]; }
+                    raw = *reinterpret_cast<const uint4 *>(&e[0]);
+                }
+                if (half == 0) vra[it] = raw; else vrb[it] = raw;
+            }
+        }
+    }
+    // ---- rotated Q rows of all n_q_pad rows -> Qs (every workgroup needs the Q of its head)
+    rope_units(n_q_pad, h * ATT_D, Qs, false, nullptr, nullptr);
+    const int L = d_L[0];
+    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
+    const int ntc = (L + ATT_TILE - 1) / ATT_TILE;
+    const bool has_fresh = n > 0;
+    const int used_c = ntc < 1 ? (has_fresh ? 0 : 1) : (ntc < ATT_SPLITS ? ntc : ATT_SPLITS);   // with nothing to do split 0 still writes an (empty) slot
+    __syncthreads();                                       // Qs complete
+    uint4 qraw[4];
+    {
+        const int qrow = row_base + lr;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            qraw[kk] = qrow < n_q_pad ? *reinterpret_cast<const uint4 *>(Qs + qrow * QS_STRIDE + 32 * kk + 8 * lg) : make_uint4(0, 0, 0, 0);
+    }
+    if (fresh ? !has_fresh : split >= used_c) return;
+    const bool active = row_base < n;
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) mrow[r] = 0ull;
+    if (fresh) {
+        __syncthreads();                                   // every wave has its Q fragments: Qs becomes the new keys' K
+        rope_units(n_q_pad, (n_heads + kvh) * ATT_D, Qs, writer, d_L, d_n);
+        if (writer) {
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+                if (2 * p < n && (long long)L + 2 * p < max_len) *reinterpret_cast<uint4 *>(vc + ((size_t)kvh * max_len + L + 2 * p) * ATT_D + d0) = vra[it];
+                if (2 * p + 1 < n && (long long)L + 2 * p + 1 < max_len) *reinterpret_cast<uint4 *>(vc + ((size_t)kvh * max_len + L + 2 * p + 1) * ATT_D + d0) = vrb[it];
+            }
+        }
+        __syncthreads();                                   // the new keys' K rows are in Qs
+#pragma unroll
+        for (int st = 0; st < 4; st++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                kraw[st][kk] = 16 * st + lr < n_q_pad ? *reinterpret_cast<const uint4 *>(Qs + (16 * st + lr) * QS_STRIDE + 32 * kk + 8 * lg) : make_uint4(0, 0, 0, 0);
+    }
+
+    float m_run[4], l_run[4];
+    floatx4 o[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) o[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    E *Pmine = Pw + w * 16 * P_STRIDE;
+
+    const int t_end = fresh ? 1 : ntc;
+    for (int t = fresh ? 0 : split; t < t_end; t += ATT_SPLITS) {
+        const int key0 = fresh ? L : t * ATT_TILE;
+        if (!fresh && t != split && active) load_k(key0);
+        __syncthreads();                                   // previous tile's Vt / Pw reads are done
+        if (!fresh && t != split) load_v(key0);
+        // ---- stage V^T (key pairs packed per dword); keys beyond the tile's live range are zero: their P is 0, but 0 x garbage could be NaN
+        const int live = fresh ? n : (L - key0 < ATT_TILE ? L - key0 : ATT_TILE);
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+            const uint4 ra = 2 * p < live ? vra[it] : make_uint4(0, 0, 0, 0), rb = 2 * p + 1 < live ? vrb[it] : make_uint4(0, 0, 0, 0);
+            const unsigned short *ea = reinterpret_cast<const unsigned short *>(&ra);
+            const unsigned short *eb = reinterpret_cast<const unsigned short *>(&rb);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                *reinterpret_cast<unsigned int *>(&Vt[(d0 + j) * VT_STRIDE + 2 * p]) = (unsigned int)ea[j] | ((unsigned int)eb[j] << 16);
+        }
+        floatx4 s[4];
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) acc = Mfma<TT>::run(__builtin_bit_cast(V8, qraw[kk]), __builtin_bit_cast(V8, kraw[st][kk]), acc);
+                s[st] = acc;
+            }
+            float tmax[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) tmax[r] = -INFINITY;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const int jl = 16 * st + lr;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool ok = jl < live && (!fresh || ((mrow[r] >> jl) & 1ull));      // cached keys < L are visible to every row
+                    const float v = ok ? s[st][r] * scale_log2 : -INFINITY;
+                    s[st][r] = v;
+                    tmax[r] = fmaxf(tmax[r], v);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = tmax[r];
+                v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
+                v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+                const float m_new = fmaxf(m_run[r], v);
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = exp2f(m_run[r] - m_use);
+                float psum = 0.f;
+#pragma unroll
+                for (int st = 0; st < 4; st++) {
+                    const float p = exp2f(s[st][r] - m_use);
+                    psum += p;
+                    Pmine[(4 * lg + r) * P_STRIDE + 16 * st + lr] = (E)p;
+                }
+                psum += __shfl_xor(psum, 1); psum += __shfl_xor(psum, 2);
+                psum += __shfl_xor(psum, 4); psum += __shfl_xor(psum, 8);
+                l_run[r] = l_run[r] * alpha + psum;
+                m_run[r] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) o[dt][r] *= alpha;
+            }
+        }
+        __syncthreads();                                   // Vt staged, Pw written
+        if (active) {
+            V8 pa[2];
+#pragma unroll
+            for (int kcx = 0; kcx < 2; kcx++)
+                pa[kcx] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4 *>(&Pmine[lr * P_STRIDE + 32 * kcx + 8 * lg]));
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++) {
+#pragma unroll
+                for (int kcx = 0; kcx < 2; kcx++) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(&Vt[(16 * dt + lr) * VT_STRIDE + 32 * kcx + 8 * lg]);
+                    o[dt] = Mfma<TT>::run(pa[kcx], __builtin_bit_cast(V8, raw), o[dt]);
+                }
+            }
+        }
+    }
+    // ---- partial result: ws[slot][row][h][0..127] = O, [128] = m, [129] = l
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = row_base + 4 * lg + r;
+            float *dst = ws + (((size_t)split * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
+            if (row < n_q_pad) {
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) dst[16 * dt + lr] = o[dt][r];
+                if (lr == 0) { dst[ATT_D] = m_run[r]; dst[ATT_D + 1] = l_run[r]; }
+            }
+        }
+    }
+}
+
+// merge of the ATT_SLOTS partials: one workgroup per (row, head), every slot's (m, l, O[d]) requested before anything is consumed
+template <typename E>
+__global__ __launch_bounds__(128) void k_attn_combine_slots(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
+                                                            const int *__restrict__ d_L, const int *__restrict__ d_n) {
+    const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    float mv[ATT_SLOTS], lv[ATT_SLOTS], pv[ATT_SLOTS];
+#pragma unroll
+    for (int s = 0; s < ATT_SLOTS; s++) {
+        const float *p = ws + (((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
+        mv[s] = p[ATT_D]; lv[s] = p[ATT_D + 1]; pv[s] = p[d];
+    }
+    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
+    E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d;
+    if (row >= n) { *dst = (E)0.f; return; }
+    const int ntc = (d_L[0] + ATT_TILE - 1) / ATT_TILE;
+    const int used_c = ntc < ATT_SPLITS ? ntc : ATT_SPLITS;        // n > 0 here, so the fresh slot is live
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < ATT_SLOTS; s++) if (s < used_c || s == ATT_SPLITS) M = fmaxf(M, mv[s]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int s = 0; s < ATT_SLOTS; s++) {
+        if (!(s < used_c || s == ATT_SPLITS) || mv[s] == -INFINITY) continue;
+        const float wgt = exp2f(mv[s] - M);
+        num += wgt * pv[s]; den += wgt * lv[s];
+    }
+    *dst = (E)(den > 0.f ? num / den : 0.f);
+}
+
+// ================================================================================================
 // Token Recycle (S/tree_model/token_recycle/token_recycle.py:33-60)
 // ================================================================================================
 struct samd_recycle {
@@ -530,6 +856,37 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
         hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n);
     }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int64_t samd_tree_attention_rope_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim) {
+    return (int64_t)ATT_SLOTS * n_q_pad * n_heads * (head_dim + 2) * 4;
+}
+
+// samd_rope_kv_write + samd_tree_attention in two launches instead of three: d_qkv is the q|k|v projection's output (dtype rows, or
+// n_partials fp32 partial sums of partial_stride elements each), d_cs the per-row cos|sin of samd_rope_rows; K / V rows of the n new
+// keys are written to the (row-major) caches at [L, L + n)
+int samd_tree_attention_rope(const void *d_qkv, int32_t n_partials, int64_t partial_stride, const float *d_cs, void *d_k_cache, void *d_v_cache,
+                             void *d_out, int32_t dtype, int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                             const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace,
+                             int64_t workspace_bytes, void *stream) {
+    if (!d_qkv || !d_cs || !d_k_cache || !d_v_cache || !d_out || !d_mask || !d_cache_length || !d_n || !d_workspace) { samd_set_error("samd_tree_attention_rope: null pointer"); return SAMD_E_INVALID; }
+    if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || n_partials < 0 ||
+        (dtype != SAMD_F16 && dtype != SAMD_BF16) || workspace_bytes < samd_tree_attention_rope_workspace(n_q_pad, n_heads, head_dim)) {
+        samd_set_error("samd_tree_attention_rope: unsupported shape (head_dim must be 128, n_q_pad <= 64, f16/bf16) or workspace too small");
+        return SAMD_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const float scale_log2 = scale * 1.4426950408889634f;
+    float *ws = (float *)d_workspace;
+#define GO(TT, NP, ET) hipLaunchKernelGGL((k_tree_attention_rope<TT, NP>), dim3(n_heads, ATT_SLOTS), dim3(256), 0, st, (const ET *)d_qkv, n_partials, (long long)partial_stride, \
+        d_cs, (ET *)d_k_cache, (ET *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len, (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2)
+#define GO2(TT, ET) do { if (n_partials == 0) GO(TT, 0, ET); else if (n_partials == 2) GO(TT, 2, ET); else if (n_partials == 5) GO(TT, 5, ET); else GO(TT, -1, ET); \
+        hipLaunchKernelGGL(k_attn_combine_slots<ET>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (ET *)d_out, n_q_pad, n_heads, d_cache_length, d_n); } while (0)
+    if (dtype == SAMD_F16) GO2(F16, _Float16); else GO2(BF16, __bf16);
+#undef GO2
+#undef GO
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -102,6 +102,9 @@ _PROTOS = {
                                       _VP, _I64, _VP]),
     "samd_rope_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_attention_block": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _F32, _VP]),
+    "samd_tree_attention_rope_workspace": (_I64, [_I32, _I32, _I32]),
+    "samd_tree_attention_rope": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32, _VP, _I64, _VP]),
+    "samd_rope_kv_write_cs": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I64, _VP]),
     "samd_rope_kv_write_vt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
     "samd_kv_compact_vt": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
     "samd_kv_compact_indices_vt": (C.c_int, [_VP, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _VP, _I32, _VP]),

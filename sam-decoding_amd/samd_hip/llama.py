@@ -89,13 +89,18 @@ class LlamaRunner:
         # does not fit (say a fine-tune's 32001-row lm_head) goes to the library GEMM on its own, the others keep the kernel
         streams = lambda t: bool(native_gemm) and t.shape[0] % 128 == 0 and t.shape[1] % 256 == 0
         self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 64))     # tuning knob; see forward_rows
-        # the attention block of a layer: "split" = RoPE + K/V row write, tree attention over 16 KV splits, split merge (three launches,
-        # row-major V cache); "block" = samd_attention_block (one launch, V cached transposed, masks with a visible prefix).  Measured
-        # per layer at Vicuna-7B head geometry (profiles/r02_attention_variants.md): split 16.8 us vs block 22.8 us at L = 800 -- one
-        # workgroup per head pays a memory round trip per 512 keys where the splits run side by side -- so the base model's verify keeps
-        # "split"; a draft head's tree levels need the visible prefix and run "block" (one layer, short contexts).
+        # the attention block of a layer (profiles/r02_attention_variants.md has the per-layer times at Vicuna-7B head geometry):
+        #   "split"  = samd_rope_kv_write_cs (per-row cos | sin prepared once per forward: one memory round trip instead of two),
+        #              samd_tree_attention over 16 KV splits, its merge -- three launches, row-major V cache;
+        #   "split3" = the round-1 form of the same: RoPE from the position tables (kept for A/B);
+        #   "split2" = samd_tree_attention_rope: the splits rotate their own Q rows, one more workgroup owns the n new keys (RoPE, K/V
+        #              row write), then the merge of the 17 slots -- two launches; measured SLOWER than three (every split redoes the
+        #              rotation; the prologue sits in front of every workgroup's first MFMA): 18.7 vs 16.7 us at 16 rows, 30 vs 23 at 64;
+        #   "block"  = samd_attention_block: one launch, V cached transposed, masks with a visible prefix.  One workgroup per head pays
+        #              a memory round trip per 512 keys where the splits run side by side (22.8 vs 16.8 us at L = 800), so the base
+        #              model's verify does not use it; a draft head's tree levels need the visible prefix and do (one layer).
         self.attention = attention or os.environ.get("SAMD_ATTENTION", "split")
-        if self.attention not in ("split", "block"):
+        if self.attention not in ("split", "split2", "split3", "block"):
             raise SamdError(f"unknown attention mode '{self.attention}'")
         self.v_transposed = self.attention == "block"
         # second copy of the projection weights in the streaming kernel's packed layout (samd_gemm_pack_weights): the
@@ -234,7 +239,7 @@ class LlamaRunner:
             s, dt, dev = self.shape, self.dtype, self.device
             RP = max(R, 16) if self.native_gemm else R           # the skinny GEMM reads 16 / 32 / 64 rows (pad rows are zero)
             z = lambda r, *sz: torch.zeros((max(r, RP),) + sz, dtype=dt, device=dev)
-            ws_bytes = lib().samd_tree_attention_workspace(R, s.heads, s.head_dim)
+            ws_bytes = max(lib().samd_tree_attention_workspace(R, s.heads, s.head_dim), lib().samd_tree_attention_rope_workspace(R, s.heads, s.head_dim))
             part_elems = 0
             if self.native_gemm:
                 qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
@@ -282,12 +287,12 @@ class LlamaRunner:
             b["x"][:rows_in].copy_(x_in[:rows_in])                # rows past d_n are never consumed
         head = getattr(self, "draft_head", False)
         block = self.attention == "block"
-        if block:
+        if self.attention != "split3":
             # cos / sin of every row's position (visible length + relative position), once per forward: the attention launches of all
             # layers read them without first having to wait for L
             check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_vis if d_vis is not None else d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R,
                                    s.head_dim, self.rope_rows, st))
-        elif d_vis is not None:
+        if d_vis is not None and not block:
             raise SamdError("a visible length different from the write position needs attention mode 'block'")
         delta, dn, dstride = None, 0, 0
         packed = self.wp["layers"] if self.wp else [{}] * len(self.w["layers"])
@@ -302,10 +307,18 @@ class LlamaRunner:
                 # RoPE + K row / V^T column write + tree attention + merge of the tile partials: one launch (csrc/attn_kernels.hip)
                 check(L.samd_attention_block(_ptr(src), n_p, stride, _ptr(b["cs"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R,
                                              s.heads, s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_vis), _ptr(d_n), self.scale, st))
+            elif self.attention == "split2":
+                check(L.samd_tree_attention_rope(_ptr(src), n_p, stride, _ptr(b["cs"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R,
+                                                 s.heads, s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                                                 _ptr(b["ws"]), b["ws_bytes"], st))
             else:
-                check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
-                                           _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
-                                           s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
+                if self.attention == "split":
+                    check(L.samd_rope_kv_write_cs(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(b["cs"]), _ptr(b["q"]), _ptr(self.kv[li, 0]),
+                                                  _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads, s.head_dim, self.max_len, dt, n_p, stride, st))
+                else:
+                    check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
+                                               _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
+                                               s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
                 check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
                                             s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
                                             _ptr(b["ws"]), b["ws_bytes"], st))

@@ -1,6 +1,8 @@
 """attn_bench.py -- the attention block of one decoder layer, x32 layers in one hipGraph (Vicuna-7B head geometry, fp16, q|k|v from
 2 fp32 split-K partials as the streaming GEMM leaves them): microseconds per layer of
-   unfused  samd_rope_kv_write + samd_tree_attention (+ its combine launch)          -- three launches
+   split3   samd_rope_kv_write + samd_tree_attention (+ its combine launch)                                         -- three launches
+   split    the same with samd_rope_kv_write_cs (cos | sin per row prepared once per forward)                        -- three launches
+   split2   samd_tree_attention_rope (RoPE and the K/V row write inside the split kernel) + the slot merge           -- two launches
    block    samd_attention_block (V cached transposed; one workgroup per head and 16 rows)                          -- one launch
 usage: python scripts/attn_bench.py [L]"""
 import math, os, sys
@@ -45,8 +47,26 @@ for R in (8, 16, 32, 64):
             check(Lib.samd_attention_block(_ptr(part), 2, RP * W, _ptr(cs), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, Hkv, D, max_len,
                                            _ptr(mask), _ptr(d_L), None, _ptr(d_n), scale, st))
 
+    ws2 = torch.zeros(Lib.samd_tree_attention_rope_workspace(R, H, D), dtype=torch.uint8, device="cuda")
+
+    def split2():
+        st = current_stream()
+        check(Lib.samd_rope_rows(_ptr(rel), _ptr(d_L), _ptr(cos), _ptr(sin), _ptr(cs), R, D, max_len, st))
+        for li in range(layers):
+            check(Lib.samd_tree_attention_rope(_ptr(part), 2, RP * W, _ptr(cs), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, Hkv, D, max_len,
+                                               _ptr(mask), _ptr(d_L), _ptr(d_n), scale, _ptr(ws2), ws2.numel(), st))
+
+    def split_cs():
+        st = current_stream()
+        check(Lib.samd_rope_rows(_ptr(rel), _ptr(d_L), _ptr(cos), _ptr(sin), _ptr(cs), R, D, max_len, st))
+        for li in range(layers):
+            check(Lib.samd_rope_kv_write_cs(_ptr(part), _ptr(rel), _ptr(d_L), _ptr(d_n), _ptr(cs), _ptr(q), _ptr(kv[li, 0]), _ptr(kv[li, 1]), R, H, Hkv, D,
+                                            max_len, samd_hip.F16, 2, RP * W, st))
+            check(Lib.samd_tree_attention(_ptr(q), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, Hkv, D, max_len, _ptr(mask), _ptr(d_L), _ptr(d_n),
+                                          scale, _ptr(ws), ws.numel(), st))
+
     res = {}
-    for name, fn in (("unfused", unfused), ("block", fused)):
+    for name, fn in (("split3", unfused), ("split", split_cs), ("split2", split2), ("block", fused)):
         ws.zero_()
         fn(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()

@@ -104,6 +104,28 @@ def test_attention_block_matches_unfused_writes_and_sdpa(dtype, H, Hkv, L, n, n_
     err = (got - want).abs().max().item()
     assert err < TOL[dtype] * max(1.0, want.abs().max().item()), err
     assert (out[n:] == 0).all()
+    # samd_rope_kv_write_cs (cos | sin per row from samd_rope_rows instead of the position tables): bit-identical q / K / V
+    kc4, vc4, q4 = kc0.clone(), vc0.clone(), torch.zeros_like(q_ref)
+    cs4 = torch.zeros((64, D), dtype=torch.float32, device="cuda")
+    check(lib().samd_rope_rows(_ptr(rel), _ptr(d_L), _ptr(cos), _ptr(sin), _ptr(cs4), max(n_pad, 16) if rows >= 16 else n_pad, D, max_len, current_stream()))
+    check(lib().samd_rope_kv_write_cs(_ptr(src), _ptr(rel), _ptr(d_L), _ptr(d_n), _ptr(cs4), _ptr(q4), _ptr(kc4), _ptr(vc4), rows, H, Hkv, D, max_len,
+                                      torch_dtype_code(dtype), n_p, stride, current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(q4[:n], q_ref[:n]) and torch.equal(kc4[:, :L + n], kc_ref[:, :L + n]) and torch.equal(vc4[:, :L + n], vc_ref[:, :L + n])
+    # samd_tree_attention_rope (two launches, row-major V): bit-identical K / V rows, output within the same tolerance
+    kc3, vc3 = kc0.clone(), vc0.clone()
+    ws3 = torch.zeros(lib().samd_tree_attention_rope_workspace(n_pad, H, D), dtype=torch.uint8, device="cuda")
+    out3 = torch.full((n_pad, H, D), 3.0, device="cuda").to(dtype)
+    cs3 = torch.zeros((64, D), dtype=torch.float32, device="cuda")
+    check(lib().samd_rope_rows(_ptr(rel), _ptr(d_L), _ptr(cos), _ptr(sin), _ptr(cs3), n_pad, D, max_len, current_stream()))
+    check(lib().samd_tree_attention_rope(_ptr(src), n_p, stride, _ptr(cs3), _ptr(kc3), _ptr(vc3), _ptr(out3), torch_dtype_code(dtype), n_pad, H, Hkv, D, max_len,
+                                         _ptr(mask), _ptr(d_L), _ptr(d_n), 1.0 / math.sqrt(D), _ptr(ws3), ws3.numel(), current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(kc3[:, :L + n], kc_ref[:, :L + n]) and torch.equal(vc3[:, :L + n], vc_ref[:, :L + n])
+    assert torch.isnan(kc3[:, L + n:].float()).all() and torch.isnan(vc3[:, L + n:].float()).all()
+    err3 = (out3[:n].float() - want).abs().max().item()
+    assert torch.isfinite(out3[:n].float()).all() and err3 < TOL[dtype] * max(1.0, want.abs().max().item()), err3
+    assert (out3[n:] == 0).all()
     # samd_rope_kv_write_vt writes the same V^T columns (and the same K rows) as the block kernel
     kc2, vt2 = kc0.clone(), vc0.transpose(1, 2).contiguous()
     q2 = torch.zeros_like(q_ref)

@@ -34,7 +34,7 @@ def dev(a):
     return torch.as_tensor(np.asarray(a, dtype=np.int32)).cuda()
 
 
-@pytest.mark.parametrize("attention", ["split", "block"])
+@pytest.mark.parametrize("attention", ["split", "split2", "split3", "block"])
 @pytest.mark.parametrize("kv_heads", [2, 1])
 def test_prefill_and_tree_verify_match_hf(kv_heads, attention):
     """both attention modes of the runner: "split" (RoPE / split attention / merge launches, row-major V cache) and "block"
