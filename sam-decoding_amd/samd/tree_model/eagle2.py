@@ -185,13 +185,13 @@ class Eagle2Head(torch.nn.Module):
 
     @torch.no_grad()
     def topk_generate_device(self, dh, hidden_states, input_ids, head_weight=None):
-        """topk_generate with every head forward on the library's kernels (device_head.DeviceHead `dh`); same tree logic.
-        Each level's forward carries all tree nodes chosen so far (stateless levels, see device_head.py)."""
-        last_hidden, last_logits = dh.extend(hidden_states, input_ids[1:])
-        return dh.expand("eagle2", lambda h, lg, tok: self._expand_device(dh, h, lg, tok), last_hidden, last_logits, input_ids[-1:].clone())
+        """topk_generate with every head forward on the library's kernels (device_head.DeviceHead `dh`); same tree logic, stateful
+        levels (8 new rows each, earlier levels stay in the head's cache), the whole draft replayed as one hipGraph."""
+        return dh.eagle2_draft(self, hidden_states, input_ids)
 
-    def _expand_device(self, dh, last_hidden, last_logits, sample_token):
-        """the level loop of topk_generate on device tensors only (fixed shapes, no host round trip): capturable"""
+    def _expand_levels(self, dh, last_hidden, last_logits, sample_token):
+        """the level loop of topk_generate on device tensors only (fixed shapes, no host round trip): capturable.  Mirrors
+        eagle2_model.py:848-913 step by step: the same top-k calls in the same order."""
         top_k, dev = self.top_k, last_hidden.device
         logp = torch.log_softmax(last_logits.float(), dim=-1)
         top = self._topk(logp, top_k)
@@ -201,19 +201,8 @@ class Eagle2Head(torch.nn.Module):
         in_hidden = last_hidden.repeat(top_k, 1)
         level_mask = torch.eye(top_k, device=dev)
         cs_index = torch.arange(top_k, device=dev)
-        x_rows = torch.empty((0, self.hidden), dtype=last_hidden.dtype, device=dev)
-        anc = torch.zeros((0, 0), device=dev)
-        depth = torch.empty(0, dtype=torch.int32, device=dev)
         for i in range(self.depth):
-            n0 = x_rows.shape[0]
-            x_rows = torch.cat((x_rows, dh._x(ids, in_hidden)), dim=0)
-            grown = torch.zeros((n0 + top_k, n0 + top_k), device=dev)
-            grown[:n0, :n0] = anc
-            grown[n0:] = level_mask
-            anc = grown
-            depth = torch.cat((depth, torch.full((top_k,), i, dtype=torch.int32, device=dev)))
-            out_all, logits_all = dh.tree(x_rows, depth, anc)
-            out, logits = out_all[n0:], logits_all[n0:]
+            out, logits = dh.level(i, ids, in_hidden, level_mask)
             bias = 1 + top_k ** 2 * max(0, i - 1) + (top_k if i > 0 else 0)
             parents_list.append(cs_index + bias)
             logp = torch.log_softmax(logits.float(), dim=-1)
@@ -230,7 +219,7 @@ class Eagle2Head(torch.nn.Module):
         all_scores = torch.cat(scores_list, dim=0).view(-1)
         all_tokens = torch.cat(tokens_list, dim=0).view(-1)
         keep = torch.sort(self._topk(all_scores, self.total_tokens).indices).values
-        draft_tokens = torch.cat((sample_token, all_tokens[keep]), dim=0)
+        draft_tokens = torch.cat((sample_token.reshape(1), all_tokens[keep]), dim=0)
         draft_parents = torch.cat(parents_list, dim=0)[keep // top_k].long()
         mask_index = torch.searchsorted(keep, draft_parents - 1, right=False)
         mask_index = torch.where(draft_parents == 0, torch.full_like(mask_index, -1), mask_index)

@@ -259,11 +259,12 @@ class TreeModelEngine(DecodeEngine):
         torch.cuda.current_stream().synchronize()
         return StepReport(self._report_np)
 
-    def _maybe_tree(self, rep):
+    def _maybe_tree(self, rep, start_token=None):
         if rep.type != 2:
             return rep
-        d = self.session.read_draft()
-        start = torch.tensor([d.tokens[0]], dtype=torch.long, device=self.device)
+        if start_token is None:                                  # after the prefill: the deferred draft's root is the start token
+            start_token = self.session.read_draft().tokens[0]
+        start = torch.tensor([start_token], dtype=torch.long, device=self.device)
         tokens, parents = self.tm.gen_draft_device(start)
         self._keep = (tokens.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous())
         self.session.set_draft(self._keep[0], self._keep[1], int(tokens.numel()), type_=1)
@@ -294,4 +295,4 @@ class TreeModelEngine(DecodeEngine):
         rows = [k if k >= 0 else n_next - 1 for k in rep.kv_index]       # -1 padding selects the last tree node (SO/samd_model.py:144)
         hs = self.verifier.hidden_rows(R)[torch.tensor(rows, dtype=torch.long, device=self.device)]
         self.tm.update(tokens=torch.tensor(rep.tokens, dtype=torch.long, device=self.device), last_hidden_states=hs)
-        return self._maybe_tree(rep)
+        return self._maybe_tree(rep, rep.next_token)            # the accept step left the bonus token as the next start token
