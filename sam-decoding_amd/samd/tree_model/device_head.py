@@ -7,15 +7,13 @@ EAGLE-2's tree levels are STATEFUL, as in the reference (eagle2_model.py:856-913
 K/V behind the rows of the earlier levels ([L + 8 i, L + 8 i + 8) of the head's cache) and attends to the L accepted tokens plus
 the ancestors among the 8 (i + 1) tree rows -- the attention kernel's visible-prefix mask (samd_attention_block: keys < L visible to
 every row, key L + j by bit j).  Nothing has to be rolled back afterwards: L only ever counts accepted tokens, the next draft
-overwrites the tree rows.  The whole draft -- the accepted tokens' extension, five levels, the top-62 re-rank -- is ONE hipGraph per
-row bucket of the extension (`eagle2_draft`).  EAGLE v1's static tree keeps the older STATELESS form (`tree`): the forward of level i
+overwrites the tree rows.  Every head forward (the accepted tokens' extension, then one 8-row forward per level) replays its row
+bucket's hipGraph; the tree logic in between stays a handful of device-side PyTorch ops (`eagle2_draft`).  EAGLE v1's static tree keeps the older STATELESS form (`tree`): the forward of level i
 carries every node-with-children so far, with their ancestor mask.  Positions are the reference's (accepted length + depth).
 
 Arithmetic is the same as Eagle2Head.forward's up to fp16 accumulation order; drafts are verified by the base model either
 way, so the generated text cannot change (tests/test_gpu_llama.py checks losslessness through this path)."""
 from typing import Optional
-
-import os
 
 import torch
 import torch.nn.functional as F
@@ -68,15 +66,9 @@ class DeviceHead:
         self.x_buf = torch.zeros((MAX_ROWS, head.hidden), dtype=dt, device=dev)
         self.mask_buf = torch.zeros(MAX_ROWS, dtype=torch.int64, device=dev)
         self._graphs = {}                                 # row bucket -> hipGraph of one head forward over the static buffers
-        # EAGLE-2 whole-draft graphs: staged inputs, device-side counts
-        self._draft_graphs = {}                           # extension row bucket -> (hipGraph, tokens, parents)
-        self.in_hidden = torch.zeros((MAX_ROWS, head.hidden), dtype=dt, device=dev)
-        self.in_ids = torch.zeros(MAX_ROWS + 1, dtype=torch.long, device=dev)
-        self.n_last = torch.zeros(1, dtype=torch.long, device=dev)     # index of the last accepted row inside the bucket
-        self.Lw = torch.zeros(1, dtype=torch.int32, device=dev)       # write position of the current tree level
-        self.n8 = torch.full((1,), 8, dtype=torch.int32, device=dev)
+        # stateful tree levels (EAGLE-2): write position of the current level, per-level relative positions
+        self.Lw = torch.zeros(1, dtype=torch.int32, device=dev)
         self.level_pos = [torch.full((MAX_ROWS,), i, dtype=torch.int32, device=dev) for i in range(8)]
-        self.level_mask = torch.zeros(MAX_ROWS, dtype=torch.int64, device=dev)
         self.length = 0                                   # host mirror of L: accepted tokens in the head's cache
         chain = [(1 << (i + 1)) - 1 for i in range(MAX_ROWS)]
         self.chain_mask = torch.tensor([r - (1 << 64) if r >= (1 << 63) else r for r in chain], dtype=torch.int64, device=dev)
@@ -104,24 +96,29 @@ class DeviceHead:
         x = part[:, :n].sum(0)
         return (x + self.fc_b.float() if self.fc_b is not None else x).to(self.embed.dtype)
 
-    def _forward(self, x: torch.Tensor, relpos: torch.Tensor, mask: torch.Tensor):
+    def _forward(self, x: torch.Tensor, relpos: torch.Tensor, mask: torch.Tensor, level: bool = False):
         """one head forward over n <= 64 rows.  Inputs are staged into fixed buffers and the launch sequence of the row
-        bucket is replayed as a hipGraph (captured on first use): ~15 kernel launches become one."""
+        bucket is replayed as a hipGraph (captured on first use): ~15 kernel launches become one.  level = a stateful tree level:
+        the rows are written at Lw (behind the earlier levels' rows) and see the first L keys plus the tree rows their mask names."""
         n = x.shape[0]
         R = self.runner.bucket(n)
         self.n.fill_(n)
         self.x_buf[:n].copy_(x)
         self.relpos_buf[:MAX_ROWS].copy_(relpos[:MAX_ROWS])
         self.mask_buf.copy_(mask)
-        g = self._graphs.get(R)
+        key = ("level", R) if level else R
+        g = self._graphs.get(key)
         if g is None:
-            run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.L, self.n, x_in=self.x_buf)
+            if level:
+                run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.Lw, self.n, x_in=self.x_buf, d_vis=self.L)
+            else:
+                run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.L, self.n, x_in=self.x_buf)
             run()                                                  # library handles / workspaces exist before capture
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 run()
-            self._graphs[R] = g
+            self._graphs[key] = g
         g.replay()
         b = self.runner._buffers(R)
         return b["x"][:n], b["logits"][:n]
@@ -144,69 +141,23 @@ class DeviceHead:
         self.relpos[:depth.numel()] = depth.to(torch.int32)
         return self._forward(x_rows, self.relpos, _mask_rows(anc))
 
-    # ---- EAGLE-2: the whole draft as one graph ------------------------------------------------------------------------
-    def _extend_bucket(self, R):
-        """the staged accepted rows (in_hidden / in_ids, n rows live) enter the head's cache; -> (last output state [1, H], logits [1, V])"""
-        x = self._x(self.in_ids[1:R + 1], self.in_hidden[:R])
-        self.x_buf[:R].copy_(x)
-        b = self.runner.forward_rows(R, self.tok, self.chain_pos, self.chain_mask, self.L, self.n, x_in=self.x_buf)
-        last = torch.index_select(b["x"], 0, self.n_last)
-        logits = torch.index_select(b["logits"], 0, self.n_last)
-        self.L.add_(self.n)                                # L counts accepted tokens; device-side so the graph replays for any n
-        return last, logits
-
+    # ---- EAGLE-2: stateful tree levels -------------------------------------------------------------------------------
     def level(self, i, ids, hidden, anc_rows):
         """tree level i (8 rows) on top of the earlier levels' rows in the cache: ids [8], hidden [8, H], anc_rows [8, 8 (i + 1)] 0/1
         (row r sees tree row j) -> (output states [8, H], logits [8, V]); views into the bucket's buffers: consume before the next call"""
-        x = self._x(ids, hidden)
-        self.x_buf[:8].copy_(x)
-        torch.add(self.L, 8 * i, out=self.Lw)
-        bits = (anc_rows.to(torch.int64) << torch.arange(anc_rows.shape[1], device=anc_rows.device, dtype=torch.int64)[None, :]).sum(-1)
-        self.level_mask[:8] = bits
-        b = self.runner.forward_rows(8, self.tok, self.level_pos[i], self.level_mask, self.Lw, self.n8, x_in=self.x_buf, d_vis=self.L)
-        return b["x"][:8], b["logits"][:8]
+        n = ids.numel()
+        torch.add(self.L, n * i, out=self.Lw)
+        return self._forward(self._x(ids, hidden), self.level_pos[i], _mask_rows(anc_rows), level=True)
 
     def eagle2_draft(self, head, hidden_states, input_ids):
         """Eagle2Head.topk_generate on the library's kernels: hidden_states [T, H] of the accepted tokens, input_ids [T + 1] ->
-        (tokens [63], parents [63]).  T <= 64 rows go through one captured graph per row bucket; a longer run (the prompt) is
-        extended in 64-row pieces first."""
-        T = hidden_states.shape[0]
-        while T > MAX_ROWS:
-            self.extend(hidden_states[:MAX_ROWS], input_ids[1:MAX_ROWS + 1])
-            hidden_states, input_ids, T = hidden_states[MAX_ROWS:], input_ids[MAX_ROWS:], T - MAX_ROWS
-        R = self.runner.bucket(T)
-        self.in_hidden.zero_()
-        self.in_hidden[:T].copy_(hidden_states)
-        self.in_ids.zero_()
-        self.in_ids[:T + 1].copy_(input_ids)
-
-        def stage(n):
-            self.n.fill_(n)
-            self.n_last.fill_(max(n - 1, 0))
-
-        def run():
-            last, logits = self._extend_bucket(R)
-            sample = torch.index_select(self.in_ids, 0, self.n_last + 1)
-            return head._expand_levels(self, last, logits, sample)
-
-        if head.trace is not None or os.environ.get("SAMD_EAGLE_GRAPH", "1") == "0":     # decision traces copy to the host: run eagerly
-            stage(T)
-            out = run()
-            self.length += T
-            return out
-        entry = self._draft_graphs.get(R)
-        if entry is None:
-            stage(0)                                       # warm-up with no live row: L stays, tree rows land beyond it
-            run()
-            torch.cuda.current_stream().synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = run()
-            entry = self._draft_graphs[R] = (g, out[0], out[1])
-        stage(T)
-        entry[0].replay()
-        self.length += T
-        return entry[1].clone(), entry[2].clone()
+        (tokens [63], parents [63]).  Every head forward replays its bucket's hipGraph (the accepted tokens' extension, then one
+        8-row forward per level); the tree logic between them is a handful of small PyTorch ops on the device, launched ahead
+        of the GPU.  (Capturing the WHOLE draft -- forwards and PyTorch ops -- as one hipGraph per extension bucket replays
+        correctly as long as at most two such graphs exist; with a third, replaying the second one faults: measured on ROCm 7.2,
+        scripts/_debug_eagle2.py.  The per-forward graphs hold only this library's launches over fixed buffers and do not.)"""
+        last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
+        return head._expand_levels(self, last_hidden, last_logits, input_ids[-1:].clone())
 
     def expand(self, key, fn, *inputs):
         """run `fn(*inputs) -> tuple of tensors`, a whole tree expansion (fixed shapes, data-dependent values, no host round

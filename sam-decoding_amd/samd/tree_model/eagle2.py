@@ -186,7 +186,7 @@ class Eagle2Head(torch.nn.Module):
     @torch.no_grad()
     def topk_generate_device(self, dh, hidden_states, input_ids, head_weight=None):
         """topk_generate with every head forward on the library's kernels (device_head.DeviceHead `dh`); same tree logic, stateful
-        levels (8 new rows each, earlier levels stay in the head's cache), the whole draft replayed as one hipGraph."""
+        levels (8 new rows each, earlier levels stay in the head's cache), every forward a hipGraph replay."""
         return dh.eagle2_draft(self, hidden_states, input_ids)
 
     def _expand_levels(self, dh, last_hidden, last_logits, sample_token):
