@@ -22,9 +22,9 @@ MAX_ROWS = 64
 
 
 def _mask_rows(anc: torch.Tensor) -> torch.Tensor:
-    """anc [n, n] 0/1 (row i sees column j) -> int64[64] bit rows for samd_tree_attention"""
-    n = anc.shape[0]
-    bits = (anc.to(torch.int64) << torch.arange(n, device=anc.device, dtype=torch.int64)[None, :]).sum(-1)
+    """anc [n, m] 0/1 (row i sees column j; m <= 64) -> int64[64] bit rows for the attention kernels"""
+    n, m = anc.shape
+    bits = (anc.to(torch.int64) << torch.arange(m, device=anc.device, dtype=torch.int64)[None, :]).sum(-1)
     out = torch.zeros(MAX_ROWS, dtype=torch.int64, device=anc.device)
     out[:n] = bits
     return out
