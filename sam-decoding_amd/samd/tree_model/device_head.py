@@ -15,6 +15,8 @@ Arithmetic is the same as Eagle2Head.forward's up to fp16 accumulation order; dr
 way, so the generated text cannot change (tests/test_gpu_llama.py checks losslessness through this path)."""
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -66,6 +68,7 @@ class DeviceHead:
         self.x_buf = torch.zeros((MAX_ROWS, head.hidden), dtype=dt, device=dev)
         self.mask_buf = torch.zeros(MAX_ROWS, dtype=torch.int64, device=dev)
         self._graphs = {}                                 # row bucket -> hipGraph of one head forward over the static buffers
+        self._levels_graph = None                         # EAGLE-2: (hipGraph of the five levels + re-rank, tokens, parents)
         # stateful tree levels (EAGLE-2): write position of the current level, per-level relative positions
         self.Lw = torch.zeros(1, dtype=torch.int32, device=dev)
         self.level_pos = [torch.full((MAX_ROWS,), i, dtype=torch.int32, device=dev) for i in range(8)]
@@ -149,15 +152,46 @@ class DeviceHead:
         torch.add(self.L, n * i, out=self.Lw)
         return self._forward(self._x(ids, hidden), self.level_pos[i], _mask_rows(anc_rows), level=True)
 
+    def _level_eager(self, i, ids, hidden, anc_rows):
+        """level() without the per-forward graph: plain launches (inside the whole-draft capture)"""
+        n = ids.numel()
+        torch.add(self.L, n * i, out=self.Lw)
+        self.n.fill_(n)
+        self.x_buf[:n].copy_(self._x(ids, hidden))
+        self.mask_buf.copy_(_mask_rows(anc_rows))
+        b = self.runner.forward_rows(8, self.tok, self.level_pos[i], self.mask_buf, self.Lw, self.n, x_in=self.x_buf, d_vis=self.L)
+        return b["x"][:n], b["logits"][:n]
+
     def eagle2_draft(self, head, hidden_states, input_ids):
         """Eagle2Head.topk_generate on the library's kernels: hidden_states [T, H] of the accepted tokens, input_ids [T + 1] ->
-        (tokens [63], parents [63]).  Every head forward replays its bucket's hipGraph (the accepted tokens' extension, then one
-        8-row forward per level); the tree logic between them is a handful of small PyTorch ops on the device, launched ahead
-        of the GPU.  (Capturing the WHOLE draft -- forwards and PyTorch ops -- as one hipGraph per extension bucket replays
-        correctly as long as at most two such graphs exist; with a third, replaying the second one faults: measured on ROCm 7.2,
-        scripts/_debug_eagle2.py.  The per-forward graphs hold only this library's launches over fixed buffers and do not.)"""
+        (tokens [63], parents [63]).  The accepted tokens enter the head's cache through the per-bucket forward graphs (`extend`);
+        the five levels and the top-62 re-rank -- five 8-row forwards and ~150 small PyTorch ops with fixed shapes -- replay as ONE
+        hipGraph (`_levels_graph`): launched one by one they keep the host busy for longer (3.7 ms) than the GPU needs (2 ms).
+        Only ONE graph of this kind exists per head: graphs that contain PyTorch allocations stopped replaying correctly once a third
+        one was captured (ROCm 7.2; the second one faults, scripts/_debug_eagle2.py) -- so the extension, whose row bucket varies,
+        stays outside it."""
         last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
-        return head._expand_levels(self, last_hidden, last_logits, input_ids[-1:].clone())
+        if head.trace is not None or os.environ.get("SAMD_EAGLE_GRAPH", "1") == "0":      # decision traces copy to the host: eager
+            return head._expand_levels(self, last_hidden, last_logits, input_ids[-1:].clone())
+        if self._levels_graph is None:
+            self.lv_hidden = torch.zeros_like(last_hidden)
+            self.lv_logits = torch.zeros_like(last_logits)
+            self.lv_sample = torch.zeros(1, dtype=torch.long, device=last_hidden.device)
+            level, self.level = self.level, self._level_eager
+            try:
+                head._expand_levels(self, self.lv_hidden, self.lv_logits, self.lv_sample)       # warm-up: tree rows land beyond L
+                torch.cuda.current_stream().synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = head._expand_levels(self, self.lv_hidden, self.lv_logits, self.lv_sample)
+            finally:
+                self.level = level
+            self._levels_graph = (g, out[0], out[1])
+        self.lv_hidden.copy_(last_hidden)
+        self.lv_logits.copy_(last_logits)
+        self.lv_sample.copy_(input_ids[-1:])
+        self._levels_graph[0].replay()
+        return self._levels_graph[1].clone(), self._levels_graph[2].clone()
 
     def expand(self, key, fn, *inputs):
         """run `fn(*inputs) -> tuple of tensors`, a whole tree expansion (fixed shapes, data-dependent values, no host round
