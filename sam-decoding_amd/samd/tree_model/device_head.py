@@ -111,11 +111,15 @@ class DeviceHead:
         self.mask_buf.copy_(mask)
         key = ("level", R) if level else R
         g = self._graphs.get(key)
+        if level:
+            run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.Lw, self.n, x_in=self.x_buf, d_vis=self.L)
+        else:
+            run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.L, self.n, x_in=self.x_buf)
+        if os.environ.get("SAMD_HEAD_GRAPH", "1") == "0":          # debugging: plain launches
+            run()
+            b = self.runner._buffers(R)
+            return b["x"][:n], b["logits"][:n]
         if g is None:
-            if level:
-                run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.Lw, self.n, x_in=self.x_buf, d_vis=self.L)
-            else:
-                run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.L, self.n, x_in=self.x_buf)
             run()                                                  # library handles / workspaces exist before capture
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
