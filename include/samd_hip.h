@@ -329,6 +329,29 @@ int samd_kv_compact_vt(samd_session_t *s, void *const *d_tensors, int32_t n_tens
 int samd_kv_compact_indices_vt(void *const *d_tensors, int32_t n_tensors, int32_t n_transposed, int32_t n_heads, int64_t max_len, int32_t head_dim,
                                int32_t elem_bytes, int32_t start, const int32_t *d_indices, int32_t accept, void *stream);
 
+/* ---- EAGLE-2's tree logic between two forwards of the draft head (csrc/eagle_kernels.hip; reference: Eagle2Model.topk_genrate,
+ * S/tree_model/eagle2/eagle2_model.py:848-913 the level loop, :893-913 the re-rank).  samd_e2_state_t holds device pointers to small
+ * caller-allocated arrays (k = 8 = top_k, depth <= 7):
+ *   row_lse f32[8], top_logp f32[8][8], top_idx i32[8][8]     -- samd_e2_rowstats: per row log-sum-exp and top-k (log-prob, token)
+ *   scores f32[8], cs_index i32[8], mask_rows u64[64], row_src i32[8], ids i32[8]   -- the current level's rows (samd_e2_select)
+ *   all_scores f32[8 + 64 depth], all_tokens i32[same], parents_list i32[1 + 8 depth]   -- the reference's scores_list / ss_token / parents_list
+ *   rec_top_vals/idx [1 + depth][8][8], rec_best_vals/idx [depth][8], rec_final_vals/idx [keep]   -- every top-k decision, in the reference's order
+ * samd_e2_select(level = -1) installs the root's 8 candidates as level 0's rows; level >= 0 picks the 8 rows of level + 1 from the
+ * 64 cumulative scores; both stage the fc projection's input rows [embed[token] | parent hidden state] into d_fc_in [8][2 hidden] and
+ * the rows' ancestor masks (bit j = tree row j) into mask_rows.  samd_e2_finish keeps the best `keep` candidates in candidate order
+ * -> tokens / parents [keep + 1] (parent -1 for the root).  samd_sum_partials_bias: out = sum of fp32 partials + bias, rounded. */
+typedef struct samd_e2_state {
+    float *row_lse; float *top_logp; int32_t *top_idx; float *scores; int32_t *cs_index; float *all_scores; int32_t *all_tokens;
+    int32_t *parents_list; uint64_t *mask_rows; int32_t *row_src; int32_t *ids;
+    float *rec_top_vals; int32_t *rec_top_idx; float *rec_best_vals; int32_t *rec_best_idx; float *rec_final_vals; int32_t *rec_final_idx;
+} samd_e2_state_t;
+int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const samd_e2_state_t *st, void *stream);
+int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidden, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in,
+                   int32_t *d_rel_pos /* optional: [8] <- level + 1 */, int32_t dtype, void *stream);
+int samd_e2_finish(const samd_e2_state_t *st, int32_t depth, int32_t keep, const int64_t *d_sample_token, int32_t *d_tokens, int32_t *d_parents, void *stream);
+int samd_sum_partials_bias(const float *d_part, int32_t n_partials, int64_t partial_stride, const void *d_bias, void *d_out, int32_t rows, int32_t N,
+                           int32_t dtype, void *stream);
+
 /* ---- memory-bound glue of the verify forward (between the library GEMMs).  The arithmetic of the
  * forward lives in HuggingFace transformers in the reference (third party, not vendored; call sites
  * SO/samd_model.py:102-106 and :134-138); these follow LlamaDecoderLayer's operators and take every

@@ -1,0 +1,280 @@
+// eagle_kernels.hip -- the tree logic of EAGLE-2's draft expansion on the device (reference: Eagle2Model.topk_genrate,
+// samd/tree_model/eagle2/eagle2_model.py:848-913 for the levels, :893-946 for the final re-rank; the reference walks Python lists
+// and issues ~25 small torch ops per level).  Between two forwards of the draft head a level needs:
+//   per row   log_softmax over the vocabulary and its top-k                       -> k_e2_rowstats (one workgroup per row)
+//   per level cumulative scores, the top-k of the k*k candidates, the next level's inputs (token embeddings | parent
+//             hidden states staged for the fc projection, ancestor mask rows)       -> k_e2_select   (one workgroup)
+//   at the end the best `keep` candidates of all levels in index order + parents    -> k_e2_finish   (one workgroup)
+// so a draft is ~6 launches per level instead of ~35, and the host stays ahead of the GPU without capturing PyTorch ops in a
+// hipGraph.  k = 8 (top_k), depth <= 7, every top-k is (value descending, index ascending) -- torch.topk's order on tie-free rows.
+// Every top-k decision is also recorded (rec_*), which is what the parity tests compare with the recorded reference.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include "samd_common.h"
+
+#define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
+
+#define E2_K 8
+#define E2_MAXDEPTH 7
+#define E2_CAND (E2_K + E2_K * E2_K * E2_MAXDEPTH)      // candidates of all levels
+
+// device state of one expansion (all arrays persistent; include/samd_hip.h samd_e2_state_t mirrors this)
+struct E2State {
+    float *row_lse;          // [8]
+    float *top_logp;         // [8][8]  log-probabilities of the row's top-k
+    int32_t *top_idx;        // [8][8]  their token ids
+    float *scores;           // [8]     cumulative score of the current level's rows
+    int32_t *cs_index;       // [8]     flat index (row * 8 + rank) of the rows chosen for the current level, in the previous level's candidates
+    float *all_scores;       // [E2_CAND]
+    int32_t *all_tokens;     // [E2_CAND]
+    int32_t *parents_list;   // [1 + 8 * depth]
+    unsigned long long *mask_rows;   // [64]  ancestor bits of the current level's rows (bit j = tree row j)
+    int32_t *row_src;        // [8]     row of the previous forward's output each new row hangs off
+    int32_t *ids;            // [8]     token of each new row
+    // records of every top-k decision, in the reference's order
+    float *rec_top_vals;     // [1 + depth][8][8]
+    int32_t *rec_top_idx;    // [1 + depth][8][8]
+    float *rec_best_vals;    // [depth][8]
+    int32_t *rec_best_idx;   // [depth][8]
+    float *rec_final_vals;   // [keep]
+    int32_t *rec_final_idx;  // [keep]
+};
+
+__device__ __forceinline__ float e2_f32(_Float16 x) { return (float)x; }
+__device__ __forceinline__ float e2_f32(__bf16 x) { return (float)x; }
+__device__ __forceinline__ float e2_f32(float x) { return x; }
+__device__ __forceinline__ bool e2_before(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+// per row: log-sum-exp over the vocabulary and the top-8 logits (value desc, index asc) -> top_logp = logit - lse, top_idx
+template <typename T>
+__global__ __launch_bounds__(256) void k_e2_rowstats(const T *__restrict__ logits, long long vocab, long long stride, E2State S) {
+    const int row = blockIdx.x;
+    const T *x = logits + (size_t)row * stride;
+    float bv[E2_K]; int bi[E2_K];
+#pragma unroll
+    for (int k = 0; k < E2_K; k++) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
+    float m = -INFINITY, s = 0.f;
+    for (long long i = threadIdx.x; i < vocab; i += blockDim.x) {
+        float v = e2_f32(x[i]); int id = (int)i;
+        if (v > m) { s = s * __expf(m - v) + 1.f; m = v; } else s += __expf(v - m);
+        if (!e2_before(v, id, bv[E2_K - 1], bi[E2_K - 1])) continue;
+#pragma unroll
+        for (int k = 0; k < E2_K; k++)
+            if (e2_before(v, id, bv[k], bi[k])) { const float tv = bv[k]; const int ti = bi[k]; bv[k] = v; bi[k] = id; v = tv; id = ti; }
+    }
+    __shared__ float sv[256 * E2_K]; __shared__ int si[256 * E2_K];
+    __shared__ float wm[4], ws[4], wv[4]; __shared__ int wi[4], wslot[4];
+    // log-sum-exp: combine (m, s) across the block
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o), os = __shfl_xor(s, o);
+        const float M = fmaxf(m, om);
+        s = (m == -INFINITY ? 0.f : s * __expf(m - M)) + (om == -INFINITY ? 0.f : os * __expf(om - M));
+        m = M;
+    }
+    if ((threadIdx.x & 63) == 0) { wm[threadIdx.x >> 6] = m; ws[threadIdx.x >> 6] = s; }
+#pragma unroll
+    for (int k = 0; k < E2_K; k++) { sv[threadIdx.x * E2_K + k] = bv[k]; si[threadIdx.x * E2_K + k] = bi[k]; }
+    __syncthreads();
+    float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])), Ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (wm[k] != -INFINITY) Ssum += ws[k] * __expf(wm[k] - M);
+    const float lse = M + logf(Ssum);
+    if (threadIdx.x == 0) S.row_lse[row] = lse;
+    for (int round = 0; round < E2_K; round++) {
+        float best = -INFINITY; int bidx = 0x7fffffff, bslot = -1;
+#pragma unroll
+        for (int k = 0; k < E2_K; k++) {
+            const int slot = threadIdx.x * E2_K + k;
+            if (si[slot] != 0x7fffffff && (bslot < 0 || e2_before(sv[slot], si[slot], best, bidx))) { best = sv[slot]; bidx = si[slot]; bslot = slot; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bidx, o), os = __shfl_xor(bslot, o);
+            if (os >= 0 && (bslot < 0 || e2_before(ov, oi, best, bidx))) { best = ov; bidx = oi; bslot = os; }
+        }
+        if ((threadIdx.x & 63) == 0) { wv[threadIdx.x >> 6] = best; wi[threadIdx.x >> 6] = bidx; wslot[threadIdx.x >> 6] = bslot; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; k++)
+                if (wslot[k] >= 0 && (bslot < 0 || e2_before(wv[k], wi[k], best, bidx))) { best = wv[k]; bidx = wi[k]; bslot = wslot[k]; }
+            S.top_logp[row * E2_K + round] = bslot < 0 ? -INFINITY : best - lse;
+            S.top_idx[row * E2_K + round] = bslot < 0 ? 0 : bidx;
+            if (bslot >= 0) si[bslot] = 0x7fffffff;
+        }
+        __syncthreads();
+    }
+}
+
+// level = -1: the root (row 0 of top_* = the last accepted position): candidates 0..7, no selection among k*k.
+// level >= 0: rows 0..7 of top_* = the outputs of tree level `level`; selects the 8 rows of level + 1 and stages their inputs.
+// hidden [rows][H] = the previous forward's output states (row r of the level, or the single last accepted row for the root);
+// fc_in [8][2H] <- [embed[ids[t]] | hidden[row_src[t]]]; mask_rows <- ancestor bits of the new rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_e2_select(E2State S, int level, const T *__restrict__ hidden, const T *__restrict__ embed, int H, int vocab,
+                                                   T *__restrict__ fc_in, int32_t *__restrict__ relpos) {
+    __shared__ int s_ids[E2_K], s_src[E2_K];
+    const int lane = threadIdx.x;
+    if (lane < 64) {                                      // wavefront 0 does the tree logic in lockstep (no block barrier inside)
+        if (level < 0) {
+            if (lane < E2_K) {
+                const float sc = S.top_logp[lane];
+                const int tok = S.top_idx[lane];
+                S.scores[lane] = sc; S.cs_index[lane] = lane;
+                S.all_scores[lane] = sc; S.all_tokens[lane] = tok;
+                S.rec_top_vals[lane] = sc; S.rec_top_idx[lane] = tok;
+                S.ids[lane] = tok; S.row_src[lane] = 0;
+                S.mask_rows[lane] = 1ull << lane;
+                s_ids[lane] = tok; s_src[lane] = 0;
+                if (lane == 0) S.parents_list[0] = 0;
+            }
+        } else {
+            // every lane reads the old state first (registers), the commit below comes later in program order of the same wave
+            const int r = lane >> 3;
+            const float cu = S.top_logp[lane] + S.scores[r];
+            const int my_tok = S.top_idx[lane];
+            const int old_cs = S.cs_index[lane & 7];
+            const unsigned long long prev_mask = S.mask_rows[lane & 7];
+            const int base = E2_K + E2_K * E2_K * level;
+            S.all_scores[base + lane] = cu; S.all_tokens[base + lane] = my_tok;
+            S.rec_top_vals[(1 + level) * 64 + lane] = S.top_logp[lane]; S.rec_top_idx[(1 + level) * 64 + lane] = my_tok;
+            // parents of this level's rows in the reference's numbering (eagle2_model.py:866-870)
+            if (lane < E2_K) S.parents_list[1 + E2_K * level + lane] = old_cs + 1 + E2_K * E2_K * (level > 0 ? level - 1 : 0) + (level > 0 ? E2_K : 0);
+            // top-8 of the 64 cumulative scores (value desc, flat index asc)
+            bool taken = false;
+            float sel_v = 0.f; int sel_i = 0;
+            for (int round = 0; round < E2_K; round++) {
+                float bvv = taken ? -INFINITY : cu; int bii = taken ? 0x7fffffff : lane;
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(bvv, o); const int oi = __shfl_xor(bii, o);
+                    if (e2_before(ov, oi, bvv, bii)) { bvv = ov; bii = oi; }
+                }
+                if (bii == lane) taken = true;
+                if (lane == round) { sel_v = bvv; sel_i = bii; }
+            }
+            // lane t < 8 holds new row t: its source row, token (held by lane sel_i) and mask
+            const int sel_c = lane < E2_K ? sel_i : 0;
+            const int tok = __shfl(my_tok, sel_c);
+            const unsigned long long pm = __shfl(prev_mask, sel_c >> 3);
+            if (lane < E2_K) {
+                const int src = sel_i >> 3;
+                S.rec_best_vals[level * E2_K + lane] = sel_v; S.rec_best_idx[level * E2_K + lane] = sel_i;
+                S.scores[lane] = sel_v; S.cs_index[lane] = sel_i; S.ids[lane] = tok; S.row_src[lane] = src;
+                S.mask_rows[lane] = pm | (1ull << (E2_K * (level + 1) + lane));
+                s_ids[lane] = tok; s_src[lane] = src;
+            }
+        }
+    }
+    if (relpos && lane < E2_K) relpos[lane] = level + 1;      // depth of the new rows (position = accepted length + depth)
+    __syncthreads();
+    // stage the fc projection's input rows: [embed[token] | parent hidden state]
+    const int vec = H / 8;                                 // 16-byte units per half row
+    for (int u = threadIdx.x; u < E2_K * 2 * vec; u += blockDim.x) {
+        const int t = u / (2 * vec), c = u - t * 2 * vec;
+        int tok = s_ids[t]; tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        const uint4 *src = c < vec ? reinterpret_cast<const uint4 *>(embed + (size_t)tok * H) + c
+                                   : reinterpret_cast<const uint4 *>(hidden + (size_t)s_src[t] * H) + (c - vec);
+        reinterpret_cast<uint4 *>(fc_in + (size_t)t * 2 * H)[c] = *src;
+    }
+}
+
+// the best `keep` of the 8 + 64 depth candidates, in candidate order, with their parents (eagle2_model.py:893-913) ->
+// tokens [keep + 1] (root = sample token), parents [keep + 1] (-1 for the root)
+__global__ __launch_bounds__(256) void k_e2_finish(E2State S, int depth, int keep, const int64_t *__restrict__ sample_token, int32_t *__restrict__ out_tokens,
+                                                   int32_t *__restrict__ out_parents) {
+    __shared__ float sc[E2_CAND]; __shared__ int rank[E2_CAND]; __shared__ int kept[E2_CAND]; __shared__ int pos_of[E2_CAND];
+    const int n = E2_K + E2_K * E2_K * depth;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sc[i] = S.all_scores[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int r = 0; const float v = sc[i];
+        for (int j = 0; j < n; j++) r += e2_before(sc[j], j, v, i) ? 1 : 0;
+        rank[i] = r;
+        if (r < keep) { S.rec_final_vals[r] = v; S.rec_final_idx[r] = i; }
+    }
+    __syncthreads();
+    // position of a kept candidate among the kept ones in candidate order (= sorted top indices)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int p = 0;
+        for (int j = 0; j < i; j++) p += rank[j] < keep ? 1 : 0;
+        pos_of[i] = p;
+        if (rank[i] < keep) kept[p] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { out_tokens[0] = (int32_t)sample_token[0]; out_parents[0] = -1; }
+    for (int t = threadIdx.x; t < keep; t += blockDim.x) {
+        const int i = kept[t];
+        out_tokens[1 + t] = S.all_tokens[i];
+        const int dp = S.parents_list[i / E2_K];          // 0 = hangs off the root; else 1 + candidate index of the parent
+        int parent = 0;
+        if (dp != 0) {
+            // searchsorted(kept, dp - 1, left) + 1: pos_of[c] = number of kept candidates before c, whether c itself was kept or not
+            int c = dp - 1; c = c < 0 ? 0 : (c >= n ? n - 1 : c);
+            parent = pos_of[c] + 1;
+            if (parent >= t + 1) parent = 0;               // a kept node whose parent was not kept (exact score ties only) hangs off the root
+        }
+        out_parents[1 + t] = parent;
+    }
+}
+
+// x[r][:] = (sum_s part[s][r][:] + bias) rounded to T: the tail of the fc projection computed as split-K partials
+template <typename T>
+__global__ __launch_bounds__(256) void k_sum_partials_bias(const float *__restrict__ part, int n_part, long long part_stride, const T *__restrict__ bias,
+                                                           T *__restrict__ out, int rows, int N) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * N) return;
+    float acc = 0.f;
+    for (int s = 0; s < n_part; s++) acc += part[(size_t)s * part_stride + i];
+    if (bias) acc += (float)bias[i % N];
+    out[i] = (T)acc;
+}
+
+extern "C" {
+
+int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const samd_e2_state_t *st, void *stream) {
+    if (!d_logits || !st || rows < 1 || rows > E2_K || vocab < E2_K || row_stride < vocab) { samd_set_error("samd_e2_rowstats: invalid argument"); return SAMD_E_INVALID; }
+    static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_rowstats<_Float16>, dim3(rows), dim3(256), 0, s, (const _Float16 *)d_logits, (long long)vocab, (long long)row_stride, S);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_rowstats<__bf16>, dim3(rows), dim3(256), 0, s, (const __bf16 *)d_logits, (long long)vocab, (long long)row_stride, S);
+    else if (dtype == SAMD_F32) hipLaunchKernelGGL(k_e2_rowstats<float>, dim3(rows), dim3(256), 0, s, (const float *)d_logits, (long long)vocab, (long long)row_stride, S);
+    else { samd_set_error("samd_e2_rowstats: bad dtype"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidden, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in,
+                   int32_t *d_rel_pos, int32_t dtype, void *stream) {
+    if (!st || level < -1 || level >= E2_MAXDEPTH || !d_hidden || !d_embed || !d_fc_in || hidden % 8 != 0 || vocab < 1) { samd_set_error("samd_e2_select: invalid argument"); return SAMD_E_INVALID; }
+    static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(1), dim3(256), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(1), dim3(256), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos);
+    else { samd_set_error("samd_e2_select: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_e2_finish(const samd_e2_state_t *st, int32_t depth, int32_t keep, const int64_t *d_sample_token, int32_t *d_tokens, int32_t *d_parents, void *stream) {
+    if (!st || depth < 1 || depth > E2_MAXDEPTH || keep < 1 || keep > E2_K + E2_K * E2_K * depth || !d_sample_token || !d_tokens || !d_parents) {
+        samd_set_error("samd_e2_finish: invalid argument"); return SAMD_E_INVALID;
+    }
+    static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
+    hipLaunchKernelGGL(k_e2_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, S, depth, keep, d_sample_token, d_tokens, d_parents);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_sum_partials_bias(const float *d_part, int32_t n_partials, int64_t partial_stride, const void *d_bias, void *d_out, int32_t rows, int32_t N,
+                           int32_t dtype, void *stream) {
+    if (!d_part || !d_out || n_partials < 1 || rows < 1 || N < 1) { samd_set_error("samd_sum_partials_bias: invalid argument"); return SAMD_E_INVALID; }
+    const long long total = (long long)rows * N;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_sum_partials_bias<_Float16>, grid, block, 0, s, d_part, n_partials, (long long)partial_stride, (const _Float16 *)d_bias, (_Float16 *)d_out, rows, N);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_sum_partials_bias<__bf16>, grid, block, 0, s, d_part, n_partials, (long long)partial_stride, (const __bf16 *)d_bias, (__bf16 *)d_out, rows, N);
+    else { samd_set_error("samd_sum_partials_bias: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+}  // extern "C"

@@ -8,7 +8,8 @@ K/V behind the rows of the earlier levels ([L + 8 i, L + 8 i + 8) of the head's 
 the ancestors among the 8 (i + 1) tree rows -- the attention kernel's visible-prefix mask (samd_attention_block: keys < L visible to
 every row, key L + j by bit j).  Nothing has to be rolled back afterwards: L only ever counts accepted tokens, the next draft
 overwrites the tree rows.  Every head forward (the accepted tokens' extension, then one 8-row forward per level) replays its row
-bucket's hipGraph; the tree logic in between stays a handful of device-side PyTorch ops (`eagle2_draft`).  EAGLE v1's static tree keeps the older STATELESS form (`tree`): the forward of level i
+bucket's hipGraph; the tree logic in between -- log-softmax + top-k per row, cumulative scores, the level's selection, the next
+level's inputs and masks, the final re-rank -- runs in three small kernels (csrc/eagle_kernels.hip; `eagle2_draft`).  EAGLE v1's static tree keeps the older STATELESS form (`tree`): the forward of level i
 carries every node-with-children so far, with their ancestor mask.  Positions are the reference's (accepted length + depth).
 
 Arithmetic is the same as Eagle2Head.forward's up to fp16 accumulation order; drafts are verified by the base model either
@@ -68,7 +69,7 @@ class DeviceHead:
         self.x_buf = torch.zeros((MAX_ROWS, head.hidden), dtype=dt, device=dev)
         self.mask_buf = torch.zeros(MAX_ROWS, dtype=torch.int64, device=dev)
         self._graphs = {}                                 # row bucket -> hipGraph of one head forward over the static buffers
-        self._levels_graph = None                         # EAGLE-2: (hipGraph of the five levels + re-rank, tokens, parents)
+        self._e2 = None                                   # EAGLE-2 tree-logic state (samd_e2_state_t), made on first use
         # stateful tree levels (EAGLE-2): write position of the current level, per-level relative positions
         self.Lw = torch.zeros(1, dtype=torch.int32, device=dev)
         self.level_pos = [torch.full((MAX_ROWS,), i, dtype=torch.int32, device=dev) for i in range(8)]
@@ -156,46 +157,86 @@ class DeviceHead:
         torch.add(self.L, n * i, out=self.Lw)
         return self._forward(self._x(ids, hidden), self.level_pos[i], _mask_rows(anc_rows), level=True)
 
-    def _level_eager(self, i, ids, hidden, anc_rows):
-        """level() without the per-forward graph: plain launches (inside the whole-draft capture)"""
-        n = ids.numel()
-        torch.add(self.L, n * i, out=self.Lw)
-        self.n.fill_(n)
-        self.x_buf[:n].copy_(self._x(ids, hidden))
-        self.mask_buf.copy_(_mask_rows(anc_rows))
-        b = self.runner.forward_rows(8, self.tok, self.level_pos[i], self.mask_buf, self.Lw, self.n, x_in=self.x_buf, d_vis=self.L)
-        return b["x"][:n], b["logits"][:n]
+    def _e2_state(self, depth, keep):
+        """device arrays of the tree logic (samd_e2_state_t); mask_rows IS the forward's mask buffer"""
+        if self._e2 is None or self._e2[0] != (depth, keep):
+            import ctypes as C
+            import samd_hip
+            dev, f32, i32 = self.embed.device, torch.float32, torch.int32
+            n_cand = 8 + 64 * depth
+            t = dict(row_lse=torch.zeros(8, dtype=f32, device=dev), top_logp=torch.zeros(64, dtype=f32, device=dev), top_idx=torch.zeros(64, dtype=i32, device=dev),
+                     scores=torch.zeros(8, dtype=f32, device=dev), cs_index=torch.zeros(8, dtype=i32, device=dev),
+                     all_scores=torch.zeros(n_cand, dtype=f32, device=dev), all_tokens=torch.zeros(n_cand, dtype=i32, device=dev),
+                     parents_list=torch.zeros(1 + 8 * depth, dtype=i32, device=dev), mask_rows=self.mask_buf,
+                     row_src=torch.zeros(8, dtype=i32, device=dev), ids=torch.zeros(8, dtype=i32, device=dev),
+                     rec_top_vals=torch.zeros((1 + depth) * 64, dtype=f32, device=dev), rec_top_idx=torch.zeros((1 + depth) * 64, dtype=i32, device=dev),
+                     rec_best_vals=torch.zeros(depth * 8, dtype=f32, device=dev), rec_best_idx=torch.zeros(depth * 8, dtype=i32, device=dev),
+                     rec_final_vals=torch.zeros(keep, dtype=f32, device=dev), rec_final_idx=torch.zeros(keep, dtype=i32, device=dev))
+            st = samd_hip.E2State(**{k: v.data_ptr() for k, v in t.items()})
+            out = (torch.zeros(keep + 1, dtype=i32, device=dev), torch.zeros(keep + 1, dtype=i32, device=dev))
+            self._e2 = ((depth, keep), t, st, C.byref(st), out)
+        return self._e2
 
     def eagle2_draft(self, head, hidden_states, input_ids):
         """Eagle2Head.topk_generate on the library's kernels: hidden_states [T, H] of the accepted tokens, input_ids [T + 1] ->
-        (tokens [63], parents [63]).  The accepted tokens enter the head's cache through the per-bucket forward graphs (`extend`);
-        the five levels and the top-62 re-rank -- five 8-row forwards and ~150 small PyTorch ops with fixed shapes -- replay as ONE
-        hipGraph (`_levels_graph`): launched one by one they keep the host busy for longer (3.7 ms) than the GPU needs (2 ms).
-        Only ONE graph of this kind exists per head: graphs that contain PyTorch allocations stopped replaying correctly once a third
-        one was captured (ROCm 7.2; the second one faults, scripts/_debug_eagle2.py) -- so the extension, whose row bucket varies,
-        stays outside it."""
-        last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
-        if head.trace is not None or os.environ.get("SAMD_EAGLE_GRAPH", "1") == "0":      # decision traces copy to the host: eager
+        (tokens [keep + 1], parents [keep + 1]).  Per level: the fc projection (streaming GEMM + bias), one 8-row head forward (its
+        hipGraph), samd_e2_rowstats (log-softmax + top-8 per row) and samd_e2_select (cumulative scores, top-8 of 64, next level's
+        inputs and masks) -- six launches where the PyTorch form issues ~35 small ops and leaves the GPU waiting for the host (3.7 ms
+        per draft against 2 ms of GPU work at Llama-3-8B shapes).  Capturing those PyTorch ops in hipGraphs instead faulted on replay
+        once several such graphs existed (ROCm 7.2, scripts/_debug_eagle2.py).  Falls back to the PyTorch form when the head's shape
+        does not fit the kernels (top_k != 8, depth > 7, fc not streamable)."""
+        import samd_hip
+        depth, keep = head.depth, head.total_tokens
+        if head.top_k != 8 or depth > 7 or self.fc_packed is None or os.environ.get("SAMD_EAGLE_KERNELS", "1") == "0":
+            last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
             return head._expand_levels(self, last_hidden, last_logits, input_ids[-1:].clone())
-        if self._levels_graph is None:
-            self.lv_hidden = torch.zeros_like(last_hidden)
-            self.lv_logits = torch.zeros_like(last_logits)
-            self.lv_sample = torch.zeros(1, dtype=torch.long, device=last_hidden.device)
-            level, self.level = self.level, self._level_eager
-            try:
-                head._expand_levels(self, self.lv_hidden, self.lv_logits, self.lv_sample)       # warm-up: tree rows land beyond L
-                torch.cuda.current_stream().synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    out = head._expand_levels(self, self.lv_hidden, self.lv_logits, self.lv_sample)
-            finally:
-                self.level = level
-            self._levels_graph = (g, out[0], out[1])
-        self.lv_hidden.copy_(last_hidden)
-        self.lv_logits.copy_(last_logits)
-        self.lv_sample.copy_(input_ids[-1:])
-        self._levels_graph[0].replay()
-        return self._levels_graph[1].clone(), self._levels_graph[2].clone()
+        L, st = self._lib, samd_hip.current_stream()
+        _, t, _st, st_ref, out = self._e2_state(depth, keep)
+        last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
+        H, V = self.embed.shape[1], last_logits.shape[-1]
+        n_fc, k_fc = self.fc_w.shape
+        sp = max(2, min(8, L.samd_gemm_splits(n_fc, k_fc, 16), k_fc // 256))
+        part = self.fc_part.view(-1)[:sp * 16 * n_fc]
+        dt = self._dt
+        check = samd_hip.check
+        check(L.samd_e2_rowstats(samd_hip._ptr(last_logits), dt, 1, V, V, st_ref, st))
+        check(L.samd_e2_select(st_ref, -1, samd_hip._ptr(last_hidden), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
+                               samd_hip._ptr(self.relpos_buf), dt, st))
+        self.n.fill_(8)
+        b = self.runner._buffers(8)
+        for i in range(depth):
+            check(L.samd_gemm_skinny(samd_hip._ptr(self.fc_in), samd_hip._ptr(self.fc_packed), 16, n_fc, k_fc, sp, samd_hip._ptr(part), None, dt, st))
+            check(L.samd_sum_partials_bias(samd_hip._ptr(part), sp, 16 * n_fc, samd_hip._ptr(self.fc_b), samd_hip._ptr(self.x_buf), 8, n_fc, dt, st))
+            torch.add(self.L, 8 * i, out=self.Lw)
+            self._level_graph().replay()
+            check(L.samd_e2_rowstats(samd_hip._ptr(b["logits"]), dt, 8, V, b["logits"].stride(0), st_ref, st))
+            check(L.samd_e2_select(st_ref, i, samd_hip._ptr(b["x"]), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
+                                   samd_hip._ptr(self.relpos_buf), dt, st))
+        self._keep_sample = input_ids[-1:].to(torch.long).contiguous()
+        check(L.samd_e2_finish(st_ref, depth, keep, samd_hip._ptr(self._keep_sample), samd_hip._ptr(out[0]), samd_hip._ptr(out[1]), st))
+        if head.trace is not None:                         # every top-k decision in the reference's order (parity tests)
+            torch.cuda.current_stream().synchronize()
+            tv, ti = t["rec_top_vals"].view(1 + depth, 8, 8).cpu(), t["rec_top_idx"].view(1 + depth, 8, 8).cpu().long()
+            bv, bi = t["rec_best_vals"].view(depth, 8).cpu(), t["rec_best_idx"].view(depth, 8).cpu().long()
+            head.trace.append((tv[0, :1], ti[0, :1]))
+            for i in range(depth):
+                head.trace.append((tv[1 + i], ti[1 + i]))
+                head.trace.append((bv[i], bi[i]))
+            head.trace.append((t["rec_final_vals"].cpu(), t["rec_final_idx"].cpu().long()))
+        return out[0].to(torch.long), out[1].to(torch.long)
+
+    def _level_graph(self):
+        """hipGraph of one 8-row tree-level forward over the fixed buffers (x_buf, relpos_buf, mask_buf, Lw, n; visible prefix L)"""
+        g = self._graphs.get(("level", 8))
+        if g is None:
+            run = lambda: self.runner.forward_rows(8, self.tok, self.relpos_buf, self.mask_buf, self.Lw, self.n, x_in=self.x_buf, d_vis=self.L)
+            run()
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            self._graphs[("level", 8)] = g
+        return g
 
     def expand(self, key, fn, *inputs):
         """run `fn(*inputs) -> tuple of tensors`, a whole tree expansion (fixed shapes, data-dependent values, no host round

@@ -40,6 +40,13 @@ class DraftHost(C.Structure):
                 ("retrieve", C.c_int32 * (MAX_DRAFT * MAX_DRAFT))]
 
 
+class E2State(C.Structure):
+    """samd_e2_state_t: device pointers of EAGLE-2's tree-logic arrays (include/samd_hip.h)"""
+    _NAMES = ("row_lse", "top_logp", "top_idx", "scores", "cs_index", "all_scores", "all_tokens", "parents_list", "mask_rows", "row_src", "ids",
+              "rec_top_vals", "rec_top_idx", "rec_best_vals", "rec_best_idx", "rec_final_vals", "rec_final_idx")
+    _fields_ = [(n, C.c_void_p) for n in _NAMES]
+
+
 class VerdictHost(C.Structure):
     """samd_verdict_host_t"""
     _fields_ = [("best", C.c_int32), ("accept", C.c_int32), ("next_node", C.c_int32), ("next_token", C.c_int32),
@@ -108,6 +115,10 @@ _PROTOS = {
     "samd_rope_kv_write_vt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
     "samd_kv_compact_vt": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
     "samd_kv_compact_indices_vt": (C.c_int, [_VP, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _VP, _I32, _VP]),
+    "samd_e2_rowstats": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP]),
+    "samd_e2_select": (C.c_int, [_VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _I32, _VP]),
+    "samd_e2_finish": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP]),
+    "samd_sum_partials_bias": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_embed_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "samd_rmsnorm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _I32, _I64, _VP]),
     "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),

@@ -1,0 +1,75 @@
+"""EAGLE-2's device-side tree logic (csrc/eagle_kernels.hip: samd_e2_rowstats / samd_e2_select / samd_e2_finish, reference
+Eagle2Model.topk_genrate, samd/tree_model/eagle2/eagle2_model.py:848-913) against plain PyTorch: per-row log-softmax + top-k, and the
+whole expansion against the PyTorch form of the same loop (Eagle2Head._expand_levels) on the same head and cache state.  The recorded
+reference outputs are compared in tests/test_gpu_eagle_golden.py."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import samd_hip
+from samd_hip import _ptr, check, current_stream, lib, torch_dtype_code
+
+
+def make_state(depth=5, keep=62):
+    dev, f32, i32 = "cuda", torch.float32, torch.int32
+    n_cand = 8 + 64 * depth
+    t = dict(row_lse=torch.zeros(8, dtype=f32, device=dev), top_logp=torch.zeros(64, dtype=f32, device=dev), top_idx=torch.zeros(64, dtype=i32, device=dev),
+             scores=torch.zeros(8, dtype=f32, device=dev), cs_index=torch.zeros(8, dtype=i32, device=dev),
+             all_scores=torch.zeros(n_cand, dtype=f32, device=dev), all_tokens=torch.zeros(n_cand, dtype=i32, device=dev),
+             parents_list=torch.zeros(1 + 8 * depth, dtype=i32, device=dev), mask_rows=torch.zeros(64, dtype=torch.int64, device=dev),
+             row_src=torch.zeros(8, dtype=i32, device=dev), ids=torch.zeros(8, dtype=i32, device=dev),
+             rec_top_vals=torch.zeros((1 + depth) * 64, dtype=f32, device=dev), rec_top_idx=torch.zeros((1 + depth) * 64, dtype=i32, device=dev),
+             rec_best_vals=torch.zeros(depth * 8, dtype=f32, device=dev), rec_best_idx=torch.zeros(depth * 8, dtype=i32, device=dev),
+             rec_final_vals=torch.zeros(keep, dtype=f32, device=dev), rec_final_idx=torch.zeros(keep, dtype=i32, device=dev))
+    st = samd_hip.E2State(**{k: v.data_ptr() for k, v in t.items()})
+    return t, st
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("vocab,rows", [(512, 8), (32000, 8), (128256, 8), (32000, 1), (1000, 3)])
+def test_rowstats_matches_log_softmax_topk(dtype, vocab, rows):
+    g = torch.Generator(device="cuda").manual_seed(vocab + rows)
+    logits = (torch.randn((rows, vocab), generator=g, device="cuda") * 4).to(dtype)
+    t, st = make_state()
+    check(lib().samd_e2_rowstats(_ptr(logits), torch_dtype_code(dtype), rows, vocab, vocab, C.byref(st), current_stream()))
+    torch.cuda.synchronize()
+    logp = torch.log_softmax(logits.float(), dim=-1)
+    # expected order: value descending, index ascending among equal values (half precision produces exact ties)
+    order = torch.argsort(-logits.float(), dim=-1, stable=True)[:, :8]        # ties of the (half-precision) logits keep index order
+    want_v = torch.gather(logp, 1, order)
+    got_v, got_i = t["top_logp"].view(8, 8)[:rows], t["top_idx"].view(8, 8)[:rows].long()
+    assert torch.equal(got_i, order)
+    assert (got_v - want_v).abs().max().item() < 2e-4
+    assert (t["row_lse"][:rows] - torch.logsumexp(logits.float(), dim=-1)).abs().max().item() < 2e-4
+
+
+def test_expansion_kernels_match_the_pytorch_loop():
+    """same head, same accepted tokens: the kernel path (samd_e2_*) and Eagle2Head._expand_levels give the same draft"""
+    from eagle_fixture_weights import call_inputs
+    from test_gpu_eagle_golden import device_head_for
+    from samd.tree_model.eagle2 import Eagle2Head
+    seed = 335
+    head, runner, dh = device_head_for(seed, Eagle2Head)
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["SAMD_EAGLE_KERNELS"] = mode
+        try:
+            dh.reset()
+            got = []
+            for ci, T in enumerate([13, 1, 4, 2, 7]):
+                hs, ids = call_inputs(seed, ci, T)
+                toks, par = head.topk_generate_device(dh, torch.from_numpy(hs).cuda().half(), torch.from_numpy(ids).cuda())
+                torch.cuda.synchronize()
+                got.append((toks.tolist(), par.tolist()))
+            outs[mode] = got
+        finally:
+            os.environ.pop("SAMD_EAGLE_KERNELS", None)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert a == b
+        assert a[1][0] == -1 and all(0 <= a[1][i] < i for i in range(1, len(a[1])))
