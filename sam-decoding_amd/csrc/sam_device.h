@@ -131,69 +131,6 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
     }
 }
 
-// Two-phase form of the same transition, for kernels that keep TWO cursors per lane in flight: chain_try is the register path
-// (true = the token was consumed by the chain word), st_first_addr / st_node_path split the node path so that the caller can issue
-// the first load of both cursors before it waits for either.
-template <int W>
-__device__ __forceinline__ bool chain_try(int &idx, int &len, int tok, ChainWord &cw) {
-    const unsigned next = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
-    const unsigned term = W == 8 ? 0xFFFFu : 0xFFFFFFFFu;
-    if (tok >= 0 && next != term && next == (unsigned)tok) {
-        idx += 1; len += 1;
-        if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
-        else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
-        return true;
-    }
-    cw = chain_none();
-    return false;
-}
-// the first 16 bytes the node path needs: the node's word 0, or (at the root) the root table entry in .x
-__device__ __forceinline__ int4 st_first_load(const StaticDev &S, int idx, int tok) {
-    if (tok < 0) return make_int4(-1, 0, 0, 0);
-    if (idx == 0) return make_int4((tok < S.vocab) ? S.root_next[tok] : -1, 0, 0, 0);
-    return reinterpret_cast<const int4 *>(S.nodes + idx)[0];
-}
-template <int W>
-__device__ __forceinline__ int st_node_path(const StaticDev &S, int &idx, int &len, int tok, ChainWord &cw, int4 first) {
-    if (tok < 0) { idx = 0; len = 0; return 1; }
-    int visited = 0;
-    bool hopped = false, have_first = true;
-    for (;;) {
-        visited++;
-        if (idx == 0) {
-            const int nx = have_first ? first.x : ((tok < S.vocab) ? S.root_next[tok] : -1);
-            if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
-            return visited;
-        }
-        const int4 *np = reinterpret_cast<const int4 *>(S.nodes + idx);
-        const int4 w0 = have_first ? first : np[0];
-        have_first = false;
-        if (hopped) len = w0.y & SAMD_LEN_MASK;
-        if (w0.z == tok) {
-            idx = w0.w; len += 1;
-            if (w0.y & SAMD_RUN) {
-                const uint4 c = S.chain[idx];              // not waited for here: first used by the next token's chain_try
-                cw.lo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
-                cw.hi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
-            }
-            return visited;
-        }
-        int nx = -1;
-        if (!(w0.y & SAMD_SINGLE)) {
-            const int4 w1 = np[1], w2 = np[2], w3 = np[3];
-            nx = (w1.z == tok) ? w1.w : nx;
-            nx = (w2.x == tok) ? w2.y : nx;
-            nx = (w2.z == tok) ? w2.w : nx;
-            nx = (w3.x == tok) ? w3.y : nx;
-            if (nx < 0 && w1.y > SAMD_INLINE_EDGES)
-                nx = spill_search(S.spill + w3.z + SAMD_SPILL_HEAD, w1.y, tok);
-        }
-        if (nx >= 0) { idx = nx; len += 1; return visited; }
-        idx = w0.x; hopped = true;
-        if (idx == 0) len = 0;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // dynamic automaton (single wavefront, uniform control flow)
 // reference: samd_sam_only/sam/dyn_sam.py:50-114 (identical in samd/sam/dyn_sam.py:41-97)

@@ -23,10 +23,12 @@ static inline StaticDev static_view(const samd_static_t *s) {
 // batched walk: one lane per cursor, T tokens each (time-major token matrix => coalesced token loads).
 // Per visited state the lane issues ONE 16-byte load in the common case (st_transfer; node word 0 holds the suffix
 // link, the length and the most frequent successor) and high-degree states resolve through a hashed spill block, so
-// the launch generates ~1 HBM request per visited state (profiles/r01_walk_pmc.md: TCC_EA0_RDREQ == visited states)
-// and runs at the memory system's request rate (~48 G requests/s on MI355X, scripts/hbm_probe.hip).  A flattened
-// one-visit-per-iteration state machine with LDS-staged tokens and a lane-quad variant (4 lanes x 16 B per node) were
-// measured and are not faster once the kernel is request-bound; the simple nesting stays.
+// the node-only launch generates ~1 HBM request per visited state (profiles/r01_walk_pmc.md: TCC_EA0_RDREQ == visited states)
+// and runs at the memory system's scattered-request rate (~48 G requests/s on MI355X, scripts/hbm_probe.hip).  CHAIN = with chain
+// words (samd_common.h): a cursor inside a non-branching run follows up to 8 tokens from ONE 16-byte load -- 0.72 requests per
+// visited state, 0.377 vs 0.419 ms per launch (profiles/r02_walk_pmc.md).  Measured and not faster: a flattened one-visit-per-
+// iteration state machine with LDS-staged tokens, a lane-quad variant (4 lanes x 16 B per node), two cursors per lane with both
+// first loads in flight together (r02: 0.383 ms, 6 % more requests from chain words fetched for tokens that then mismatch).
 // ================================================================================================
 template <int W, bool CHAIN>
 __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__restrict__ cursors,
@@ -47,49 +49,6 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
             tok = nxt;
         }
         if (commit) reinterpret_cast<int2 *>(cursors)[b] = make_int2(idx, len);
-    }
-    if (visited_total) {
-        for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
-        if ((threadIdx.x & 63) == 0 && visited) atomicAdd(visited_total, visited);
-    }
-}
-
-// two cursors per lane: the first load of both (node word 0 / root entry) is in flight before either is consumed, and a chain word
-// fetched after a rank-0 step is not waited for until the next token.  With one cursor per lane the kernel sits between latency- and
-// request-bound once chain words have removed a third of its requests (profiles/r02_walk_pmc.md); the second cursor fills the gap.
-template <int W>
-__global__ __launch_bounds__(256) void k_static_walk2(StaticDev S, int32_t *__restrict__ cursors, const int32_t *__restrict__ tokens, int B, int T,
-                                                      int commit, int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total) {
-    const int half = (B + 1) >> 1;
-    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = a + half;
-    const bool haveA = a < half, haveB = haveA && b < B;
-    unsigned long long visited = 0;
-    if (haveA) {
-        const int2 ca = reinterpret_cast<const int2 *>(cursors)[a];
-        const int2 cb = haveB ? reinterpret_cast<const int2 *>(cursors)[b] : make_int2(0, 0);
-        int idxA = ca.x, lenA = ca.y, idxB = cb.x, lenB = cb.y;
-        int tokA = tokens[a], tokB = haveB ? tokens[b] : -1;
-        ChainWord cwA = chain_none(), cwB = chain_none();
-        for (int t = 0; t < T; t++) {
-            const int nxtA = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + a] : 0;
-            const int nxtB = (t + 1 < T && haveB) ? tokens[(size_t)(t + 1) * B + b] : -1;
-            const bool hitA = chain_try<W>(idxA, lenA, tokA, cwA);
-            const bool hitB = !haveB || chain_try<W>(idxB, lenB, tokB, cwB);
-            int4 fA, fB;
-            if (!hitA) fA = st_first_load(S, idxA, tokA);
-            if (!hitB) fB = st_first_load(S, idxB, tokB);
-            visited += hitA ? 1 : st_node_path<W>(S, idxA, lenA, tokA, cwA, fA);
-            if (haveB) visited += hitB ? 1 : st_node_path<W>(S, idxB, lenB, tokB, cwB, fB);
-            if (trace) {
-                reinterpret_cast<int2 *>(trace)[(size_t)t * B + a] = make_int2(idxA, lenA);
-                if (haveB) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(idxB, lenB);
-            }
-            tokA = nxtA; tokB = nxtB;
-        }
-        if (commit) {
-            reinterpret_cast<int2 *>(cursors)[a] = make_int2(idxA, lenA);
-            if (haveB) reinterpret_cast<int2 *>(cursors)[b] = make_int2(idxB, lenB);
-        }
     }
     if (visited_total) {
         for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
@@ -341,14 +300,7 @@ int samd_device_info(int64_t out[4]) {
 static void launch_walk(const samd_static_t *sam, int blocks, int threads, hipStream_t st, int32_t *d_cursors, const int32_t *d_tokens, int B, int T,
                         int commit, int32_t *d_trace, unsigned long long *d_visited) {
     static const bool use_chain = [] { const char *e = getenv("SAMD_WALK_CHAIN"); return !(e && e[0] == '0'); }();
-    static const bool two_cursors = [] { const char *e = getenv("SAMD_WALK_ILP"); return !(e && e[0] == '1'); }();     // SAMD_WALK_ILP=1: one cursor per lane
     const StaticDev v = static_view(sam);
-    if (use_chain && v.chain && two_cursors && B >= 2 * threads) {
-        const int blocks2 = ((B + 1) / 2 + threads - 1) / threads;
-        if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk2<8>), dim3(blocks2), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
-        else hipLaunchKernelGGL((k_static_walk2<4>), dim3(blocks2), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
-        return;
-    }
     if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, false>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
     else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, true>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
     else hipLaunchKernelGGL((k_static_walk<4, true>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
