@@ -47,7 +47,7 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // interleaved in groups of 64 (tile t = gate columns 64t.. | up columns 64t..), and the epilogue writes
 // silu(gate) * up [rows][N/2] -- LlamaMLP's activation without a launch, a 2N-wide intermediate or its re-read.
 template <typename TT, int RT, int EPI>
-__global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 1 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
+__global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 2 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                         float *__restrict__ partial, typename TT::elem *__restrict__ out,
                                                         int K, int N, int n_chunks, int n_splits) {
     typedef typename TT::elem E;
@@ -110,40 +110,26 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 1 : GEMM_WAVES / 2) void
     };
     // one phase: MFMAs of chunk c out of `cur` / LDS buffer `buf`, then the same registers are refilled with chunk c+2
     // and LDS buffer (buf + 2) % 3, which every wave finished reading before this phase's barrier
-    // A fragments of k block b of the current chunk: all row tiles in one batch of ds_read_b128 (row tile mt sits 16 rows = 8 KiB
-    // further: immediate offsets), issued WITHOUT a wait: the caller waits with lgkmcnt once the next block's reads are out too
-    auto issue_reads = [&](uint32_t xbase, int b, u32x4 (&r)[RT][2]) {
-        const uint32_t u0 = (uint32_t)((8 * b + 2 * g) ^ n) * 16, u1 = (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;   // rows 16 mt + n: (row & 15) == n
-        const uint32_t a0 = xbase + u0, a1 = xbase + u1;
-        if constexpr (RT == 1)
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3" : "=&v"(r[0][0]), "=&v"(r[0][1]) : "v"(a0), "v"(a1));
-        else if constexpr (RT == 2)
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:8192"
-                         : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]) : "v"(a0), "v"(a1));
-        else
-            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %9 offset:8192\n\t"
-                         "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %9 offset:16384\n\tds_read_b128 %6, %8 offset:24576\n\t"
-                         "ds_read_b128 %7, %9 offset:24576"
-                         : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1])
-                         : "v"(a0), "v"(a1));
-    };
-    // one phase: MFMAs of chunk c out of `cur` / LDS buffer `buf`, then the same registers are refilled with chunk c+2
-    // and LDS buffer (buf + 2) % 3, which every wave finished reading before this phase's barrier.  The LDS reads of k block b + 1
-    // are in flight while block b's MFMAs run (two register sets; LDS reads retire in order and nothing else uses lgkmcnt inside the
-    // loop, so "block b has landed" is lgkmcnt(2 RT) while block b + 1 is outstanding): at 64 rows a wave reads 32 KiB of A per chunk
-    // and the exposed LDS latency, four times per chunk, was what held the 4-row-tile stream at 3.4 TB/s.
     auto phase = [&](u32x4 (&cur)[4][2], int c, int buf) {
         landed(c + 1 < c1);
         const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
-        u32x4 ra[RT][2], rb[RT][2];
-        issue_reads(xbase, 0, ra);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            u32x4 (&r)[RT][2] = (b & 1) ? rb : ra;
-            if (b + 1 < 4) {
-                issue_reads(xbase, b + 1, (b & 1) ? ra : rb);
-                asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(2 * RT) : "memory");
-            } else asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+            const uint32_t u0 = (uint32_t)((8 * b + 2 * g) ^ n) * 16, u1 = (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;   // rows 16 mt + n: (row & 15) == n
+            // all row tiles of this k block in one LDS round trip (row tile mt sits 16 rows = 8 KiB further: immediate offsets)
+            const uint32_t a0 = xbase + u0, a1 = xbase + u1;
+            u32x4 r[RT][2];
+            if constexpr (RT == 1)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]) : "v"(a0), "v"(a1));
+            else if constexpr (RT == 2)
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:8192\n\t"
+                             "s_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]) : "v"(a0), "v"(a1));
+            else
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %9 offset:8192\n\t"
+                             "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %9 offset:16384\n\tds_read_b128 %6, %8 offset:24576\n\t"
+                             "ds_read_b128 %7, %9 offset:24576\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1])
+                             : "v"(a0), "v"(a1));
 #pragma unroll
             for (int mt = 0; mt < RT; mt++) {
                 acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][0]), __builtin_bit_cast(V8, cur[b][0]), acc[mt]);

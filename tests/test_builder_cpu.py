@@ -160,12 +160,5 @@ def test_gemm_kernel_isa_keeps_the_hand_counted_waits_valid(tmp_path):
         waits = {int(x) for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", body)}
         assert waits <= allowed, (name, waits)
         assert "global_load_lds_dwordx4" in body and "ds_read_b128" in body
-        # the A fragments of k block b + 1 are read while block b's MFMAs run: "block b landed" is the hand-written lgkmcnt(2 RT),
-        # valid only while nothing else counts on lgkmcnt inside the loop (no scalar loads after the first MFMA)
-        first_mfma = body.find("v_mfma")
-        assert first_mfma > 0 and not re.search(r"s_load|s_buffer_load", body[first_mfma:]), name
-        if re.search(r"Li\dELi0E", name):                        # plain epilogue: every lgkmcnt in the kernel is ours or the argument wait
-            lg = {int(x) for x in re.findall(r"lgkmcnt\((\d+)\)", body)}
-            assert lg <= {0, 2 * rt}, (name, lg)
     for m in re.finditer(r"\.name:\s+_Z13k_gemm_skinny.*?\.vgpr_spill_count:\s+(\d+)", asm, flags=re.S):
         assert int(m.group(1)) == 0
