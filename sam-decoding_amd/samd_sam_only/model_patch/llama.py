@@ -48,6 +48,50 @@ def tree_attention(q, k_cache, v_cache, tree_attn_mask, cache_length: int, n: in
     return out[:n]
 
 
+def hf_attention_forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+    """Drop-in for transformers' LlamaAttention.forward (the reference patches HF modules through `attn_patch_dict`,
+    samd_sam_only/model_patch/__init__.py:1-7): same projections, rotary embedding and cache update as HF, but the attention product
+    of a draft step -- bs = 1, <= 64 new rows, head_dim 128, fp16 / bf16, K/V views of a row-major SamdStaticCache, a 4-D additive
+    mask whose new-key block is the tree mask (model_patch/llama.py:94-96) -- runs on samd_tree_attention.  Anything else (prefill
+    chunks > 64 rows, other caches, fp32) goes to HF's eager attention unchanged."""
+    from transformers.models.llama.modeling_llama import apply_rotary_pos_emb, eager_attention_forward
+    input_shape = hidden_states.shape[:-1]
+    hidden_shape = (*input_shape, -1, self.head_dim)
+    q = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    k = self.k_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    v = self.v_proj(hidden_states).view(hidden_shape).transpose(1, 2)
+    cos, sin = position_embeddings
+    q, k = apply_rotary_pos_emb(q, k, cos, sin)
+    if past_key_values is not None:
+        k, v = past_key_values.update(k, v, self.layer_idx)
+    n, total = q.shape[2], k.shape[2]
+    D = self.head_dim
+    usable = (q.shape[0] == 1 and n <= samd_hip.MAX_DRAFT and D == 128 and q.dtype in (torch.float16, torch.bfloat16) and q.is_cuda
+              and attention_mask is not None and attention_mask.dim() == 4 and attention_mask.shape[-1] >= total
+              and k.stride(3) == 1 and k.stride(2) == D and v.stride(3) == 1 and v.stride(2) == D and k.stride(1) == v.stride(1)
+              and k.stride(1) % D == 0 and not getattr(past_key_values, "v_transposed", False))
+    if not usable:
+        out, w = eager_attention_forward(self, q, k, v, attention_mask, dropout=0.0, scaling=self.scaling, **kwargs)
+        return self.o_proj(out.reshape(*input_shape, -1).contiguous()), w
+    L = total - n
+    H, Hkv, max_len = q.shape[1], k.shape[1], k.stride(1) // D
+    m = (attention_mask[0, 0, :n, L:total] == 0).to(torch.int64)
+    rows = torch.zeros(samd_hip.MAX_DRAFT, dtype=torch.int64, device=q.device)
+    rows[:n] = (m << torch.arange(n, device=q.device, dtype=torch.int64)[None, :]).sum(-1)
+    n_pad = n
+    qn = q[0].transpose(0, 1).contiguous()                                   # [n, H, D]
+    out = torch.empty_like(qn)
+    ws_bytes = samd_hip.lib().samd_tree_attention_workspace(n_pad, H, D)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    d_L = torch.tensor([L], dtype=torch.int32, device=q.device)
+    d_n = torch.tensor([n], dtype=torch.int32, device=q.device)
+    samd_hip.check(samd_hip.lib().samd_tree_attention(
+        samd_hip._ptr(qn), samd_hip._ptr(k), samd_hip._ptr(v), samd_hip._ptr(out), samd_hip.torch_dtype_code(q.dtype), n_pad, H, Hkv, D, max_len,
+        samd_hip._ptr(rows), samd_hip._ptr(d_L), samd_hip._ptr(d_n), float(self.scaling), samd_hip._ptr(ws), ws_bytes, samd_hip.current_stream()))
+    torch.cuda.current_stream().synchronize()                                 # rows / d_L / d_n / ws are locals
+    return self.o_proj(out.reshape(*input_shape, -1)), None
+
+
 def _runner_for(lm, max_cache_len, dtype, device, **kw):
     from samd_hip.llama import LlamaRunner
     return LlamaRunner.from_hf(lm, max_cache_len, dtype, device, **kw)
@@ -59,7 +103,9 @@ def _tables():
         from transformers.models.llama.modeling_llama import LlamaAttention
     except Exception:                                # transformers absent: the runner can still be built from raw weights
         return {}, {}
-    return {LlamaForCausalLM: [("forward", _runner_for)]}, {LlamaAttention: [("forward", tree_attention)]}
+    # patch_dict: what SamdModel swaps the LM's forward for (its own decoder loop, samd_hip.llama.LlamaRunner);
+    # attn_patch_dict: a forward with HF's LlamaAttention signature for callers that keep driving the HF module themselves
+    return {LlamaForCausalLM: [("forward", _runner_for)]}, {LlamaAttention: [("forward", hf_attention_forward)]}
 
 
 patch_dict, attn_patch_dict = _tables()

@@ -419,3 +419,54 @@ def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
         assert toks.tolist() == prompt and logits.shape == (200, 512) and hidden.shape == (200, 256)
         assert (logits - full.logits[0]).abs().max().item() < TOL
     assert (outs["wide"][5] - outs["chunked"][5]).abs().max().item() < 3e-2          # final-norm hidden states of every prompt token
+
+
+def test_attn_patch_dict_forward_is_a_drop_in_for_hf_attention():
+    """samd_sam_only.model_patch.attn_patch_dict (the reference's patch registry, model_patch/__init__.py:1-7): binding its
+    LlamaAttention.forward keeps an HF model + SamdStaticCache producing HF's logits while a <= 64-row tree step runs on
+    samd_tree_attention (fp16 tolerance 3e-2 against the unpatched fp32 model)."""
+    import types
+    from transformers import DynamicCache
+    from transformers.models.llama.modeling_llama import LlamaAttention
+    from samd_sam_only.cache import SamdStaticCache
+    from samd_sam_only.model_patch import attn_patch_dict
+    lm32 = tiny_llama(2, seed=21)
+    lm = tiny_llama(2, seed=21).half()
+    rng = np.random.default_rng(21)
+    prompt = rng.integers(3, 512, 50).tolist()
+    n, L = 19, len(prompt)
+    anc = random_parents(rng, n, "bushy")
+    toks = rng.integers(3, 512, n).tolist()
+    depth = [0] * n
+    for i in range(1, n):
+        depth[i] = depth[anc[i]] + 1
+    ids = torch.tensor([prompt], device="cuda")
+    def mask4d(dtype):
+        m = torch.full((1, 1, n, L + n), torch.finfo(dtype).min, device="cuda", dtype=dtype)
+        m[..., :L] = 0
+        for i in range(n):
+            j = i
+            while j != -1:
+                m[0, 0, i, L + j] = 0
+                j = anc[j]
+        return m
+    with torch.no_grad():
+        ref_cache = DynamicCache()
+        lm32(input_ids=ids, past_key_values=ref_cache, use_cache=True)
+        want = lm32(input_ids=torch.tensor([toks], device="cuda"), position_ids=torch.tensor([[L + d for d in depth]], device="cuda"),
+                    attention_mask=mask4d(torch.float32), past_key_values=ref_cache, use_cache=True).logits[0]
+    name, fn = attn_patch_dict[LlamaAttention][0]
+    calls = []
+    for mod in lm.modules():
+        if isinstance(mod, LlamaAttention):
+            def bound(self, *a, _fn=fn, **kw):
+                calls.append(a[0].shape[1] if a else kw["hidden_states"].shape[1])
+                return _fn(self, *a, **kw)
+            setattr(mod, name, types.MethodType(bound, mod))
+    cache = SamdStaticCache(lm.config, batch_size=1, max_cache_len=256, device="cuda", dtype=torch.float16)
+    with torch.no_grad():
+        lm(input_ids=ids, past_key_values=cache, use_cache=True, cache_position=torch.arange(L, device="cuda"))
+        cache.set_length()
+        got = lm(input_ids=torch.tensor([toks], device="cuda"), position_ids=torch.tensor([[L + d for d in depth]], device="cuda"),
+                 attention_mask=mask4d(torch.float16), past_key_values=cache, use_cache=True, cache_position=torch.arange(L, L + n, device="cuda")).logits[0]
+    assert calls and (got.float() - want).abs().max().item() < TOL
