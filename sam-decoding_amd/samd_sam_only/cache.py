@@ -69,6 +69,14 @@ class SamdStaticCache:
     def get_max_cache_shape(self) -> Optional[int]:
         return self.max_cache_len
 
+    # what transformers 5.x asks a cache for when it builds the causal mask of a forward (masking_utils._preprocess_mask_arguments):
+    # queries start at the committed length, keys are the rows update() returns ([0, committed + new))
+    def get_query_offset(self, layer_idx=0):
+        return self.cache_length
+
+    def get_mask_sizes(self, query_length, layer_idx=0):
+        return self.cache_length + int(query_length), 0
+
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
         """cache.py:103-115"""
         n = key_states.shape[2]
