@@ -183,7 +183,7 @@ class DeviceHead:
         hipGraph), samd_e2_rowstats (log-softmax + top-8 per row) and samd_e2_select (cumulative scores, top-8 of 64, next level's
         inputs and masks) -- six launches where the PyTorch form issues ~35 small ops and leaves the GPU waiting for the host (3.7 ms
         per draft against 2 ms of GPU work at Llama-3-8B shapes).  Capturing those PyTorch ops in hipGraphs instead faulted on replay
-        once several such graphs existed (ROCm 7.2, scripts/_debug_eagle2.py).  Falls back to the PyTorch form when the head's shape
+        once several such graphs existed (ROCm 7.2).  Falls back to the PyTorch form when the head's shape
         does not fit the kernels (top_k != 8, depth > 7, fc not streamable)."""
         import samd_hip
         depth, keep = head.depth, head.total_tokens

@@ -1,6 +1,6 @@
 """eagle_draft_bench.py -- one EAGLE-2 draft (extension of T accepted tokens + 5 tree levels + re-rank) of the device head at
 Llama-3-8B shapes (bf16, GQA 32/8, vocabulary 128256), random weights: milliseconds per draft, wall clock around a synchronised
-loop, with the levels replayed as one hipGraph (default) and launched one by one (SAMD_EAGLE_GRAPH=0), plus the pieces:
+loop, with the tree logic in the library's kernels (default) and as PyTorch ops (SAMD_EAGLE_KERNELS=0), plus the pieces:
 one head forward per row bucket, the fc projection, the per-level PyTorch ops.  usage: python scripts/eagle_draft_bench.py [T]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,8 +35,9 @@ def draft():
     for _ in range(20):                       # a request: L grows to ~60 + 20 T
         dh.eagle2_draft(head, hs, ids)
 for mode in ("1", "0"):
-    os.environ["SAMD_EAGLE_GRAPH"] = mode
-    print(f"draft (T = {T}), levels as one graph = {mode}: {timed(draft, 5) / 20:.3f} ms", flush=True)
+    os.environ["SAMD_EAGLE_KERNELS"] = mode
+    print(f"draft (T = {T}), tree-logic kernels = {mode}: {timed(draft, 5) / 20:.3f} ms", flush=True)
+os.environ["SAMD_EAGLE_KERNELS"] = "1"
 x8 = torch.randn((8, 4096), generator=g, device="cuda").to(dtype)
 pos, eye = dh.level_pos[0], torch.eye(8, device="cuda")
 from samd.tree_model.device_head import _mask_rows
