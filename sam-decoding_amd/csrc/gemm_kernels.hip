@@ -46,8 +46,9 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // EPI 0: out / fp32 partials as they are.  EPI 1 (splits == 1 only): the matrix is the MLP's gate|up pair with its rows
 // interleaved in groups of 64 (tile t = gate columns 64t.. | up columns 64t..), and the epilogue writes
 // silu(gate) * up [rows][N/2] -- LlamaMLP's activation without a launch, a 2N-wide intermediate or its re-read.
-template <typename TT, int RT, int EPI>
-__global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 2 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
+// DEPTH = weight chunks (+ their A tiles) in flight whenever a wave waits; DEPTH + 1 LDS buffers (dynamic LDS: 128 KiB at 64 rows).
+template <typename TT, int RT, int EPI, int DEPTH>
+__global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 || DEPTH > 2 ? 2 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                         float *__restrict__ partial, typename TT::elem *__restrict__ out,
                                                         int K, int N, int n_chunks, int n_splits) {
     typedef typename TT::elem E;
@@ -59,7 +60,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 2 : GEMM_WAVES / 2) void
     // ds_read_b128 wave-instruction touches (same unit, rows m..m+15) land in 16 different 16-byte slots -> no bank
     // conflict, and rows stay contiguous so the tile can be filled by LDS-DMA (global_load_lds, 1 KiB per wave-instruction,
     // no VGPR round trip; the swizzle goes on the SOURCE address).
-    __shared__ __attribute__((aligned(1024))) E xs[3][R][GEMM_KC];
+    constexpr int NB = DEPTH + 1;
+    extern __shared__ __attribute__((aligned(1024))) char gemm_lds[];
+    E (*xs)[R][GEMM_KC] = reinterpret_cast<E (*)[R][GEMM_KC]>(gemm_lds);
 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const int n0 = blockIdx.x * GEMM_COLS + 16 * w;
@@ -78,40 +81,44 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 2 : GEMM_WAVES / 2) void
     // outstanding load (vmcnt(0)) in front of each chunk's first LDS read and first MFMA, which leaves ONE chunk in flight.
     // Here TWO chunks (+ their A tiles) are in flight whenever a wave waits: memory ops retire in issue order, so "chunk c
     // has landed, chunk c+1 may still fly" is vmcnt(8 + XV).  scripts/stream_probe.hip: 18.3 vs 20.2 us for the QKV matrix.
-    u32x4 wa[4][2], wb[4][2];
-    auto load_w = [&](u32x4 (&dst)[4][2], int c) {
+    u32x4 wr[DEPTH][4][2];
+    auto load_wb = [&](u32x4 (&dst)[4][2], int c, int b) {
         const char *p = wtile + (size_t)c * 65536;                   // wave-uniform -> SGPR base, one offset VGPR
 #pragma unroll
-        for (int b = 0; b < 4; b++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 8192 * (2 * b + j)) : "memory");
+        for (int j = 0; j < 2; j++)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 8192 * (2 * b + j)) : "memory");
     };
-    auto stage_x = [&](int c, int buf) {          // asynchronous: lands in LDS, counted by vmcnt
-#pragma unroll
-        for (int i = 0; i < XV; i++) {
-            const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
-            const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
-            E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;       // wave-uniform base; the hardware adds lane * 16 B
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        }
+    auto stage_xi = [&](int c, int buf, int i) {   // asynchronous: lands in LDS, counted by vmcnt
+        const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
+        const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
+        E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;       // wave-uniform base; the hardware adds lane * 16 B
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         asm volatile("" ::: "memory");
+    };
+    auto load_w = [&](u32x4 (&dst)[4][2], int c) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) load_wb(dst, c, b);
+    };
+    auto stage_x = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < XV; i++) stage_xi(c, buf, i);
     };
     // wait for the oldest chunk in flight, then meet the other waves -- their LDS-DMA shares of the A tile are then in
     // place.  Bare s_barrier: __syncthreads() carries a fence that would drain the younger chunk as well.  Nothing ties
     // the weight registers to the wait (an in/out operand would make the compiler copy them BEFORE the wait, i.e. while
     // the load is in flight); instead every MFMA also consumes an LDS operand that a volatile asm after the wait produces,
     // and volatile asm statements keep their order.
-    auto landed = [&](bool younger_in_flight) {
-        if (younger_in_flight) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + XV) : "memory");
+    auto landed = [&](int younger_in_flight) {
+        if (DEPTH > 2 && younger_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (8 + XV)) : "memory");
+        else if (younger_in_flight >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + XV) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // one phase: MFMAs of chunk c out of `cur` / LDS buffer `buf`, then the same registers are refilled with chunk c+2
-    // and LDS buffer (buf + 2) % 3, which every wave finished reading before this phase's barrier
+    // one phase: MFMAs of chunk c out of `cur` / LDS buffer `buf`, then the same registers are refilled with chunk c + DEPTH
+    // and LDS buffer (buf - 1) mod NB, which every wave finished reading before this phase's barrier
     auto phase = [&](u32x4 (&cur)[4][2], int c, int buf) {
-        landed(c + 1 < c1);
+        landed(c1 - 1 - c);
         const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -135,23 +142,30 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 ? 2 : GEMM_WAVES / 2) void
                 acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][0]), __builtin_bit_cast(V8, cur[b][0]), acc[mt]);
                 acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][1]), __builtin_bit_cast(V8, cur[b][1]), acc[mt]);
             }
+            // 64 rows: refill as soon as this k block's operands are consumed -- the loads trickle into the memory pipe between
+            // the k blocks instead of arriving as one burst after a load-free compute window (all 8 waves compute at once):
+            // gate|up 40.5 -> 39.8 us; neutral at 16 / 32 rows, which keep the burst (profiles/r02_gemm_rows64.md)
+            if (RT == 4 && c + DEPTH < c1) {
+                load_wb(cur, c + DEPTH, b);
+                if (b < XV) stage_xi(c + DEPTH, buf == 0 ? NB - 1 : buf - 1, b);
+            }
         }
-        if (c + 2 < c1) { load_w(cur, c + 2); stage_x(c + 2, buf == 0 ? 2 : buf - 1); }
+        if (RT != 4 && c + DEPTH < c1) { load_w(cur, c + DEPTH); stage_x(c + DEPTH, buf == 0 ? NB - 1 : buf - 1); }
     };
     if (c0 < c1) {
-        load_w(wa, c0);
-        stage_x(c0, 0);
-        if (c0 + 1 < c1) { load_w(wb, c0 + 1); stage_x(c0 + 1, 1); }
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++)
+            if (c0 + d < c1) { load_w(wr[d], c0 + d); stage_x(c0 + d, d); }
         int buf = 0;
-        for (int c = c0; c < c1; c += 2) {
-            phase(wa, c, buf);
-            buf = buf == 2 ? 0 : buf + 1;
-            if (c + 1 < c1) { phase(wb, c + 1, buf); buf = buf == 2 ? 0 : buf + 1; }
+        for (int c = c0; c < c1; c += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++)
+                if (c + d < c1) { phase(wr[d], c + d, buf); buf = buf == NB - 1 ? 0 : buf + 1; }
         }
     }
     // C layout of mfma_16x16: lane holds rows 4g + r of column n
     if constexpr (EPI == 1) {
-        float *ex = reinterpret_cast<float *>(&xs[0][0][0]);        // [R][64] up values; the A tiles are dead by now
+        float *ex = reinterpret_cast<float *>(gemm_lds);            // [R][64] up values; the A tiles are dead by now
         __syncthreads();
         if (w >= 4) {
 #pragma unroll
@@ -198,6 +212,30 @@ __global__ __launch_bounds__(256) void k_gemm_pack(const uint4 *__restrict__ W, 
     out[u] = W[(row * K + col) / 8];
 }
 
+// DEPTH = 2 chunks in flight at every row tile.  Three (128 KiB of LDS at 64 rows) measured SLOWER: gate|up 40.3 vs 38.8 us at 64
+// rows, 34.9 vs 34.5 at 32 -- the launch is not short of requests in flight (profiles/r02_gemm_rows64.md).
+template <typename TT, int RT, int EPI, int DEPTH>
+static hipError_t gemm_launch(dim3 grid, hipStream_t st, const void *A, const void *W, float *partial, void *out, int K, int N, int chunks, int splits) {
+    constexpr int lds = (DEPTH + 1) * 16 * RT * GEMM_KC * 2;
+    if constexpr (lds > 65536) {
+        static const hipError_t attr = hipFuncSetAttribute((const void *)k_gemm_skinny<TT, RT, EPI, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL((k_gemm_skinny<TT, RT, EPI, DEPTH>), grid, dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, partial,
+                       (typename TT::elem *)out, K, N, chunks, splits);
+    return hipSuccess;
+}
+
+template <int EPI>
+static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t st, const void *A, const void *W, float *partial, void *out, int K, int N, int chunks,
+                                int splits) {
+#define GO(TT, RT, D) return gemm_launch<TT, RT, EPI, D>(grid, st, A, W, partial, out, K, N, chunks, splits)
+#define ROWS(TT) do { if (rows_pad == 16) GO(TT, 1, 2); else if (rows_pad == 32) GO(TT, 2, 2); else GO(TT, 4, 2); } while (0)
+    if (dtype == SAMD_F16) ROWS(GF16); else ROWS(GBF16);
+#undef ROWS
+#undef GO
+}
+
 extern "C" {
 
 // choose the split-K factor.  Measured (scripts/gemm_bench.py, profiles/): the stream is fastest when the launch is ONE
@@ -228,13 +266,8 @@ int samd_gemm_skinny_silu(const void *d_A, const void *d_W, int32_t rows_pad, in
         K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
         samd_set_error("samd_gemm_skinny_silu: unsupported shape (rows 16/32/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
     }
-    const dim3 grid(N / GEMM_COLS, 1), block(64 * GEMM_WAVES);
-    hipStream_t st = (hipStream_t)stream;
-    const int chunks = K / GEMM_KC;
-#define GO(TT, RT) hipLaunchKernelGGL((k_gemm_skinny<TT, RT, 1>), grid, block, 0, st, (const TT::elem *)d_A, (const TT::elem *)d_W, (float *)nullptr, (TT::elem *)d_out, K, N, chunks, 1)
-    if (dtype == SAMD_F16) { if (rows_pad == 16) GO(GF16, 1); else if (rows_pad == 32) GO(GF16, 2); else GO(GF16, 4); }
-    else { if (rows_pad == 16) GO(GBF16, 1); else if (rows_pad == 32) GO(GBF16, 2); else GO(GBF16, 4); }
-#undef GO
+    const hipError_t e = gemm_dispatch<1>(dtype, rows_pad, dim3(N / GEMM_COLS, 1), (hipStream_t)stream, d_A, d_W, nullptr, d_out, K, N, K / GEMM_KC, 1);
+    if (e != hipSuccess) { samd_set_error("samd_gemm_skinny_silu: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }
@@ -255,14 +288,9 @@ int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t
         K % GEMM_KC != 0 || splits < 1 || splits > K / GEMM_KC || (splits == 1 ? !d_out : !d_partial) || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
         samd_set_error("samd_gemm_skinny: unsupported shape (rows 16/32/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
     }
-    const dim3 grid(N / GEMM_COLS, splits), block(64 * GEMM_WAVES);
-    hipStream_t st = (hipStream_t)stream;
-    const int chunks = K / GEMM_KC;
-    void *out = splits == 1 ? d_out : nullptr;
-#define GO(TT, RT) hipLaunchKernelGGL((k_gemm_skinny<TT, RT, 0>), grid, block, 0, st, (const TT::elem *)d_A, (const TT::elem *)d_W, d_partial, (TT::elem *)out, K, N, chunks, splits)
-    if (dtype == SAMD_F16) { if (rows_pad == 16) GO(GF16, 1); else if (rows_pad == 32) GO(GF16, 2); else GO(GF16, 4); }
-    else { if (rows_pad == 16) GO(GBF16, 1); else if (rows_pad == 32) GO(GBF16, 2); else GO(GBF16, 4); }
-#undef GO
+    const hipError_t e = gemm_dispatch<0>(dtype, rows_pad, dim3(N / GEMM_COLS, splits), (hipStream_t)stream, d_A, d_W, d_partial, splits == 1 ? d_out : nullptr, K, N,
+                                          K / GEMM_KC, splits);
+    if (e != hipSuccess) { samd_set_error("samd_gemm_skinny: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -1,6 +1,6 @@
 """gemm_probe.py -- only the weight-streaming projections of ONE decoder layer + lm_head (k_gemm_skinny at 16 rows, Vicuna-7B
 shapes, packed weights), rotating over three weight sets so that nothing is served from the Infinity Cache; for rocprofv3
---stats / --pmc passes (scripts/pmc_gemm.sh).  usage: python3 scripts/gemm_probe.py [layers_worth_of_launches]"""
+--stats / --pmc passes (scripts/pmc_gemm.sh).  usage: python3 scripts/gemm_probe.py [layers_worth_of_launches] [rows]"""
 import os
 import sys
 
@@ -10,8 +10,8 @@ import torch
 import samd_hip
 
 L = samd_hip.lib()
-R = 16
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+R = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 shapes = [("qkv", 12288, 4096, False), ("o", 4096, 4096, False), ("gate_up", 22016, 4096, True), ("down", 4096, 11008, False)]
 sets = []
 for _ in range(3):

@@ -289,3 +289,24 @@ def test_sampling_generate_runs_and_is_seeded():
     assert outs[0].output_ids == outs[1].output_ids
     seq = outs[0].output_ids[0]
     assert seq[:len(prompt)] == prompt and len(seq) > len(prompt) and all(0 <= t < 512 for t in seq)
+
+
+def test_runner_shorter_than_generation_config_is_an_error():
+    """a ready-made runner holds K/V rows for ITS max_cache_len only: asking for a longer generation must raise instead of
+    silently dropping rows past the end (reference: the cache is always sized from generation_config, samd_model.py:176-191);
+    a shorter or equal request keeps working on the same runner."""
+    import samd_hip
+    import samd_sam_only as SO
+    from samd_hip.llama import LlamaRunner
+    mcfg = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-5)
+    runner = LlamaRunner.random_init(mcfg, 128, torch.float16, seed=4, std=0.05)
+    cfg = SO.SamdConfig(max_predicts=8, len_bias=0)
+    model = SO.SamdModel(cfg, runner, SO.DraftModel(cfg, device="cuda"), 2, torch.float16, "cuda")
+    ids = torch.tensor([np.random.default_rng(1).integers(3, 512, 12).tolist()], device="cuda")
+    with pytest.raises(samd_hip.SamdError, match="exceeds the runner's max_cache_len 128"):
+        model.generate(ids, generation_config=SO.SamdGenerationConfig(max_new_tokens=8, max_cache_len=256))
+    out = model.generate(ids, generation_config=SO.SamdGenerationConfig(max_new_tokens=8, max_cache_len=128))
+    assert len(out.output_ids[0]) > ids.shape[1]
+    out2 = model.generate(ids, generation_config=SO.SamdGenerationConfig(max_new_tokens=8, max_cache_len=96))
+    assert out2.output_ids == out.output_ids
