@@ -345,7 +345,11 @@ typedef struct samd_e2_state {
     int32_t *parents_list; uint64_t *mask_rows; int32_t *row_src; int32_t *ids;
     float *rec_top_vals; int32_t *rec_top_idx; float *rec_best_vals; int32_t *rec_best_idx; float *rec_final_vals; int32_t *rec_final_idx;
 } samd_e2_state_t;
-int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const samd_e2_state_t *st, void *stream);
+/* d_workspace (samd_e2_rowstats_workspace(vocab) bytes; 0 = vocabulary too large for the split form): every row is spread over
+ * vocab / 4096 workgroups + one merge launch (f16 / bf16 logits); NULL: one workgroup per row (also the f32 form). Same results. */
+int64_t samd_e2_rowstats_workspace(int64_t vocab);
+int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const samd_e2_state_t *st, void *d_workspace,
+                     int64_t workspace_bytes, void *stream);
 int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidden, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in,
                    int32_t *d_rel_pos /* optional: [8] <- level + 1 */, int32_t dtype, void *stream);
 int samd_e2_finish(const samd_e2_state_t *st, int32_t depth, int32_t keep, const int64_t *d_sample_token, int32_t *d_tokens, int32_t *d_parents, void *stream);

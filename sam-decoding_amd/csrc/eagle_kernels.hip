@@ -46,6 +46,29 @@ __device__ __forceinline__ float e2_f32(__bf16 x) { return (float)x; }
 __device__ __forceinline__ float e2_f32(float x) { return x; }
 __device__ __forceinline__ bool e2_before(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
+// wave-wide max / min on the DPP network (row_shr 1, 2, 4, 8 inside each row of 16 lanes, row_bcast:15 / :31 across the rows; the
+// result sits in lane 63): ~8 VALU instructions where a __shfl_xor butterfly is 6 dependent LDS-crossbar round trips.  All 64
+// lanes must be active.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int e2_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ float e2_wave_max(float x) {
+    const int ninf = __builtin_bit_cast(int, -INFINITY);
+#define E2_STEP(CTRL, MASK) x = fmaxf(x, __builtin_bit_cast(float, e2_dpp<CTRL, MASK>(ninf, __builtin_bit_cast(int, x))))
+    E2_STEP(0x111, 0xf); E2_STEP(0x112, 0xf); E2_STEP(0x114, 0xf); E2_STEP(0x118, 0xf); E2_STEP(0x142, 0xa); E2_STEP(0x143, 0xc);
+#undef E2_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ int e2_wave_min(int x) {                 // non-negative values
+#define E2_STEP(CTRL, MASK) x = min(x, e2_dpp<CTRL, MASK>(0x7fffffff, x))
+    E2_STEP(0x111, 0xf); E2_STEP(0x112, 0xf); E2_STEP(0x114, 0xf); E2_STEP(0x118, 0xf); E2_STEP(0x142, 0xa); E2_STEP(0x143, 0xc);
+#undef E2_STEP
+    return __builtin_amdgcn_readlane(x, 63);
+}
+// the wave's best (value desc, index asc) of one (v, i) per lane; i = 0x7fffffff marks "nothing"
+__device__ __forceinline__ void e2_wave_best(float v, int i, float &out_v, int &out_i) {
+    out_v = e2_wave_max(v);
+    out_i = e2_wave_min(v == out_v ? i : 0x7fffffff);
+}
+
 // per row: log-sum-exp over the vocabulary and the top-8 logits (value desc, index asc) -> top_logp = logit - lse, top_idx.
 // One workgroup of 1024 threads per row; 16-byte vector loads, four in flight per thread (a scalar loop with its data-dependent
 // insertion branch waits a full memory latency per element: 433 us per call at a 128 k vocabulary against 15 us for this form).
@@ -135,12 +158,158 @@ __global__ __launch_bounds__(1024) void k_e2_rowstats(const T *__restrict__ logi
     }
 }
 
+// The same result from MANY workgroups (the one-workgroup form above is VALU-bound on a single CU: with 64 lanes per wave some
+// lane inserts at almost every element, so every element pays the 8-step insertion -- 75 us per call at a 128 k vocabulary whatever
+// the row count).  Stage 1: workgroup (row, split) owns 4096 consecutive elements, 16 per thread in registers; log-sum-exp partial
+// (m, s) and the segment's best 8 by 8 rounds of block arg-max (only the winning thread rescans its 16).  Stage 2: one workgroup per
+// row merges the splits' (m, s) in split order and the <= 64 x 8 candidates the same way.  Order: (value desc, index asc) throughout.
+#define E2_SEG 4096                     // elements per stage-1 workgroup
+#define E2_EPT 16                       // elements per thread (256 threads)
+#define E2_MAXSPLIT 64
+
+// 8 rounds of block arg-max over per-thread element lists held in registers (N per thread); the holder of the winner removes it
+// and rescans its list.  Every thread ends up with the 8 winners in res_v / res_i (registers: a store to global memory inside the
+// loop would make every round's barrier wait for it -- 2.3 us per round, measured).  256 threads; sv / si = 8 LDS slots each.
+template <int N>
+__device__ __forceinline__ void e2_block_top8(float (&v)[N], int (&id)[N], float (&res_v)[E2_K], int (&res_i)[E2_K], float *sv, int *si) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < N; q++) if (e2_before(v[q], id[q], bv, bi)) { bv = v[q]; bi = id[q]; }
+#pragma unroll
+    for (int round = 0; round < E2_K; round++) {
+        float wv; int wi;
+        e2_wave_best(bv, bi, wv, wi);
+        const int slot = (round & 1) * 4;
+        if (lane == 0) { sv[slot + wave] = wv; si[slot + wave] = wi; }
+        __syncthreads();
+        float gv = sv[slot]; int gi = si[slot];
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            const float ov = sv[slot + k]; const int oi = si[slot + k];
+            if (e2_before(ov, oi, gv, gi)) { gv = ov; gi = oi; }
+        }
+        res_v[round] = gv; res_i[round] = gi;
+        if (bi == gi && gi != 0x7fffffff) {                // indices are unique: this thread holds the winner
+            bv = -INFINITY; bi = 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < N; q++) {
+                if (id[q] == gi) { v[q] = -INFINITY; id[q] = 0x7fffffff; }
+                if (e2_before(v[q], id[q], bv, bi)) { bv = v[q]; bi = id[q]; }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_e2_rowstats_part(const T *__restrict__ logits, long long vocab, long long stride, int n_split,
+                                                          float *__restrict__ part_ms, float *__restrict__ part_v, int *__restrict__ part_i) {
+    const int row = blockIdx.x, split = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T *x = logits + (size_t)row * stride;
+    const long long seg0 = (long long)split * E2_SEG;
+    constexpr int VEC = 16 / sizeof(T), NV = E2_EPT / VEC;
+    float v[E2_EPT]; int id[E2_EPT];
+    const bool vec_ok = ((((size_t)x) & 15) == 0);
+    if (vec_ok) {
+        uint4 raw[NV];
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const long long e0 = seg0 + ((long long)u * 256 + tid) * VEC;
+            if (e0 + VEC <= vocab) raw[u] = *reinterpret_cast<const uint4 *>(x + e0);
+        }
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const long long e0 = seg0 + ((long long)u * 256 + tid) * VEC;
+            const T *e = reinterpret_cast<const T *>(&raw[u]);
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+                const long long g = e0 + q;
+                const bool in = g < vocab;
+                v[u * VEC + q] = !in ? -INFINITY : (e0 + VEC <= vocab ? e2_f32(e[q]) : e2_f32(x[g]));
+                id[u * VEC + q] = in ? (int)g : 0x7fffffff;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < E2_EPT; q++) {
+            const long long g = seg0 + (long long)q * 256 + tid;
+            const bool in = g < vocab;
+            v[q] = in ? e2_f32(x[g]) : -INFINITY; id[q] = in ? (int)g : 0x7fffffff;
+        }
+    }
+    float m = -INFINITY, s = 0.f;
+#pragma unroll
+    for (int q = 0; q < E2_EPT; q++) m = fmaxf(m, v[q]);
+#pragma unroll
+    for (int q = 0; q < E2_EPT; q++) if (v[q] != -INFINITY) s += __expf(v[q] - m);
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o), os = __shfl_xor(s, o);
+        const float M = fmaxf(m, om);
+        s = (m == -INFINITY ? 0.f : s * __expf(m - M)) + (om == -INFINITY ? 0.f : os * __expf(om - M));
+        m = M;
+    }
+    __shared__ float wm[4], ws[4], sv[8]; __shared__ int si[8];
+    if (lane == 0) { wm[wave] = m; ws[wave] = s; }
+    __syncthreads();
+    if (tid == 0) {
+        float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])), S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (wm[k] != -INFINITY) S += ws[k] * __expf(wm[k] - M);
+        part_ms[((size_t)row * n_split + split) * 2] = M; part_ms[((size_t)row * n_split + split) * 2 + 1] = S;
+    }
+    float res_v[E2_K]; int res_i[E2_K];
+    e2_block_top8<E2_EPT>(v, id, res_v, res_i, sv, si);
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < E2_K; k++) { part_v[((size_t)row * n_split + split) * E2_K + k] = res_v[k]; part_i[((size_t)row * n_split + split) * E2_K + k] = res_i[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_e2_rowstats_merge(int n_split, const float *__restrict__ part_ms, const float *__restrict__ part_v,
+                                                           const int *__restrict__ part_i, E2State S) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    __shared__ float sv[8], s_lse; __shared__ int si[8];
+    if (tid < 64) {                                           // log-sum-exp over the splits, in split order
+        float m = tid < n_split ? part_ms[((size_t)row * n_split + tid) * 2] : -INFINITY;
+        float M = m;
+        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+        if (tid == 0) {
+            float acc = 0.f;
+            for (int k = 0; k < n_split; k++) {
+                const float mk = part_ms[((size_t)row * n_split + k) * 2];
+                if (mk != -INFINITY) acc += part_ms[((size_t)row * n_split + k) * 2 + 1] * __expf(mk - M);
+            }
+            s_lse = M + logf(acc);
+        }
+    }
+    float v[2]; int id[2];
+    const int n_cand = n_split * E2_K;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int c = tid + 256 * q;
+        v[q] = c < n_cand ? part_v[(size_t)row * n_cand + c] : -INFINITY;
+        id[q] = c < n_cand ? part_i[(size_t)row * n_cand + c] : 0x7fffffff;
+        if (id[q] == 0x7fffffff) v[q] = -INFINITY;
+    }
+    float out_v[E2_K]; int out_i[E2_K];
+    e2_block_top8<2>(v, id, out_v, out_i, sv, si);            // (its barriers also publish s_lse)
+    if (tid == 0) {
+        const float lse = s_lse;
+        S.row_lse[row] = lse;
+#pragma unroll
+        for (int k = 0; k < E2_K; k++) {
+            S.top_logp[row * E2_K + k] = out_i[k] == 0x7fffffff ? -INFINITY : out_v[k] - lse;
+            S.top_idx[row * E2_K + k] = out_i[k] == 0x7fffffff ? 0 : out_i[k];
+        }
+    }
+}
+
 // level = -1: the root (row 0 of top_* = the last accepted position): candidates 0..7, no selection among k*k.
 // level >= 0: rows 0..7 of top_* = the outputs of tree level `level`; selects the 8 rows of level + 1 and stages their inputs.
 // hidden [rows][H] = the previous forward's output states (row r of the level, or the single last accepted row for the root);
 // fc_in [8][2H] <- [embed[ids[t]] | hidden[row_src[t]]]; mask_rows <- ancestor bits of the new rows.
 template <typename T>
-__global__ __launch_bounds__(256) void k_e2_select(E2State S, int level, const T *__restrict__ hidden, const T *__restrict__ embed, int H, int vocab,
+__global__ __launch_bounds__(1024) void k_e2_select(E2State S, int level, const T *__restrict__ hidden, const T *__restrict__ embed, int H, int vocab,
                                                    T *__restrict__ fc_in, int32_t *__restrict__ relpos) {
     __shared__ int s_ids[E2_K], s_src[E2_K];
     const int lane = threadIdx.x;
@@ -173,11 +342,8 @@ __global__ __launch_bounds__(256) void k_e2_select(E2State S, int level, const T
             bool taken = false;
             float sel_v = 0.f; int sel_i = 0;
             for (int round = 0; round < E2_K; round++) {
-                float bvv = taken ? -INFINITY : cu; int bii = taken ? 0x7fffffff : lane;
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(bvv, o); const int oi = __shfl_xor(bii, o);
-                    if (e2_before(ov, oi, bvv, bii)) { bvv = ov; bii = oi; }
-                }
+                float bvv; int bii;
+                e2_wave_best(taken ? -INFINITY : cu, taken ? 0x7fffffff : lane, bvv, bii);
                 if (bii == lane) taken = true;
                 if (lane == round) { sel_v = bvv; sel_i = bii; }
             }
@@ -198,18 +364,29 @@ __global__ __launch_bounds__(256) void k_e2_select(E2State S, int level, const T
     __syncthreads();
     // stage the fc projection's input rows: [embed[token] | parent hidden state]
     const int vec = H / 8;                                 // 16-byte units per half row
-    for (int u = threadIdx.x; u < E2_K * 2 * vec; u += blockDim.x) {
-        const int t = u / (2 * vec), c = u - t * 2 * vec;
-        int tok = s_ids[t]; tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-        const uint4 *src = c < vec ? reinterpret_cast<const uint4 *>(embed + (size_t)tok * H) + c
-                                   : reinterpret_cast<const uint4 *>(hidden + (size_t)s_src[t] * H) + (c - vec);
-        reinterpret_cast<uint4 *>(fc_in + (size_t)t * 2 * H)[c] = *src;
+    const int total = E2_K * 2 * vec;
+    for (int u0 = threadIdx.x; u0 < total; u0 += 8 * blockDim.x) {       // eight loads in flight per thread, then the stores
+        uint4 buf[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int u = u0 + k * blockDim.x;
+            if (u < total) {
+                const int t = u / (2 * vec), c = u - t * 2 * vec;
+                int tok = s_ids[t]; tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+                buf[k] = c < vec ? reinterpret_cast<const uint4 *>(embed + (size_t)tok * H)[c] : reinterpret_cast<const uint4 *>(hidden + (size_t)s_src[t] * H)[c - vec];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int u = u0 + k * blockDim.x;
+            if (u < total) { const int t = u / (2 * vec), c = u - t * 2 * vec; reinterpret_cast<uint4 *>(fc_in + (size_t)t * 2 * H)[c] = buf[k]; }
+        }
     }
 }
 
 // the best `keep` of the 8 + 64 depth candidates, in candidate order, with their parents (eagle2_model.py:893-913) ->
 // tokens [keep + 1] (root = sample token), parents [keep + 1] (-1 for the root)
-__global__ __launch_bounds__(256) void k_e2_finish(E2State S, int depth, int keep, const int64_t *__restrict__ sample_token, int32_t *__restrict__ out_tokens,
+__global__ __launch_bounds__(1024) void k_e2_finish(E2State S, int depth, int keep, const int64_t *__restrict__ sample_token, int32_t *__restrict__ out_tokens,
                                                    int32_t *__restrict__ out_parents) {
     __shared__ float sc[E2_CAND]; __shared__ int rank[E2_CAND]; __shared__ int kept[E2_CAND]; __shared__ int pos_of[E2_CAND];
     const int n = E2_K + E2_K * E2_K * depth;
@@ -260,10 +437,30 @@ __global__ __launch_bounds__(256) void k_sum_partials_bias(const float *__restri
 
 extern "C" {
 
-int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const samd_e2_state_t *st, void *stream) {
+int64_t samd_e2_rowstats_workspace(int64_t vocab) {
+    const int64_t n_split = (vocab + E2_SEG - 1) / E2_SEG;
+    return n_split > E2_MAXSPLIT ? 0 : (int64_t)E2_K * n_split * (2 + 2 * E2_K) * 4;
+}
+
+int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const samd_e2_state_t *st, void *d_workspace,
+                     int64_t workspace_bytes, void *stream) {
     if (!d_logits || !st || rows < 1 || rows > E2_K || vocab < E2_K || row_stride < vocab) { samd_set_error("samd_e2_rowstats: invalid argument"); return SAMD_E_INVALID; }
     static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
     hipStream_t s = (hipStream_t)stream;
+    const int64_t need = samd_e2_rowstats_workspace(vocab);
+    if (d_workspace && need > 0 && dtype != SAMD_F32) {
+        if (workspace_bytes < need) { samd_set_error("samd_e2_rowstats: workspace of %lld bytes, need %lld", (long long)workspace_bytes, (long long)need); return SAMD_E_INVALID; }
+        const int n_split = (int)((vocab + E2_SEG - 1) / E2_SEG);
+        float *part_ms = (float *)d_workspace, *part_v = part_ms + (size_t)E2_K * n_split * 2;
+        int *part_i = (int *)(part_v + (size_t)E2_K * n_split * E2_K);
+        const dim3 grid(rows, n_split);
+        if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_rowstats_part<_Float16>, grid, dim3(256), 0, s, (const _Float16 *)d_logits, (long long)vocab, (long long)row_stride, n_split, part_ms, part_v, part_i);
+        else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_rowstats_part<__bf16>, grid, dim3(256), 0, s, (const __bf16 *)d_logits, (long long)vocab, (long long)row_stride, n_split, part_ms, part_v, part_i);
+        else { samd_set_error("samd_e2_rowstats: bad dtype"); return SAMD_E_INVALID; }
+        hipLaunchKernelGGL(k_e2_rowstats_merge, dim3(rows), dim3(256), 0, s, n_split, (const float *)part_ms, (const float *)part_v, (const int *)part_i, S);
+        LAUNCHCHK();
+        return SAMD_OK;
+    }
     if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_rowstats<_Float16>, dim3(rows), dim3(1024), 0, s, (const _Float16 *)d_logits, (long long)vocab, (long long)row_stride, S);
     else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_rowstats<__bf16>, dim3(rows), dim3(1024), 0, s, (const __bf16 *)d_logits, (long long)vocab, (long long)row_stride, S);
     else if (dtype == SAMD_F32) hipLaunchKernelGGL(k_e2_rowstats<float>, dim3(rows), dim3(1024), 0, s, (const float *)d_logits, (long long)vocab, (long long)row_stride, S);
@@ -277,8 +474,8 @@ int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidde
     if (!st || level < -1 || level >= E2_MAXDEPTH || !d_hidden || !d_embed || !d_fc_in || hidden % 8 != 0 || vocab < 1) { samd_set_error("samd_e2_select: invalid argument"); return SAMD_E_INVALID; }
     static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(1), dim3(256), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(1), dim3(256), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(1), dim3(1024), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(1), dim3(1024), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos);
     else { samd_set_error("samd_e2_select: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
@@ -289,7 +486,7 @@ int samd_e2_finish(const samd_e2_state_t *st, int32_t depth, int32_t keep, const
         samd_set_error("samd_e2_finish: invalid argument"); return SAMD_E_INVALID;
     }
     static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
-    hipLaunchKernelGGL(k_e2_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, S, depth, keep, d_sample_token, d_tokens, d_parents);
+    hipLaunchKernelGGL(k_e2_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, S, depth, keep, d_sample_token, d_tokens, d_parents);
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -174,6 +174,8 @@ class DeviceHead:
                      rec_final_vals=torch.zeros(keep, dtype=f32, device=dev), rec_final_idx=torch.zeros(keep, dtype=i32, device=dev))
             st = samd_hip.E2State(**{k: v.data_ptr() for k, v in t.items()})
             out = (torch.zeros(keep + 1, dtype=i32, device=dev), torch.zeros(keep + 1, dtype=i32, device=dev))
+            nb = int(self._lib.samd_e2_rowstats_workspace(self.base.shape.vocab))
+            self._e2_ws = (torch.zeros(max(nb, 4) // 4, dtype=f32, device=dev), nb)      # split rowstats: partial (m, s) + candidates
             self._e2 = ((depth, keep), t, st, C.byref(st), out)
         return self._e2
 
@@ -199,17 +201,21 @@ class DeviceHead:
         part = self.fc_part.view(-1)[:sp * 16 * n_fc]
         dt = self._dt
         check = samd_hip.check
-        check(L.samd_e2_rowstats(samd_hip._ptr(last_logits), dt, 1, V, V, st_ref, st))
+        ws, ws_bytes = self._e2_ws
+        ws_ptr = samd_hip._ptr(ws) if ws_bytes else None
+        check(L.samd_e2_rowstats(samd_hip._ptr(last_logits), dt, 1, V, V, st_ref, ws_ptr, ws_bytes, st))
         check(L.samd_e2_select(st_ref, -1, samd_hip._ptr(last_hidden), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
                                samd_hip._ptr(self.relpos_buf), dt, st))
         self.n.fill_(8)
         b = self.runner._buffers(8)
+        torch.add(self.L, 0, out=self.Lw)                  # a first use warms the graph up: it must write tree rows, not accepted ones,
+        level_graph = self._level_graph()                  # and come BEFORE rows are staged (the forward transforms b["x"] in place)
         for i in range(depth):
             check(L.samd_gemm_skinny(samd_hip._ptr(self.fc_in), samd_hip._ptr(self.fc_packed), 16, n_fc, k_fc, sp, samd_hip._ptr(part), None, dt, st))
-            check(L.samd_sum_partials_bias(samd_hip._ptr(part), sp, 16 * n_fc, samd_hip._ptr(self.fc_b), samd_hip._ptr(self.x_buf), 8, n_fc, dt, st))
+            check(L.samd_sum_partials_bias(samd_hip._ptr(part), sp, 16 * n_fc, samd_hip._ptr(self.fc_b), samd_hip._ptr(b["x"]), 8, n_fc, dt, st))
             torch.add(self.L, 8 * i, out=self.Lw)
-            self._level_graph().replay()
-            check(L.samd_e2_rowstats(samd_hip._ptr(b["logits"]), dt, 8, V, b["logits"].stride(0), st_ref, st))
+            level_graph.replay()
+            check(L.samd_e2_rowstats(samd_hip._ptr(b["logits"]), dt, 8, V, b["logits"].stride(0), st_ref, ws_ptr, ws_bytes, st))
             check(L.samd_e2_select(st_ref, i, samd_hip._ptr(b["x"]), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
                                    samd_hip._ptr(self.relpos_buf), dt, st))
         self._keep_sample = input_ids[-1:].to(torch.long).contiguous()
@@ -226,16 +232,17 @@ class DeviceHead:
         return out[0].to(torch.long), out[1].to(torch.long)
 
     def _level_graph(self):
-        """hipGraph of one 8-row tree-level forward over the fixed buffers (x_buf, relpos_buf, mask_buf, Lw, n; visible prefix L)"""
-        g = self._graphs.get(("level", 8))
+        """hipGraph of one 8-row tree-level forward over the fixed buffers (the bucket's x, relpos_buf, mask_buf, Lw, n; visible prefix L)"""
+        g = self._graphs.get(("level-in-place", 8))
         if g is None:
-            run = lambda: self.runner.forward_rows(8, self.tok, self.relpos_buf, self.mask_buf, self.Lw, self.n, x_in=self.x_buf, d_vis=self.L)
+            b = self.runner._buffers(8)                           # the level's input rows are staged in the bucket's own x (no copy)
+            run = lambda: self.runner.forward_rows(8, self.tok, self.relpos_buf, self.mask_buf, self.Lw, self.n, x_in=b["x"], d_vis=self.L)
             run()
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 run()
-            self._graphs[("level", 8)] = g
+            self._graphs[("level-in-place", 8)] = g
         return g
 
     def expand(self, key, fn, *inputs):

@@ -284,7 +284,8 @@ class LlamaRunner:
             check(L.samd_embed_rows(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(b["x"]), R, s.hidden, s.vocab, dt, st))
         else:
             rows_in = min(R, x_in.shape[0])
-            b["x"][:rows_in].copy_(x_in[:rows_in])                # rows past d_n are never consumed
+            if x_in.data_ptr() != b["x"].data_ptr():              # a caller may stage the rows in the bucket's own buffer
+                b["x"][:rows_in].copy_(x_in[:rows_in])            # rows past d_n are never consumed
         head = getattr(self, "draft_head", False)
         block = self.attention == "block"
         if self.attention != "split3":
@@ -298,11 +299,10 @@ class LlamaRunner:
         packed = self.wp["layers"] if self.wp else [{}] * len(self.w["layers"])
         for li, w in enumerate(self.w["layers"]):
             wp = packed[li]
-            if head and li == 0:
-                b["h"][:R].copy_(b["x"][:R])                      # eagle2_model.py:516-519: no input layer-norm in the head's layer
-            else:
+            raw_in = head and li == 0                             # eagle2_model.py:516-519: no input layer-norm in the head's layer
+            if not raw_in:
                 check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
-            src, n_p, stride = gemm(b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
+            src, n_p, stride = gemm(b["x"] if raw_in else b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
             if block:
                 # RoPE + K row / V^T column write + tree attention + merge of the tile partials: one launch (csrc/attn_kernels.hip)
                 check(L.samd_attention_block(_ptr(src), n_p, stride, _ptr(b["cs"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R,
@@ -333,7 +333,8 @@ class LlamaRunner:
         check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
         # (for a draft head the call above only folds the last projection into the residual stream; its norm output is unused)
         gemm(b["x"] if head else b["h"], self.w["lm_head"], self.wp["lm_head"] if self.wp else None, b["logits"])
-        check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
+        if not head:                                              # a draft head's callers rank the logits themselves
+            check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
         return b
 
     # ------------------------------------------------------------------------------------------------

@@ -34,10 +34,13 @@ def draft():
     dh.reset()
     for _ in range(20):                       # a request: L grows to ~60 + 20 T
         dh.eagle2_draft(head, hs, ids)
-for mode in ("1", "0"):
+only = "--only-draft" in sys.argv                   # under rocprofv3: nothing but kernel-mode drafts after the set-up
+for mode in (("1",) if only else ("1", "0")):
     os.environ["SAMD_EAGLE_KERNELS"] = mode
     print(f"draft (T = {T}), tree-logic kernels = {mode}: {timed(draft, 5) / 20:.3f} ms", flush=True)
 os.environ["SAMD_EAGLE_KERNELS"] = "1"
+if only:
+    sys.exit(0)
 x8 = torch.randn((8, 4096), generator=g, device="cuda").to(dtype)
 pos, eye = dh.level_pos[0], torch.eye(8, device="cuda")
 from samd.tree_model.device_head import _mask_rows

@@ -31,13 +31,20 @@ def make_state(depth=5, keep=62):
     return t, st
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["split", "one-workgroup"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("vocab,rows", [(512, 8), (32000, 8), (128256, 8), (32000, 1), (1000, 3)])
-def test_rowstats_matches_log_softmax_topk(dtype, vocab, rows):
+@pytest.mark.parametrize("vocab,rows", [(512, 8), (32000, 8), (128256, 8), (32000, 1), (1000, 3), (4097, 2), (151936, 8)])
+def test_rowstats_matches_log_softmax_topk(dtype, vocab, rows, split):
     g = torch.Generator(device="cuda").manual_seed(vocab + rows)
     logits = (torch.randn((rows, vocab), generator=g, device="cuda") * 4).to(dtype)
+    if vocab == 4097:
+        logits[:, -1] = 30.0                                  # the best element sits alone in the last split
     t, st = make_state()
-    check(lib().samd_e2_rowstats(_ptr(logits), torch_dtype_code(dtype), rows, vocab, vocab, C.byref(st), current_stream()))
+    nbytes = lib().samd_e2_rowstats_workspace(vocab)
+    assert nbytes == 8 * ((vocab + 4095) // 4096) * 18 * 4
+    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda") if split else None
+    check(lib().samd_e2_rowstats(_ptr(logits), torch_dtype_code(dtype), rows, vocab, vocab, C.byref(st), _ptr(ws) if split else None, nbytes if split else 0,
+                                 current_stream()))
     torch.cuda.synchronize()
     logp = torch.log_softmax(logits.float(), dim=-1)
     # expected order: value descending, index ascending among equal values (half precision produces exact ties)
