@@ -352,6 +352,15 @@ int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t 
                      int64_t workspace_bytes, void *stream);
 int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidden, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in,
                    int32_t *d_rel_pos /* optional: [8] <- level + 1 */, int32_t dtype, void *stream);
+/* the accepted tokens of one verified step -> the draft head's extension forward, device to device (reference: the plugin's
+ * update() + the first forward of topk_genrate, S/tree_model/eagle2/eagle2.py:37-63, eagle2_model.py:835-846): row t < n_accepted of
+ * d_fc_in [n_accepted][2 hidden] <- [embed[acc_tokens[t + 1] or, for the last row, start_token[0]] | d_hidden_rows[kv_index[t]]]
+ * (kv_index -1 = row n_rows - 1, the reference's padding entry); d_rel_pos[t] = t, d_mask_rows[t] = causal chain, d_n[0] = n_accepted,
+ * d_sample_token[0] (optional) = start_token[0] widened for samd_e2_finish.
+ * d_kv_index / d_acc_tokens / d_start_token: the session's report block (samd_session_device_views). */
+int samd_e2_stage_extend(const void *d_hidden_rows, const int32_t *d_kv_index, const int32_t *d_acc_tokens, const int32_t *d_start_token, int32_t n_accepted,
+                         int32_t n_rows, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in, int32_t *d_rel_pos, uint64_t *d_mask_rows, int32_t *d_n,
+                         int64_t *d_sample_token, int32_t dtype, void *stream);
 int samd_e2_finish(const samd_e2_state_t *st, int32_t depth, int32_t keep, const int64_t *d_sample_token, int32_t *d_tokens, int32_t *d_parents, void *stream);
 int samd_sum_partials_bias(const float *d_part, int32_t n_partials, int64_t partial_stride, const void *d_bias, void *d_out, int32_t rows, int32_t N,
                            int32_t dtype, void *stream);

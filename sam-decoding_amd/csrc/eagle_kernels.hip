@@ -384,6 +384,48 @@ __global__ __launch_bounds__(1024) void k_e2_select(E2State S, int level, const 
     }
 }
 
+// The accepted tokens of one verified step enter the draft head without a host round trip (reference: the plugin's update() +
+// the first forward of topk_genrate, eagle2.py:37-63, eagle2_model.py:835-846): row t < T of the fc projection's input is
+// [embed[token after the t-th accepted token] | base-model hidden state of the t-th accepted token], where the tokens are the step's
+// accepted tokens (acc_tokens[1..T-1]) followed by the bonus token (start_token), and the hidden state is the verify forward's row
+// kv_index[t] (-1 = the padding entry of the reference's retrieve rows: the LAST draft row, SO/samd_model.py:144).  Also the causal
+// chain mask / relative positions of the T rows and n = T.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_e2_stage_extend(const T *__restrict__ hidden_rows, const int32_t *__restrict__ kv_index, const int32_t *__restrict__ acc_tokens,
+                                                          const int32_t *__restrict__ start_token, int n_acc, int n_rows, const T *__restrict__ embed, int H, int vocab,
+                                                          T *__restrict__ fc_in, int32_t *__restrict__ relpos, unsigned long long *__restrict__ mask_rows, int32_t *__restrict__ d_n,
+                                                          int64_t *__restrict__ sample_token) {
+    __shared__ int s_tok[64], s_row[64];
+    const int tid = threadIdx.x;
+    if (tid < n_acc) {
+        int tok = tid + 1 < n_acc ? acc_tokens[tid + 1] : start_token[0];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        int row = kv_index[tid]; row = row < 0 ? n_rows - 1 : row; row = row < 0 ? 0 : (row > 63 ? 63 : row);
+        s_tok[tid] = tok; s_row[tid] = row;
+        relpos[tid] = tid;
+        mask_rows[tid] = tid >= 63 ? ~0ull : ((1ull << (tid + 1)) - 1);
+    }
+    if (tid == 0) { d_n[0] = n_acc; if (sample_token) sample_token[0] = start_token[0]; }
+    __syncthreads();
+    const int vec = H / 8, total = n_acc * 2 * vec;
+    for (int u0 = tid; u0 < total; u0 += 8 * blockDim.x) {
+        uint4 buf[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int u = u0 + k * blockDim.x;
+            if (u < total) {
+                const int t = u / (2 * vec), c = u - t * 2 * vec;
+                buf[k] = c < vec ? reinterpret_cast<const uint4 *>(embed + (size_t)s_tok[t] * H)[c] : reinterpret_cast<const uint4 *>(hidden_rows + (size_t)s_row[t] * H)[c - vec];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int u = u0 + k * blockDim.x;
+            if (u < total) { const int t = u / (2 * vec), c = u - t * 2 * vec; reinterpret_cast<uint4 *>(fc_in + (size_t)t * 2 * H)[c] = buf[k]; }
+        }
+    }
+}
+
 // the best `keep` of the 8 + 64 depth candidates, in candidate order, with their parents (eagle2_model.py:893-913) ->
 // tokens [keep + 1] (root = sample token), parents [keep + 1] (-1 for the root)
 __global__ __launch_bounds__(1024) void k_e2_finish(E2State S, int depth, int keep, const int64_t *__restrict__ sample_token, int32_t *__restrict__ out_tokens,
@@ -477,6 +519,21 @@ int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidde
     if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(1), dim3(1024), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos);
     else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(1), dim3(1024), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos);
     else { samd_set_error("samd_e2_select: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_e2_stage_extend(const void *d_hidden_rows, const int32_t *d_kv_index, const int32_t *d_acc_tokens, const int32_t *d_start_token, int32_t n_accepted,
+                         int32_t n_rows, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in, int32_t *d_rel_pos, uint64_t *d_mask_rows, int32_t *d_n,
+                         int64_t *d_sample_token, int32_t dtype, void *stream) {
+    if (!d_hidden_rows || !d_kv_index || !d_acc_tokens || !d_start_token || n_accepted < 1 || n_accepted > 64 || n_rows < 1 || n_rows > 64 || !d_embed || hidden % 8 != 0 ||
+        vocab < 1 || !d_fc_in || !d_rel_pos || !d_mask_rows || !d_n) { samd_set_error("samd_e2_stage_extend: invalid argument"); return SAMD_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_stage_extend<_Float16>, dim3(1), dim3(1024), 0, s, (const _Float16 *)d_hidden_rows, d_kv_index, d_acc_tokens, d_start_token, n_accepted,
+                                              n_rows, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos, (unsigned long long *)d_mask_rows, d_n, d_sample_token);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_stage_extend<__bf16>, dim3(1), dim3(1024), 0, s, (const __bf16 *)d_hidden_rows, d_kv_index, d_acc_tokens, d_start_token, n_accepted,
+                                                    n_rows, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos, (unsigned long long *)d_mask_rows, d_n, d_sample_token);
+    else { samd_set_error("samd_e2_stage_extend: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -69,6 +69,7 @@ class DeviceHead:
         self.x_buf = torch.zeros((MAX_ROWS, head.hidden), dtype=dt, device=dev)
         self.mask_buf = torch.zeros(MAX_ROWS, dtype=torch.int64, device=dev)
         self._graphs = {}                                 # row bucket -> hipGraph of one head forward over the static buffers
+        self._step_plans = {}                             # row bucket -> resolved arguments of eagle2_draft_step's launches
         self._e2 = None                                   # EAGLE-2 tree-logic state (samd_e2_state_t), made on first use
         # stateful tree levels (EAGLE-2): write position of the current level, per-level relative positions
         self.Lw = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -192,10 +193,73 @@ class DeviceHead:
         if head.top_k != 8 or depth > 7 or self.fc_packed is None or os.environ.get("SAMD_EAGLE_KERNELS", "1") == "0":
             last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
             return head._expand_levels(self, last_hidden, last_logits, input_ids[-1:].clone())
+        last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
+        self._keep_sample = input_ids[-1:].to(torch.long).contiguous()
+        return self._e2_levels(head, samd_hip._ptr(last_hidden), samd_hip._ptr(last_logits), self._keep_sample)
+
+    def eagle2_draft_step(self, head, hidden_rows, views, n_accepted, n_rows):
+        """eagle2_draft for the accepted tokens of ONE verified step, read where the step left them on the device: hidden_rows
+        [R, H] = the verify forward's last hidden states, views = the session's report block (kv_index / acc_tokens / start_token
+        pointers), n_accepted = the step's accepted tokens (host copy of the verdict), n_rows = the verified draft's size.
+        samd_e2_stage_extend builds the fc input rows, chain mask, positions and n; fc + bias land in the row bucket's own x; the
+        extension forward replays its in-place hipGraph: 5 launches + a replay where the general path issues ~25 PyTorch ops and
+        two host-to-device copies.  Same arithmetic as extend() + eagle2_draft()."""
+        import samd_hip
+        T = int(n_accepted)
+        R = self.runner.bucket(T)
+        plan = self._step_plans.get(R)
+        if plan is None:                                       # everything that does not depend on the step, resolved once per row bucket
+            L, dt, _ptr = self._lib, self._dt, samd_hip._ptr
+            b = self.runner._buffers(R)
+            g = self._extend_graph(R)                          # before rows are staged (first use warms up in place)
+            if getattr(self, "_sample64", None) is None:
+                self._sample64 = torch.zeros(1, dtype=torch.long, device=self.embed.device)
+            rp = b["rows_pad"]
+            n_fc, k_fc = self.fc_w.shape
+            sp = max(2, min(8, L.samd_gemm_splits(n_fc, k_fc, rp), k_fc // 256))
+            part = self.fc_part.view(-1)[:sp * rp * n_fc]
+            H = self.embed.shape[1]
+            plan = self._step_plans[R] = dict(
+                g=g, H=H, esz=b["x"].element_size(), x=b["x"].data_ptr(), logits=b["logits"].data_ptr(), lstride=b["logits"].stride(0),
+                stage_tail=(_ptr(self.embed), H, self.embed.shape[0], _ptr(self.fc_in), _ptr(self.relpos_buf), _ptr(self.mask_buf), _ptr(self.n), _ptr(self._sample64), dt),
+                gemm=(_ptr(self.fc_in), _ptr(self.fc_packed), rp, n_fc, k_fc, sp, _ptr(part), None, dt),
+                bias=(_ptr(part), sp, rp * n_fc, _ptr(self.fc_b), _ptr(b["x"])), n_fc=n_fc)
+        L, st, check, _ptr = self._lib, samd_hip.current_stream(), samd_hip.check, samd_hip._ptr
+        check(L.samd_e2_stage_extend(_ptr(hidden_rows), _ptr(views["kv_index"]), _ptr(views["acc_tokens"]), _ptr(views["start_token"]), T, int(n_rows), *plan["stage_tail"], st))
+        check(L.samd_gemm_skinny(*plan["gemm"], st))
+        check(L.samd_sum_partials_bias(*plan["bias"], T, plan["n_fc"], self._dt, st))
+        plan["g"].replay()
+        self.length += T
+        self.L.add_(T)
+        H, esz = plan["H"], plan["esz"]
+        return self._e2_levels(head, plan["x"] + (T - 1) * H * esz, plan["logits"] + (T - 1) * plan["lstride"] * esz, self._sample64)
+
+    def fast_step_ok(self, head, n_accepted):
+        return (head.top_k == 8 and head.depth <= 7 and self.fc_packed is not None and self.fc_b is not None and 1 <= n_accepted <= MAX_ROWS
+                and os.environ.get("SAMD_EAGLE_KERNELS", "1") != "0" and os.environ.get("SAMD_EAGLE_FAST_STEP", "1") != "0")
+
+    def _extend_graph(self, R):
+        """hipGraph of one causal extension forward over R rows staged in the bucket's own x (relpos_buf, mask_buf, L, n)"""
+        g = self._graphs.get(("extend-in-place", R))
+        if g is None:
+            b = self.runner._buffers(R)
+            run = lambda: self.runner.forward_rows(R, self.tok, self.relpos_buf, self.mask_buf, self.L, self.n, x_in=b["x"])
+            self.n.fill_(1)                                    # the warm-up run writes one row at L (overwritten by the real one)
+            run()
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            self._graphs[("extend-in-place", R)] = g
+        return g
+
+    def _e2_levels(self, head, p_last_hidden, p_last_logits, sample64):
+        """the tree levels + re-rank after the extension: p_last_* = device addresses of the last accepted row's output state / logits"""
+        import samd_hip
+        depth, keep = head.depth, head.total_tokens
         L, st = self._lib, samd_hip.current_stream()
         _, t, _st, st_ref, out = self._e2_state(depth, keep)
-        last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
-        H, V = self.embed.shape[1], last_logits.shape[-1]
+        H, V = self.embed.shape[1], self.base.shape.vocab
         n_fc, k_fc = self.fc_w.shape
         sp = max(2, min(8, L.samd_gemm_splits(n_fc, k_fc, 16), k_fc // 256))
         part = self.fc_part.view(-1)[:sp * 16 * n_fc]
@@ -203,13 +267,13 @@ class DeviceHead:
         check = samd_hip.check
         ws, ws_bytes = self._e2_ws
         ws_ptr = samd_hip._ptr(ws) if ws_bytes else None
-        check(L.samd_e2_rowstats(samd_hip._ptr(last_logits), dt, 1, V, V, st_ref, ws_ptr, ws_bytes, st))
-        check(L.samd_e2_select(st_ref, -1, samd_hip._ptr(last_hidden), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
+        torch.add(self.L, 0, out=self.Lw)                  # a first use warms the graph up: it must write tree rows, not accepted ones,
+        level_graph = self._level_graph()                  # and come BEFORE rows are staged (the forward transforms b["x"] in place)
+        check(L.samd_e2_rowstats(samd_hip._ptr(p_last_logits), dt, 1, V, V, st_ref, ws_ptr, ws_bytes, st))
+        check(L.samd_e2_select(st_ref, -1, samd_hip._ptr(p_last_hidden), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
                                samd_hip._ptr(self.relpos_buf), dt, st))
         self.n.fill_(8)
         b = self.runner._buffers(8)
-        torch.add(self.L, 0, out=self.Lw)                  # a first use warms the graph up: it must write tree rows, not accepted ones,
-        level_graph = self._level_graph()                  # and come BEFORE rows are staged (the forward transforms b["x"] in place)
         for i in range(depth):
             check(L.samd_gemm_skinny(samd_hip._ptr(self.fc_in), samd_hip._ptr(self.fc_packed), 16, n_fc, k_fc, sp, samd_hip._ptr(part), None, dt, st))
             check(L.samd_sum_partials_bias(samd_hip._ptr(part), sp, 16 * n_fc, samd_hip._ptr(self.fc_b), samd_hip._ptr(b["x"]), 8, n_fc, dt, st))
@@ -218,8 +282,7 @@ class DeviceHead:
             check(L.samd_e2_rowstats(samd_hip._ptr(b["logits"]), dt, 8, V, b["logits"].stride(0), st_ref, ws_ptr, ws_bytes, st))
             check(L.samd_e2_select(st_ref, i, samd_hip._ptr(b["x"]), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
                                    samd_hip._ptr(self.relpos_buf), dt, st))
-        self._keep_sample = input_ids[-1:].to(torch.long).contiguous()
-        check(L.samd_e2_finish(st_ref, depth, keep, samd_hip._ptr(self._keep_sample), samd_hip._ptr(out[0]), samd_hip._ptr(out[1]), st))
+        check(L.samd_e2_finish(st_ref, depth, keep, samd_hip._ptr(sample64), samd_hip._ptr(out[0]), samd_hip._ptr(out[1]), st))
         if head.trace is not None:                         # every top-k decision in the reference's order (parity tests)
             torch.cuda.current_stream().synchronize()
             tv, ti = t["rec_top_vals"].view(1 + depth, 8, 8).cpu(), t["rec_top_idx"].view(1 + depth, 8, 8).cpu().long()

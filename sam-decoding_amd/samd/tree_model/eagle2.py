@@ -292,6 +292,15 @@ class Eagle2(TreeModel):
             return self.model.topk_generate_device(self.device_head, hs, ids)
         return self.model.topk_generate(hs, ids, self.lm_head.to(self.model.dtype))
 
+    def gen_draft_from_step(self, hidden_rows, views, n_accepted, n_rows):
+        """update() + gen_draft_device() for the accepted tokens of one verified step that are still on the device (the engine's
+        report block `views`, the verify forward's hidden rows): no host-to-device copies, no PyTorch staging ops.  None when
+        the fast path does not apply (accumulated tokens of earlier steps pending, no device head, unusual head shape)."""
+        dh = self.device_head
+        if dh is None or self.accept_tokens is not None or not dh.fast_step_ok(self.model, n_accepted):
+            return None
+        return dh.eagle2_draft_step(self.model, hidden_rows, views, n_accepted, n_rows)
+
     def gen_draft(self, start_token: int):
         """eagle2.py:52-63 -> (tokens, buffers_kwargs); the buffers come from the tree-buffer kernel."""
         from samd_sam_only.sam.static_sam import gen_buffers

@@ -266,9 +266,18 @@ class TreeModelEngine(DecodeEngine):
             start_token = self.session.read_draft().tokens[0]
         start = torch.tensor([start_token], dtype=torch.long, device=self.device)
         tokens, parents = self.tm.gen_draft_device(start)
+        return self._install(rep, tokens, parents)
+
+    def _install(self, rep, tokens, parents):
+        """install the plugin's draft (tokens + parent array; the tree-buffer kernel derives mask, positions, retrieve rows).  The
+        host knows everything the caller reads from the report afterwards -- the draft is a tree of tokens.numel() nodes -- so it
+        does not synchronise again (SAMD_TREE_REPORT_SYNC=1: read the report back, as round 1 did)."""
         self._keep = (tokens.to(torch.int32).contiguous(), parents.to(torch.int32).contiguous())
         self.session.set_draft(self._keep[0], self._keep[1], int(tokens.numel()), type_=1)
-        return self._report()
+        if os.environ.get("SAMD_TREE_REPORT_SYNC", "0") == "1":
+            return self._report()
+        rep.type, rep.n, rep.n_leaves, rep.max_depth = 1, int(tokens.numel()), -1, -1
+        return rep
 
     def start(self, input_ids):
         s = self.session
@@ -292,6 +301,13 @@ class TreeModelEngine(DecodeEngine):
             g.replay()
         torch.cuda.current_stream().synchronize()
         rep = StepReport(self._report_np)
+        fast = getattr(self.tm, "gen_draft_from_step", None)
+        if rep.type == 2 and fast is not None:
+            # the plugin drafts next and nothing is pending: the accepted tokens, their verify rows and the bonus token are read
+            # where the step left them on the device; the installed draft's size is known, so the host does not wait for it
+            out = fast(self.verifier.hidden_rows(R), self._views, rep.accept, n_next)
+            if out is not None:
+                return self._install(rep, *out)
         rows = [k if k >= 0 else n_next - 1 for k in rep.kv_index]       # -1 padding selects the last tree node (SO/samd_model.py:144)
         hs = self.verifier.hidden_rows(R)[torch.tensor(rows, dtype=torch.long, device=self.device)]
         self.tm.update(tokens=torch.tensor(rep.tokens, dtype=torch.long, device=self.device), last_hidden_states=hs)

@@ -80,3 +80,35 @@ def test_expansion_kernels_match_the_pytorch_loop():
     for a, b in zip(outs["1"], outs["0"]):
         assert a == b
         assert a[1][0] == -1 and all(0 <= a[1][i] < i for i in range(1, len(a[1])))
+
+
+def test_step_fast_path_matches_the_general_path():
+    """eagle2_draft_step (accepted tokens, verify rows and bonus token read from device arrays: samd_e2_stage_extend + in-place
+    extension graph) gives the same draft as update() + eagle2_draft() fed with host-gathered tensors, call after call -- also for
+    -1 entries of kv_index (the reference's padding: the last draft row) and for more than 8 accepted tokens (16-row bucket)."""
+    from test_gpu_eagle_golden import device_head_for
+    from samd.tree_model.eagle2 import Eagle2Head
+    seed = 335
+    head_a, _, dh_a = device_head_for(seed, Eagle2Head)
+    head_b, _, dh_b = device_head_for(seed, Eagle2Head)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    H = dh_a.embed.shape[1]
+    dh_a.reset(); dh_b.reset()
+    # the first call of a request carries the whole prompt: general path on both heads
+    hs0 = torch.randn((21, H), generator=g, device="cuda").half(); ids0 = torch.randint(3, 512, (22,), generator=g, device="cuda")
+    assert [x.tolist() for x in dh_a.eagle2_draft(head_a, hs0, ids0)] == [x.tolist() for x in dh_b.eagle2_draft(head_b, hs0, ids0)]
+    for T, n_rows in [(1, 61), (3, 61), (7, 61), (13, 20), (2, 9), (1, 1)]:
+        rows = torch.randn((64, H), generator=g, device="cuda").half()                    # the verify forward's hidden rows (bucket buffer)
+        kv = torch.randint(0, n_rows, (64,), generator=g, device="cuda", dtype=torch.int32)
+        if T > 1:
+            kv[T - 1] = -1
+        acc = torch.randint(3, 512, (64,), generator=g, device="cuda", dtype=torch.int32)
+        start = torch.randint(3, 512, (1,), generator=g, device="cuda", dtype=torch.int32)
+        views = dict(kv_index=kv.data_ptr(), acc_tokens=acc.data_ptr(), start_token=start.data_ptr())
+        assert dh_b.fast_step_ok(head_b, T)
+        got = dh_b.eagle2_draft_step(head_b, rows, views, T, n_rows)
+        idx = torch.where(kv[:T] < 0, torch.full_like(kv[:T], n_rows - 1), kv[:T]).long()
+        want = dh_a.eagle2_draft(head_a, rows[idx], torch.cat((acc[:T].long(), start.long())))
+        torch.cuda.synchronize()
+        assert got[0].tolist() == want[0].tolist() and got[1].tolist() == want[1].tolist(), (T, n_rows)
+        assert dh_a.length == dh_b.length and int(dh_b.L.item()) == dh_b.length
