@@ -333,7 +333,7 @@ int samd_kv_compact_indices_vt(void *const *d_tensors, int32_t n_tensors, int32_
  * S/tree_model/eagle2/eagle2_model.py:848-913 the level loop, :893-913 the re-rank).  samd_e2_state_t holds device pointers to small
  * caller-allocated arrays (k = 8 = top_k, depth <= 7):
  *   row_lse f32[8], top_logp f32[8][8], top_idx i32[8][8]     -- samd_e2_rowstats: per row log-sum-exp and top-k (log-prob, token)
- *   scores f32[8], cs_index i32[8], mask_rows u64[64], row_src i32[8], ids i32[8]   -- the current level's rows (samd_e2_select)
+ *   scores f32[16] (two level parities), cs_index i32[8], mask_rows u64[64], row_src i32[8], ids i32[8]   -- the current level's rows (samd_e2_select)
  *   all_scores f32[8 + 64 depth], all_tokens i32[same], parents_list i32[1 + 8 depth]   -- the reference's scores_list / ss_token / parents_list
  *   rec_top_vals/idx [1 + depth][8][8], rec_best_vals/idx [depth][8], rec_final_vals/idx [keep]   -- every top-k decision, in the reference's order
  * samd_e2_select(level = -1) installs the root's 8 candidates as level 0's rows; level >= 0 picks the 8 rows of level + 1 from the

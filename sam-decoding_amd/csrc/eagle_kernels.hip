@@ -18,13 +18,14 @@
 #define E2_K 8
 #define E2_MAXDEPTH 7
 #define E2_CAND (E2_K + E2_K * E2_K * E2_MAXDEPTH)      // candidates of all levels
+#define E2_SELECT_WGS 16                                // workgroups of k_e2_select (staging of the fc input rows)
 
 // device state of one expansion (all arrays persistent; include/samd_hip.h samd_e2_state_t mirrors this)
 struct E2State {
     float *row_lse;          // [8]
     float *top_logp;         // [8][8]  log-probabilities of the row's top-k
     int32_t *top_idx;        // [8][8]  their token ids
-    float *scores;           // [8]     cumulative score of the current level's rows
+    float *scores;           // [2][8]  cumulative score of the current level's rows, double-buffered by level parity
     int32_t *cs_index;       // [8]     flat index (row * 8 + rank) of the rows chosen for the current level, in the previous level's candidates
     float *all_scores;       // [E2_CAND]
     int32_t *all_tokens;     // [E2_CAND]
@@ -62,6 +63,12 @@ __device__ __forceinline__ int e2_wave_min(int x) {                 // non-negat
     E2_STEP(0x111, 0xf); E2_STEP(0x112, 0xf); E2_STEP(0x114, 0xf); E2_STEP(0x118, 0xf); E2_STEP(0x142, 0xa); E2_STEP(0x143, 0xc);
 #undef E2_STEP
     return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ float e2_wave_sum(float x) {
+#define E2_STEP(CTRL, MASK) x += __builtin_bit_cast(float, e2_dpp<CTRL, MASK>(0, __builtin_bit_cast(int, x)))
+    E2_STEP(0x111, 0xf); E2_STEP(0x112, 0xf); E2_STEP(0x114, 0xf); E2_STEP(0x118, 0xf); E2_STEP(0x142, 0xa); E2_STEP(0x143, 0xc);
+#undef E2_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 // the wave's best (value desc, index asc) of one (v, i) per lane; i = 0x7fffffff marks "nothing"
 __device__ __forceinline__ void e2_wave_best(float v, int i, float &out_v, int &out_i) {
@@ -167,36 +174,47 @@ __global__ __launch_bounds__(1024) void k_e2_rowstats(const T *__restrict__ logi
 #define E2_EPT 16                       // elements per thread (256 threads)
 #define E2_MAXSPLIT 64
 
-// 8 rounds of block arg-max over per-thread element lists held in registers (N per thread); the holder of the winner removes it
-// and rescans its list.  Every thread ends up with the 8 winners in res_v / res_i (registers: a store to global memory inside the
-// loop would make every round's barrier wait for it -- 2.3 us per round, measured).  256 threads; sv / si = 8 LDS slots each.
+// The best 8 of a 256-thread workgroup's elements (N per thread, in registers), (value desc, index asc), left in res_v / res_i of
+// wave 0.  Every wave first finds ITS best 8 without a barrier: 8 rounds of wave arg-max over the lanes' current best; a lane keeps
+// its best and second best, so the winner usually just promotes its second (a rescan of its N elements, run by one lane while 63
+// wait, only when it wins again: scripts/probes/top8_probe.hip -- the rescan was 60 % of a round, the block barrier + LDS exchange
+// of a block-wide round another 25 %).  Then one barrier and wave 0 merges the 4 x 8 candidates, one per lane.
 template <int N>
 __device__ __forceinline__ void e2_block_top8(float (&v)[N], int (&id)[N], float (&res_v)[E2_K], int (&res_i)[E2_K], float *sv, int *si) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float bv = -INFINITY; int bi = 0x7fffffff;
+    float b1v, b2v; int b1i, b2i;
+    auto scan = [&]() {
+        b1v = b2v = -INFINITY; b1i = b2i = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < N; q++) if (e2_before(v[q], id[q], bv, bi)) { bv = v[q]; bi = id[q]; }
-#pragma unroll
+        for (int q = 0; q < N; q++) {
+            if (e2_before(v[q], id[q], b1v, b1i)) { b2v = b1v; b2i = b1i; b1v = v[q]; b1i = id[q]; }
+            else if (e2_before(v[q], id[q], b2v, b2i)) { b2v = v[q]; b2i = id[q]; }
+        }
+    };
+    scan();
+    bool have2 = true;
+#pragma unroll 1
     for (int round = 0; round < E2_K; round++) {
         float wv; int wi;
-        e2_wave_best(bv, bi, wv, wi);
-        const int slot = (round & 1) * 4;
-        if (lane == 0) { sv[slot + wave] = wv; si[slot + wave] = wi; }
-        __syncthreads();
-        float gv = sv[slot]; int gi = si[slot];
+        e2_wave_best(b1v, b1i, wv, wi);
+        if (lane == 0) { sv[wave * E2_K + round] = wv; si[wave * E2_K + round] = wi; }
+        if (b1i == wi && wi != 0x7fffffff) {               // indices are unique: this lane holds the winner
 #pragma unroll
-        for (int k = 1; k < 4; k++) {
-            const float ov = sv[slot + k]; const int oi = si[slot + k];
-            if (e2_before(ov, oi, gv, gi)) { gv = ov; gi = oi; }
+            for (int q = 0; q < N; q++) if (id[q] == wi) { v[q] = -INFINITY; id[q] = 0x7fffffff; }
+            if (have2) { b1v = b2v; b1i = b2i; have2 = false; }
+            else { scan(); have2 = true; }
         }
-        res_v[round] = gv; res_i[round] = gi;
-        if (bi == gi && gi != 0x7fffffff) {                // indices are unique: this thread holds the winner
-            bv = -INFINITY; bi = 0x7fffffff;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float cv = lane < 4 * E2_K ? sv[lane] : -INFINITY; int ci = lane < 4 * E2_K ? si[lane] : 0x7fffffff;
+        if (ci == 0x7fffffff) cv = -INFINITY;
 #pragma unroll
-            for (int q = 0; q < N; q++) {
-                if (id[q] == gi) { v[q] = -INFINITY; id[q] = 0x7fffffff; }
-                if (e2_before(v[q], id[q], bv, bi)) { bv = v[q]; bi = id[q]; }
-            }
+        for (int round = 0; round < E2_K; round++) {
+            float wv; int wi;
+            e2_wave_best(cv, ci, wv, wi);
+            res_v[round] = wv; res_i[round] = wi;
+            if (ci == wi) { cv = -INFINITY; ci = 0x7fffffff; }
         }
     }
 }
@@ -242,13 +260,12 @@ __global__ __launch_bounds__(256) void k_e2_rowstats_part(const T *__restrict__ 
     for (int q = 0; q < E2_EPT; q++) m = fmaxf(m, v[q]);
 #pragma unroll
     for (int q = 0; q < E2_EPT; q++) if (v[q] != -INFINITY) s += __expf(v[q] - m);
-    for (int o = 32; o > 0; o >>= 1) {
-        const float om = __shfl_xor(m, o), os = __shfl_xor(s, o);
-        const float M = fmaxf(m, om);
-        s = (m == -INFINITY ? 0.f : s * __expf(m - M)) + (om == -INFINITY ? 0.f : os * __expf(om - M));
+    {
+        const float M = e2_wave_max(m);
+        s = e2_wave_sum(m == -INFINITY ? 0.f : s * __expf(m - M));
         m = M;
     }
-    __shared__ float wm[4], ws[4], sv[8]; __shared__ int si[8];
+    __shared__ float wm[4], ws[4], sv[4 * E2_K]; __shared__ int si[4 * E2_K];
     if (lane == 0) { wm[wave] = m; ws[wave] = s; }
     __syncthreads();
     if (tid == 0) {
@@ -268,19 +285,13 @@ __global__ __launch_bounds__(256) void k_e2_rowstats_part(const T *__restrict__ 
 __global__ __launch_bounds__(256) void k_e2_rowstats_merge(int n_split, const float *__restrict__ part_ms, const float *__restrict__ part_v,
                                                            const int *__restrict__ part_i, E2State S) {
     const int row = blockIdx.x, tid = threadIdx.x;
-    __shared__ float sv[8], s_lse; __shared__ int si[8];
-    if (tid < 64) {                                           // log-sum-exp over the splits, in split order
-        float m = tid < n_split ? part_ms[((size_t)row * n_split + tid) * 2] : -INFINITY;
-        float M = m;
-        for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
-        if (tid == 0) {
-            float acc = 0.f;
-            for (int k = 0; k < n_split; k++) {
-                const float mk = part_ms[((size_t)row * n_split + k) * 2];
-                if (mk != -INFINITY) acc += part_ms[((size_t)row * n_split + k) * 2 + 1] * __expf(mk - M);
-            }
-            s_lse = M + logf(acc);
-        }
+    __shared__ float sv[4 * E2_K], s_lse; __shared__ int si[4 * E2_K];
+    if (tid < 64) {                                           // log-sum-exp over the splits: one split per lane
+        const float mk = tid < n_split ? part_ms[((size_t)row * n_split + tid) * 2] : -INFINITY;
+        const float sk = tid < n_split ? part_ms[((size_t)row * n_split + tid) * 2 + 1] : 0.f;
+        const float M = e2_wave_max(mk);
+        const float acc = e2_wave_sum(mk == -INFINITY ? 0.f : sk * __expf(mk - M));
+        if (tid == 0) s_lse = M + logf(acc);
     }
     float v[2]; int id[2];
     const int n_cand = n_split * E2_K;
@@ -309,35 +320,43 @@ __global__ __launch_bounds__(256) void k_e2_rowstats_merge(int n_split, const fl
 // hidden [rows][H] = the previous forward's output states (row r of the level, or the single last accepted row for the root);
 // fc_in [8][2H] <- [embed[ids[t]] | hidden[row_src[t]]]; mask_rows <- ancestor bits of the new rows.
 template <typename T>
-__global__ __launch_bounds__(1024) void k_e2_select(E2State S, int level, const T *__restrict__ hidden, const T *__restrict__ embed, int H, int vocab,
+__global__ __launch_bounds__(256) void k_e2_select(E2State S, int level, const T *__restrict__ hidden, const T *__restrict__ embed, int H, int vocab,
                                                    T *__restrict__ fc_in, int32_t *__restrict__ relpos) {
+    // Every workgroup repeats the (cheap) tree logic in its wavefront 0 and then stages its share of the fc input rows; only
+    // workgroup 0 commits the state.  The one input the commit overwrites -- the rows' cumulative scores -- is double-buffered by
+    // level parity (scores[0..7] / scores[8..15]), so the other workgroups never read what workgroup 0 is writing.
     __shared__ int s_ids[E2_K], s_src[E2_K];
     const int lane = threadIdx.x;
+    const bool commit = blockIdx.x == 0;
+    const float *scores_r = S.scores + E2_K * (level & 1);
+    float *scores_w = S.scores + E2_K * ((level + 1) & 1);
     if (lane < 64) {                                      // wavefront 0 does the tree logic in lockstep (no block barrier inside)
         if (level < 0) {
-            if (lane < E2_K) {
+            if (lane < E2_K) { s_ids[lane] = S.top_idx[lane]; s_src[lane] = 0; }
+            if (lane < E2_K && commit) {
                 const float sc = S.top_logp[lane];
                 const int tok = S.top_idx[lane];
-                S.scores[lane] = sc; S.cs_index[lane] = lane;
+                scores_w[lane] = sc; S.cs_index[lane] = lane;
                 S.all_scores[lane] = sc; S.all_tokens[lane] = tok;
                 S.rec_top_vals[lane] = sc; S.rec_top_idx[lane] = tok;
                 S.ids[lane] = tok; S.row_src[lane] = 0;
                 S.mask_rows[lane] = 1ull << lane;
-                s_ids[lane] = tok; s_src[lane] = 0;
                 if (lane == 0) S.parents_list[0] = 0;
             }
         } else {
             // every lane reads the old state first (registers), the commit below comes later in program order of the same wave
             const int r = lane >> 3;
-            const float cu = S.top_logp[lane] + S.scores[r];
+            const float cu = S.top_logp[lane] + scores_r[r];
             const int my_tok = S.top_idx[lane];
-            const int old_cs = S.cs_index[lane & 7];
-            const unsigned long long prev_mask = S.mask_rows[lane & 7];
+            const int old_cs = commit ? S.cs_index[lane & 7] : 0;
+            const unsigned long long prev_mask = commit ? S.mask_rows[lane & 7] : 0ull;
             const int base = E2_K + E2_K * E2_K * level;
-            S.all_scores[base + lane] = cu; S.all_tokens[base + lane] = my_tok;
-            S.rec_top_vals[(1 + level) * 64 + lane] = S.top_logp[lane]; S.rec_top_idx[(1 + level) * 64 + lane] = my_tok;
-            // parents of this level's rows in the reference's numbering (eagle2_model.py:866-870)
-            if (lane < E2_K) S.parents_list[1 + E2_K * level + lane] = old_cs + 1 + E2_K * E2_K * (level > 0 ? level - 1 : 0) + (level > 0 ? E2_K : 0);
+            if (commit) {
+                S.all_scores[base + lane] = cu; S.all_tokens[base + lane] = my_tok;
+                S.rec_top_vals[(1 + level) * 64 + lane] = S.top_logp[lane]; S.rec_top_idx[(1 + level) * 64 + lane] = my_tok;
+                // parents of this level's rows in the reference's numbering (eagle2_model.py:866-870)
+                if (lane < E2_K) S.parents_list[1 + E2_K * level + lane] = old_cs + 1 + E2_K * E2_K * (level > 0 ? level - 1 : 0) + (level > 0 ? E2_K : 0);
+            }
             // top-8 of the 64 cumulative scores (value desc, flat index asc)
             bool taken = false;
             float sel_v = 0.f; int sel_i = 0;
@@ -351,25 +370,25 @@ __global__ __launch_bounds__(1024) void k_e2_select(E2State S, int level, const 
             const int sel_c = lane < E2_K ? sel_i : 0;
             const int tok = __shfl(my_tok, sel_c);
             const unsigned long long pm = __shfl(prev_mask, sel_c >> 3);
-            if (lane < E2_K) {
+            if (lane < E2_K) { s_ids[lane] = tok; s_src[lane] = sel_i >> 3; }
+            if (lane < E2_K && commit) {
                 const int src = sel_i >> 3;
                 S.rec_best_vals[level * E2_K + lane] = sel_v; S.rec_best_idx[level * E2_K + lane] = sel_i;
-                S.scores[lane] = sel_v; S.cs_index[lane] = sel_i; S.ids[lane] = tok; S.row_src[lane] = src;
+                scores_w[lane] = sel_v; S.cs_index[lane] = sel_i; S.ids[lane] = tok; S.row_src[lane] = src;
                 S.mask_rows[lane] = pm | (1ull << (E2_K * (level + 1) + lane));
-                s_ids[lane] = tok; s_src[lane] = src;
             }
         }
     }
-    if (relpos && lane < E2_K) relpos[lane] = level + 1;      // depth of the new rows (position = accepted length + depth)
+    if (relpos && lane < E2_K && commit) relpos[lane] = level + 1;      // depth of the new rows (position = accepted length + depth)
     __syncthreads();
     // stage the fc projection's input rows: [embed[token] | parent hidden state]
     const int vec = H / 8;                                 // 16-byte units per half row
-    const int total = E2_K * 2 * vec;
-    for (int u0 = threadIdx.x; u0 < total; u0 += 8 * blockDim.x) {       // eight loads in flight per thread, then the stores
+    const int total = E2_K * 2 * vec, nthr = blockDim.x * gridDim.x;
+    for (int u0 = blockIdx.x * blockDim.x + threadIdx.x; u0 < total; u0 += 8 * nthr) {       // eight loads in flight per thread, then the stores
         uint4 buf[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int u = u0 + k * blockDim.x;
+            const int u = u0 + k * nthr;
             if (u < total) {
                 const int t = u / (2 * vec), c = u - t * 2 * vec;
                 int tok = s_ids[t]; tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
@@ -378,7 +397,7 @@ __global__ __launch_bounds__(1024) void k_e2_select(E2State S, int level, const 
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const int u = u0 + k * blockDim.x;
+            const int u = u0 + k * nthr;
             if (u < total) { const int t = u / (2 * vec), c = u - t * 2 * vec; reinterpret_cast<uint4 *>(fc_in + (size_t)t * 2 * H)[c] = buf[k]; }
         }
     }
@@ -516,8 +535,8 @@ int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidde
     if (!st || level < -1 || level >= E2_MAXDEPTH || !d_hidden || !d_embed || !d_fc_in || hidden % 8 != 0 || vocab < 1) { samd_set_error("samd_e2_select: invalid argument"); return SAMD_E_INVALID; }
     static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(1), dim3(1024), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(1), dim3(1024), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(E2_SELECT_WGS), dim3(256), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(E2_SELECT_WGS), dim3(256), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos);
     else { samd_set_error("samd_e2_select: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;

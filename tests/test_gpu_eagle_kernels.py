@@ -20,7 +20,7 @@ def make_state(depth=5, keep=62):
     dev, f32, i32 = "cuda", torch.float32, torch.int32
     n_cand = 8 + 64 * depth
     t = dict(row_lse=torch.zeros(8, dtype=f32, device=dev), top_logp=torch.zeros(64, dtype=f32, device=dev), top_idx=torch.zeros(64, dtype=i32, device=dev),
-             scores=torch.zeros(8, dtype=f32, device=dev), cs_index=torch.zeros(8, dtype=i32, device=dev),
+             scores=torch.zeros(16, dtype=f32, device=dev), cs_index=torch.zeros(8, dtype=i32, device=dev),
              all_scores=torch.zeros(n_cand, dtype=f32, device=dev), all_tokens=torch.zeros(n_cand, dtype=i32, device=dev),
              parents_list=torch.zeros(1 + 8 * depth, dtype=i32, device=dev), mask_rows=torch.zeros(64, dtype=torch.int64, device=dev),
              row_src=torch.zeros(8, dtype=i32, device=dev), ids=torch.zeros(8, dtype=i32, device=dev),
