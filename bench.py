@@ -155,16 +155,16 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
                 frac_of_request_ceiling=round(gbps / (HBM_REQUESTS_PER_S * 16 / 1e9), 4)), toks
 
 
-def lm_roofline(runner, iters=10):
+def lm_roofline(runner, iters=10, rows=16):
     """the kernel that takes most of the step: k_gemm_skinny, the weight stream of the verify forward.  All projections of
-    all layers at the 16-row tile (layer l's matrices are 400 MB apart from layer l+1's: nothing is re-read from a cache),
+    all layers at the `rows`-row tile (layer l's matrices are 400 MB apart from layer l+1's: nothing is re-read from a cache),
     replayed as one hipGraph and timed with HIP events; algorithmic bytes = the weight bytes (2 B x N x K per projection)."""
     import torch
     import samd_hip
     from samd_hip import _ptr, check, current_stream
     if runner.wp is None or not runner.fused_mlp or any(v is None for l in runner.wp["layers"] for v in l.values()):
         return None
-    L, s, b = samd_hip.lib(), runner.shape, runner._buffers(16)
+    L, s, b = samd_hip.lib(), runner.shape, runner._buffers(rows)
     RP, part, dt = b["rows_pad"], b["part"], runner.dt
     attn2d = b["attn"].view(b["attn"].shape[0], -1)
     nbytes = [0]
@@ -192,11 +192,11 @@ def lm_roofline(runner, iters=10):
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "gemm_pmc.json")))
-        if pmc["config"]["weight_bytes_per_layer"] * len(runner.w["layers"]) == nbytes[0]:
+        if rows == 16 and pmc["config"]["weight_bytes_per_layer"] * len(runner.w["layers"]) == nbytes[0]:
             traffic = int((pmc["fetch_bytes_per_layer"] * pmc["fetch_size_correction"] + pmc["write_bytes_per_layer"]) / 4)
     except (OSError, KeyError, ValueError):
         pass
-    return dict(bound="hbm", kernel="k_gemm_skinny (16-row tile; q/k/v, o, gate|up + SiLU, down of every layer)", achieved=round(gbps, 1),
+    return dict(bound="hbm", kernel=f"k_gemm_skinny ({rows}-row tile; q/k/v, o, gate|up + SiLU, down of every layer)", achieved=round(gbps, 1),
                 peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBPS, 4), traffic=traffic, launch_ms=round(ms / launches, 5),
                 launches_per_forward=launches, alg_bytes_per_launch=int(nbytes[0] / launches), forward_gemm_ms=round(ms, 4))
 
@@ -599,7 +599,7 @@ def main():
                 for m in (2.30, 3.03, 4.62)} if "16" in breakdown and "64" in breakdown else None,
             # `roofline` = the SAM traversal kernel (the one BASELINE.json's north star asks to be priced against HBM peak);
             # `roofline_lm` = the kernel that takes most of a step's time, priced the same way
-            "roofline": roof, "roofline_lm": lm_roofline(runner), "cpu_baseline": cpu,
+            "roofline": roof, "roofline_lm": lm_roofline(runner), "roofline_lm_rows64": lm_roofline(runner, rows=64), "cpu_baseline": cpu,
             "setup": {"static_build_s": round(build_s, 2), "host": f"{os.cpu_count()} cores"},
         }
         print(json.dumps(out), flush=True)
