@@ -258,6 +258,17 @@ int samd_session_step(samd_session_t *s, const samd_static_t *sam, const samd_pa
  * start+idx[j] -> start+j (j < accept), then cache_length += accept.  d_tensors: device array of
  * n_tensors base pointers, each [n_heads][max_len][head_dim] of `elem_bytes`-byte elements.
  * start / idx / accept are read from the session (device side); is_tree==0 (sequence) skips the copy. */
+/* eval_posterior's sampling branch on the device (SO/utils.py:142-184).  d_probs [n_candidates * depth][vocab] (f16 / bf16 / f32) =
+ * softmax of the WARPED logits of every (candidate row, position) -- the caller applies SamdGenerationConfig.logits_processor to the
+ * whole batch on the device; d_candidates int64 [n_candidates][depth] (-1 padded); d_uniforms double [n_uniforms] = the next values
+ * of the host's random.random() stream, in order: THE RNG CONTRACT -- the k-th uniform examined in a step is the k-th value the
+ * reference would have drawn (one per distinct token tried, utils.py:165); d_out[2] says how many were consumed, and the caller
+ * restores its generator and advances it by exactly that count.  d_work [vocab] (dtype of d_probs) = scratch; when d_out[3] == 1 it
+ * holds the renormalised residual distribution the reference returns as sample_p (utils.py:176-177), otherwise sample_p is the
+ * softmax of the RAW logits of (row d_out[0], position d_out[1] - 1).  d_out int32[5] = {best row, accept length, uniforms consumed,
+ * residual flag, status (1 = ran out of uniforms)}.  Rounding follows torch on tensors of the same dtype. */
+int samd_posterior_sampled(const void *d_probs, int32_t dtype, const int64_t *d_candidates, int32_t n_candidates, int32_t depth, int64_t vocab,
+                           const double *d_uniforms, int32_t n_uniforms, void *d_work, int32_t *d_out, void *stream);
 int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len,
                     int32_t head_dim, int32_t elem_bytes, void *stream);
 

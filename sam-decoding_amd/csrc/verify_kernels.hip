@@ -762,6 +762,98 @@ __global__ __launch_bounds__(64) void k_recycle_draft(const int *__restrict__ ta
 // ================================================================================================
 // C ABI
 // ================================================================================================
+
+// ---- eval_posterior, sampling branch (reference: samd_sam_only/utils.py:142-184) ---------------------------------------------
+// The reference walks the candidate rows depth by depth on the host: at depth i the rows that still carry the accepted prefix
+// offer their distinct next tokens in row order; token x is accepted with probability p(x) under the warped distribution of the
+// accepted node (one host random.random() per examined token, utils.py:165); a rejection zeroes p(x) and renormalises
+// (gtp = gtp / gtp.sum(), in the logits' dtype).  Here: probs [C * D][V] = softmax of the warped logits of every (row, position)
+// (the caller runs HF's warpers over the whole batch on the device), uniforms = the next values of the host's random stream
+// in order; one workgroup does the walk -- thread 0 the scalar trie logic, all threads the renormalisation -- and reports
+// out = {best row, accept length, uniforms consumed, 1 when `work` holds the residual distribution the reference returns as
+// sample_p (utils.py:176-177), status (1 = ran out of uniforms)}.  Rounding follows torch on a tensor of dtype T: the sum is
+// accumulated in fp32 and rounded to T, every quotient is rounded to T, r is compared in T.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_posterior_sampled(const T *__restrict__ probs, const long long *__restrict__ cand, int C, int D, long long V,
+                                                            const double *__restrict__ uniforms, int n_uniforms, T *__restrict__ work, int *__restrict__ out) {
+    __shared__ long long prefix[64];
+    __shared__ int seen[1024];
+    __shared__ int s_action, s_tok, s_row, s_anchor;
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    int n_acc = 1, best = 0, k = 0, adjusted = 0, status = 0;
+    if (tid == 0) prefix[0] = cand[0];
+    __syncthreads();
+    while (n_acc < D && !status) {
+        adjusted = 0;
+        // the first row that carries the accepted prefix: its (row, n_acc - 1) distribution is the accepted node's
+        if (tid == 0) {
+            int a = -1;
+            for (int j = 0; j < C && a < 0; j++) {
+                bool eq = true;
+                for (int q = 0; q < n_acc; q++) eq = eq && cand[(size_t)j * D + q] == prefix[q];
+                if (eq) a = j;
+            }
+            s_anchor = a;
+        }
+        __syncthreads();
+        const int anchor = s_anchor;
+        if (anchor < 0) break;
+        const T *src = probs + ((size_t)anchor * D + (n_acc - 1)) * V;
+        for (long long i = tid; i < V; i += blockDim.x) work[i] = src[i];
+        __syncthreads();
+        int n_seen = 0, row = 0;
+        bool grown = false;
+        while (true) {
+            if (tid == 0) {                                  // next row that offers a token not tried at this depth
+                int action = 0, tok = -1, hit = -1;
+                while (row < C) {
+                    const int j = row++;
+                    bool eq = true;
+                    for (int q = 0; q < n_acc; q++) eq = eq && cand[(size_t)j * D + q] == prefix[q];
+                    if (!eq) continue;
+                    const long long x = cand[(size_t)j * D + n_acc];
+                    if (x < 0) continue;                     // -1 = padding of a shorter candidate (utils.py:162)
+                    bool dup = false;
+                    for (int q = 0; q < n_seen && q < 1024; q++) dup = dup || seen[q] == (int)x;
+                    if (dup) continue;
+                    if (n_seen < 1024) seen[n_seen] = (int)x;
+                    n_seen++;
+                    if (k >= n_uniforms) { action = 3; break; }
+                    const T r = (T)(float)uniforms[k++];     // torch compares the host scalar in the tensor's dtype
+                    tok = (int)x; hit = j;
+                    action = (float)r <= (float)work[tok] ? 1 : 2;
+                    if (action == 1) prefix[n_acc] = x;
+                    break;
+                }
+                s_action = action; s_tok = tok; s_row = hit;
+            }
+            __syncthreads();
+            const int action = s_action, tok = s_tok;
+            if (action == 0) break;                          // no more rows at this depth
+            if (action == 3) { status = 1; break; }
+            if (action == 1) { best = s_row; n_acc++; grown = true; break; }
+            // rejected: zero the token's mass and renormalise
+            if (tid == 0) work[tok] = (T)0.f;
+            __syncthreads();
+            float acc = 0.f;
+            for (long long i = tid; i < V; i += blockDim.x) acc += (float)work[i];
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();
+            float tot = 0.f;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) tot += red[w];
+            const float denom = (float)(T)tot;
+            for (long long i = tid; i < V; i += blockDim.x) work[i] = (T)((float)work[i] / denom);
+            adjusted = 1;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (!grown) break;
+    }
+    if (tid == 0) { out[0] = best; out[1] = n_acc; out[2] = k; out[3] = (adjusted && n_acc != D) ? 1 : 0; out[4] = status; }
+}
+
 extern "C" {
 
 int samd_argmax_rows(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const int32_t *d_rows,
@@ -796,6 +888,23 @@ static int kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tenso
                               (long long)max_len, row_bytes, 0, 0, n_tensors - n_transposed);
     else hipLaunchKernelGGL(k_kv_compact, dim3(n_tensors * n_heads), dim3(256), lds, (hipStream_t)stream, d_tensors, (const int *)nullptr, d_indices, n_heads,
                             (long long)max_len, row_bytes, start, accept, n_tensors - n_transposed);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_posterior_sampled(const void *d_probs, int32_t dtype, const int64_t *d_candidates, int32_t n_candidates, int32_t depth, int64_t vocab,
+                           const double *d_uniforms, int32_t n_uniforms, void *d_work, int32_t *d_out, void *stream) {
+    if (!d_probs || !d_candidates || n_candidates < 1 || depth < 1 || depth > 64 || vocab < 1 || !d_uniforms || n_uniforms < 0 || !d_work || !d_out) {
+        samd_set_error("samd_posterior_sampled: invalid argument (depth <= 64)"); return SAMD_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAMD_F32) hipLaunchKernelGGL(k_posterior_sampled<float>, dim3(1), dim3(1024), 0, st, (const float *)d_probs, (const long long *)d_candidates, n_candidates, depth,
+                                              (long long)vocab, d_uniforms, n_uniforms, (float *)d_work, d_out);
+    else if (dtype == SAMD_F16) hipLaunchKernelGGL(k_posterior_sampled<_Float16>, dim3(1), dim3(1024), 0, st, (const _Float16 *)d_probs, (const long long *)d_candidates, n_candidates,
+                                                   depth, (long long)vocab, d_uniforms, n_uniforms, (_Float16 *)d_work, d_out);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_posterior_sampled<__bf16>, dim3(1), dim3(1024), 0, st, (const __bf16 *)d_probs, (const long long *)d_candidates, n_candidates,
+                                                    depth, (long long)vocab, d_uniforms, n_uniforms, (__bf16 *)d_work, d_out);
+    else { samd_set_error("samd_posterior_sampled: bad dtype"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
 }

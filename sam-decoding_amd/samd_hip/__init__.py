@@ -115,6 +115,7 @@ _PROTOS = {
     "samd_rope_kv_write_vt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
     "samd_kv_compact_vt": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
     "samd_kv_compact_indices_vt": (C.c_int, [_VP, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _VP, _I32, _VP]),
+    "samd_posterior_sampled": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, _VP, _I32, _VP, _VP, _VP]),
     "samd_e2_rowstats_workspace": (C.c_int64, [_I64]),
     "samd_e2_stage_extend": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "samd_e2_rowstats": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _I64, _VP]),

@@ -95,6 +95,41 @@ def _sampled(logits, candidates, config):
     return torch.tensor(best, dtype=torch.long, device=dev), torch.tensor(n_acc, dtype=torch.long, device=dev), sample_p.view(1, -1)
 
 
+def _sampled_device(logits, candidates, config):
+    """the same walk in ONE kernel (samd_posterior_sampled) and one host round trip, where the reference issues a device
+    synchronisation per examined token (`x.item()`, `r <= acp` on a device scalar): HF's warpers and the softmax run over all
+    (row, position) logits at once on the device; the kernel consumes uniforms in the reference's order.  RNG contract: the k-th
+    uniform a step examines is the k-th value `random.random()` would have returned -- a block of values is drawn under a saved
+    generator state, the kernel reports how many it used, the state is restored and advanced by exactly that many, so the host
+    stream stays where the reference's would be."""
+    import numpy as np
+    C_, D, V = candidates.shape[0], candidates.shape[1], logits.shape[-1]
+    rows = logits.reshape(C_ * D, V)
+    probs = torch.softmax(config.logits_processor(None, rows), dim=-1).contiguous()
+    cand = candidates.to(torch.long).contiguous()
+    n_u = C_ + D + 8                                          # at most one uniform per distinct token tried: <= rows, + slack
+    state = random.getstate()
+    u = torch.from_numpy(np.asarray([random.random() for _ in range(n_u)], dtype=np.float64)).to(logits.device)
+    work = torch.empty(V, dtype=probs.dtype, device=logits.device)
+    out = torch.zeros(5, dtype=torch.int32, device=logits.device)
+    samd_hip.check(samd_hip.lib().samd_posterior_sampled(samd_hip._ptr(probs), samd_hip.torch_dtype_code(probs.dtype), samd_hip._ptr(cand), C_, D, V,
+                                                         samd_hip._ptr(u), n_u, samd_hip._ptr(work), samd_hip._ptr(out), samd_hip.current_stream()))
+    best, n_acc, used, residual, status = out.tolist()
+    random.setstate(state)
+    for _ in range(used):
+        random.random()
+    if status:
+        raise samd_hip.SamdError("samd_posterior_sampled ran out of uniforms")
+    sample_p = work if residual else torch.softmax(logits[best, n_acc - 1], dim=0)
+    dev = candidates.device
+    return torch.tensor(best, dtype=torch.long, device=dev), torch.tensor(n_acc, dtype=torch.long, device=dev), sample_p.view(1, -1)
+
+
 def eval_posterior(logits: torch.Tensor, candidates: torch.Tensor, config):
-    """logits [C, depth, V], candidates [C, depth] -> (best_candidate, accept_length, next sample_p [1, V])."""
-    return _greedy(logits, candidates) if config.greedy else _sampled(logits, candidates, config)
+    """logits [C, depth, V], candidates [C, depth] -> (best_candidate, accept_length, next sample_p [1, V]).  Sampling on device
+    tensors runs in the library's kernel; on host tensors (tools, fixtures) in the plain restatement above."""
+    if config.greedy:
+        return _greedy(logits, candidates)
+    if logits.is_cuda and candidates.shape[1] <= 64 and logits.dtype in (torch.float16, torch.bfloat16, torch.float32):
+        return _sampled_device(logits, candidates, config)
+    return _sampled(logits, candidates, config)

@@ -115,9 +115,11 @@ def test_chat_session_streams_through_the_engine():
 
 
 def test_sampling_posterior_on_device_tensors_matches_reference(golden):
-    """the sampling branch with logits and candidates on the GPU: same host `random` stream (the reference's RNG contract,
-    utils.py:160-168: one random.random() per examined position) -> same accepted prefix and candidate; residual distribution
-    within 1e-5 of the recorded fp32 one (device softmax)."""
+    """the sampling branch in the library's kernel (samd_posterior_sampled) against the recorded reference: same host `random`
+    stream (the RNG contract: the k-th uniform a step examines is the k-th value random.random() would have returned, one per
+    distinct token tried, utils.py:165) -> same accepted prefix and candidate, residual distribution within 1e-5 of the recorded
+    fp32 one (device softmax / sum order), and the host generator ends exactly where the reference's loop leaves it."""
+    from samd_sam_only import posterior
     from samd_sam_only.utils import SamdGenerationConfig, eval_posterior
     for case in golden("posterior_sampling.json.gz"):
         cfg = SamdGenerationConfig(greedy=False, temperature=case["temperature"], top_p=case["top_p"], top_k=case["top_k"])
@@ -125,5 +127,50 @@ def test_sampling_posterior_on_device_tensors_matches_reference(golden):
         cand = torch.tensor(case["candidates"], device="cuda")
         random.seed(case["seed"])
         best, acc, sp = eval_posterior(logits, cand, cfg)
+        after_device = random.random()
         assert (int(best), int(acc)) == (case["best"], case["accept"])
         assert sp.is_cuda and np.allclose(sp.view(-1).cpu().numpy(), np.asarray(case["sample_p"], dtype=np.float32), atol=1e-5)
+        random.seed(case["seed"])
+        posterior._sampled(logits.cpu(), cand.cpu(), cfg)                     # the plain restatement of the reference's loop
+        assert random.random() == after_device
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sampling_posterior_kernel_follows_the_loop_in_half_precision(dtype):
+    """random candidate tries over half-precision logits (what a real model hands over): the kernel and the reference's loop
+    (restated in samd_sam_only.posterior._sampled, run on the same device tensors) take the same decisions, leave the host
+    generator at the same place and return the same distribution up to one rounding of the dtype."""
+    from samd_sam_only import posterior
+    from samd_sam_only.utils import SamdGenerationConfig
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rng = np.random.default_rng(5)
+    V = 2000
+    for trial in range(12):
+        C, D = int(rng.integers(1, 9)), int(rng.integers(2, 7))
+        cand = torch.full((C, D), -1, dtype=torch.long)
+        cand[:, 0] = 7
+        for j in range(C):
+            depth = int(rng.integers(2, D + 1))
+            cand[j, 1:depth] = torch.from_numpy(rng.integers(3, 12, depth - 1))
+        cand = cand.cuda()
+        # logits peaked on small token ids so that candidates are accepted and rejected in turn
+        logits = torch.randn((C, D, V), generator=g, device="cuda") * 2
+        logits[..., 3:12] += 6
+        # rows with the same prefix must carry the same logits (they are the same tree node)
+        for j in range(C):
+            for i in range(D):
+                for j0 in range(j):
+                    if torch.equal(cand[j0, :i + 1], cand[j, :i + 1]):
+                        logits[j, i] = logits[j0, i]
+                        break
+        logits = logits.to(dtype)
+        cfg = SamdGenerationConfig(greedy=False, temperature=float(rng.choice([0.7, 1.0])), top_p=float(rng.choice([0.0, 0.9])), top_k=int(rng.choice([0, 40])))
+        random.seed(100 + trial)
+        b0, a0, p0 = posterior._sampled(logits, cand, cfg)
+        r0 = random.random()
+        random.seed(100 + trial)
+        b1, a1, p1 = posterior._sampled_device(logits, cand, cfg)
+        r1 = random.random()
+        assert (int(b0), int(a0), r0) == (int(b1), int(a1), r1), trial
+        tol = 2.0 ** (-9 if dtype == torch.float16 else -6)
+        assert (p0.float() - p1.float()).abs().max().item() <= tol * max(1e-3, p0.float().max().item())
