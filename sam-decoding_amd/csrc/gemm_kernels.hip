@@ -16,7 +16,9 @@
 //     buffers; the weights go HBM -> VGPR -> MFMA with TWO chunks in flight (see the pipeline comment in the kernel);
 //   * one balanced wave of workgroups per launch (samd_gemm_splits); split-K partial sums are written as fp32 and added up
 //     by the consuming kernel (rmsnorm + residual, rope), so a split costs no extra launch.
-// Measured and dropped: a 16-row variant that stages the whole A slice once (159 vs 141 us per layer), nontemporal loads,
+//   * the weight loads carry the nt (non-temporal) policy bit: -10 % on every projection launch (round 2; an earlier test through
+//     __builtin_nontemporal_load on the pre-asm kernel had shown nothing);
+// Measured and dropped: a 16-row variant that stages the whole A slice once (159 vs 141 us per layer),
 // 16-wave workgroups, an intra-workgroup K split, an Infinity-Cache warmer on a side stream, producers of A inside the launch
 // (DESIGN.md, K7).  Ablation: with the MFMAs and the LDS traffic compiled out the kernel is 3 % faster -- it runs at what
 // separate launches of 33-180 MB can stream (4.1-5.9 TB/s incl. ramp-up and tail).
@@ -85,8 +87,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 || DEPTH > 2 ? 2 : GEMM_WA
     auto load_wb = [&](u32x4 (&dst)[4][2], int c, int b) {
         const char *p = wtile + (size_t)c * 65536;                   // wave-uniform -> SGPR base, one offset VGPR
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 8192 * (2 * b + j)) : "memory");
+        for (int j = 0; j < 2; j++)        // nt: every weight byte is read once, by one CU -- streamed past the caches (13.7 vs 15.1 us, 30.1 vs 33.3)
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 8192 * (2 * b + j)) : "memory");
     };
     auto stage_xi = [&](int c, int buf, int i) {   // asynchronous: lands in LDS, counted by vmcnt
         const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
@@ -194,7 +196,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 || DEPTH > 2 ? 2 : GEMM_WA
         for (int r = 0; r < 4; r++) {
             const int m = 16 * mt + 4 * g + r;
             if (out) out[(size_t)m * N + n0 + n] = (E)acc[mt][r];
-            else partial[((size_t)split * R + m) * N + n0 + n] = acc[mt][r];
+            // write-through (sc1) stores: the fp32 partials leave the L2 while the launch still streams, instead of as dirty lines the
+            // kernel boundary has to flush (64 rows: 46 MB per layer; 3.93 -> 3.89 ms per step, neutral at 16 rows)
+            else __hip_atomic_store(&partial[((size_t)split * R + m) * N + n0 + n], acc[mt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
