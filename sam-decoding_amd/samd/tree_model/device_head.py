@@ -270,18 +270,17 @@ class DeviceHead:
         torch.add(self.L, 0, out=self.Lw)                  # a first use warms the graph up: it must write tree rows, not accepted ones,
         level_graph = self._level_graph()                  # and come BEFORE rows are staged (the forward transforms b["x"] in place)
         check(L.samd_e2_rowstats(samd_hip._ptr(p_last_logits), dt, 1, V, V, st_ref, ws_ptr, ws_bytes, st))
+        pL, pLw, pn = samd_hip._ptr(self.L), samd_hip._ptr(self.Lw), samd_hip._ptr(self.n)
         check(L.samd_e2_select(st_ref, -1, samd_hip._ptr(p_last_hidden), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
-                               samd_hip._ptr(self.relpos_buf), dt, st))
-        self.n.fill_(8)
+                               samd_hip._ptr(self.relpos_buf), pL, pLw, pn, dt, st))      # also Lw <- L (level 0's rows) and n <- 8
         b = self.runner._buffers(8)
         for i in range(depth):
             check(L.samd_gemm_skinny(samd_hip._ptr(self.fc_in), samd_hip._ptr(self.fc_packed), 16, n_fc, k_fc, sp, samd_hip._ptr(part), None, dt, st))
             check(L.samd_sum_partials_bias(samd_hip._ptr(part), sp, 16 * n_fc, samd_hip._ptr(self.fc_b), samd_hip._ptr(b["x"]), 8, n_fc, dt, st))
-            torch.add(self.L, 8 * i, out=self.Lw)
             level_graph.replay()
             check(L.samd_e2_rowstats(samd_hip._ptr(b["logits"]), dt, 8, V, b["logits"].stride(0), st_ref, ws_ptr, ws_bytes, st))
             check(L.samd_e2_select(st_ref, i, samd_hip._ptr(b["x"]), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
-                                   samd_hip._ptr(self.relpos_buf), dt, st))
+                                   samd_hip._ptr(self.relpos_buf), pL, pLw, pn, dt, st))   # Lw <- L + 8 (i + 1)
         check(L.samd_e2_finish(st_ref, depth, keep, samd_hip._ptr(sample64), samd_hip._ptr(out[0]), samd_hip._ptr(out[1]), st))
         if head.trace is not None:                         # every top-k decision in the reference's order (parity tests)
             torch.cuda.current_stream().synchronize()
