@@ -107,7 +107,7 @@ def _sampled_device(logits, candidates, config):
     rows = logits.reshape(C_ * D, V)
     probs = torch.softmax(config.logits_processor(None, rows), dim=-1).contiguous()
     cand = candidates.to(torch.long).contiguous()
-    n_u = C_ + D + 8                                          # at most one uniform per distinct token tried: <= rows, + slack
+    n_u = C_ * D + 8                                          # one uniform per distinct (depth, token) tried: never more than the cells
     state = random.getstate()
     u = torch.from_numpy(np.asarray([random.random() for _ in range(n_u)], dtype=np.float64)).to(logits.device)
     work = torch.empty(V, dtype=probs.dtype, device=logits.device)
