@@ -362,8 +362,9 @@ int64_t samd_e2_rowstats_workspace(int64_t vocab);
 int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t vocab, int64_t row_stride, const samd_e2_state_t *st, void *d_workspace,
                      int64_t workspace_bytes, void *stream);
 int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidden, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in,
-                   int32_t *d_rel_pos /* optional: [8] <- level + 1 */, const int32_t *d_L, int32_t *d_Lw /* optional pair: Lw <- L + 8 (level + 1), the
-                   cache row of the new level */, int32_t *d_n /* optional: <- 8 */, int32_t dtype, void *stream);
+                   int32_t *d_rel_pos /* optional: [8] <- level + 1 */, int32_t *d_L, int32_t *d_Lw /* optional pair: L += advance_L (the accepted
+                   tokens the extension forward just wrote), Lw <- L + 8 (level + 1) = the cache row of the new level */, int32_t *d_n /* optional: <- 8 */,
+                   int32_t advance_L, int32_t dtype, void *stream);
 /* the accepted tokens of one verified step -> the draft head's extension forward, device to device (reference: the plugin's
  * update() + the first forward of topk_genrate, S/tree_model/eagle2/eagle2.py:37-63, eagle2_model.py:835-846): row t < n_accepted of
  * d_fc_in [n_accepted][2 hidden] <- [embed[acc_tokens[t + 1] or, for the last row, start_token[0]] | d_hidden_rows[kv_index[t]]]

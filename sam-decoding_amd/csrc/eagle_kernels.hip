@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256) void k_e2_rowstats_merge(int n_split, const fl
 // fc_in [8][2H] <- [embed[ids[t]] | hidden[row_src[t]]]; mask_rows <- ancestor bits of the new rows.
 template <typename T>
 __global__ __launch_bounds__(256) void k_e2_select(E2State S, int level, const T *__restrict__ hidden, const T *__restrict__ embed, int H, int vocab,
-                                                   T *__restrict__ fc_in, int32_t *__restrict__ relpos, const int32_t *__restrict__ d_L, int32_t *__restrict__ d_Lw,
-                                                   int32_t *__restrict__ d_n) {
+                                                   T *__restrict__ fc_in, int32_t *__restrict__ relpos, int32_t *__restrict__ d_L, int32_t *__restrict__ d_Lw,
+                                                   int32_t *__restrict__ d_n, int advance_L) {
     // Every workgroup repeats the (cheap) tree logic in its wavefront 0 and then stages its share of the fc input rows; only
     // workgroup 0 commits the state.  The one input the commit overwrites -- the rows' cumulative scores -- is double-buffered by
     // level parity (scores[0..7] / scores[8..15]), so the other workgroups never read what workgroup 0 is writing.
@@ -382,7 +382,11 @@ __global__ __launch_bounds__(256) void k_e2_select(E2State S, int level, const T
     }
     if (relpos && lane < E2_K && commit) relpos[lane] = level + 1;      // depth of the new rows (position = accepted length + depth)
     if (commit && lane == 0) {                             // where the new level's K / V rows go: behind the earlier levels' rows
-        if (d_L && d_Lw) d_Lw[0] = d_L[0] + E2_K * (level + 1);
+        if (d_L && d_Lw) {
+            const int L = d_L[0] + advance_L;              // advance_L: the accepted tokens the extension forward just wrote (level -1)
+            if (advance_L) d_L[0] = L;
+            d_Lw[0] = L + E2_K * (level + 1);
+        }
         if (d_n) d_n[0] = E2_K;
     }
     __syncthreads();
@@ -536,12 +540,14 @@ int samd_e2_rowstats(const void *d_logits, int32_t dtype, int32_t rows, int64_t 
 }
 
 int samd_e2_select(const samd_e2_state_t *st, int32_t level, const void *d_hidden, const void *d_embed, int32_t hidden, int32_t vocab, void *d_fc_in,
-                   int32_t *d_rel_pos, const int32_t *d_L, int32_t *d_Lw, int32_t *d_n, int32_t dtype, void *stream) {
-    if (!st || level < -1 || level >= E2_MAXDEPTH || !d_hidden || !d_embed || !d_fc_in || hidden % 8 != 0 || vocab < 1) { samd_set_error("samd_e2_select: invalid argument"); return SAMD_E_INVALID; }
+                   int32_t *d_rel_pos, int32_t *d_L, int32_t *d_Lw, int32_t *d_n, int32_t advance_L, int32_t dtype, void *stream) {
+    if (!st || level < -1 || level >= E2_MAXDEPTH || !d_hidden || !d_embed || !d_fc_in || hidden % 8 != 0 || vocab < 1 || advance_L < 0 || (advance_L && (!d_L || !d_Lw))) {
+        samd_set_error("samd_e2_select: invalid argument"); return SAMD_E_INVALID;
+    }
     static_assert(sizeof(E2State) == sizeof(samd_e2_state_t), "samd_e2_state_t layout"); E2State S; memcpy((void *)&S, (const void *)st, sizeof(S));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(E2_SELECT_WGS), dim3(256), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos, d_L, d_Lw, d_n);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(E2_SELECT_WGS), dim3(256), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos, d_L, d_Lw, d_n);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_e2_select<_Float16>, dim3(E2_SELECT_WGS), dim3(256), 0, s, S, level, (const _Float16 *)d_hidden, (const _Float16 *)d_embed, hidden, vocab, (_Float16 *)d_fc_in, d_rel_pos, d_L, d_Lw, d_n, advance_L);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_e2_select<__bf16>, dim3(E2_SELECT_WGS), dim3(256), 0, s, S, level, (const __bf16 *)d_hidden, (const __bf16 *)d_embed, hidden, vocab, (__bf16 *)d_fc_in, d_rel_pos, d_L, d_Lw, d_n, advance_L);
     else { samd_set_error("samd_e2_select: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;

@@ -195,7 +195,8 @@ class DeviceHead:
             return head._expand_levels(self, last_hidden, last_logits, input_ids[-1:].clone())
         last_hidden, last_logits = self.extend(hidden_states, input_ids[1:])
         self._keep_sample = input_ids[-1:].to(torch.long).contiguous()
-        return self._e2_levels(head, samd_hip._ptr(last_hidden), samd_hip._ptr(last_logits), self._keep_sample)
+        tokens, parents = self._e2_levels(head, samd_hip._ptr(last_hidden), samd_hip._ptr(last_logits), self._keep_sample)
+        return tokens.to(torch.long), parents.to(torch.long)
 
     def eagle2_draft_step(self, head, hidden_rows, views, n_accepted, n_rows):
         """eagle2_draft for the accepted tokens of ONE verified step, read where the step left them on the device: hidden_rows
@@ -230,9 +231,10 @@ class DeviceHead:
         check(L.samd_sum_partials_bias(*plan["bias"], T, plan["n_fc"], self._dt, st))
         plan["g"].replay()
         self.length += T
-        self.L.add_(T)
         H, esz = plan["H"], plan["esz"]
-        return self._e2_levels(head, plan["x"] + (T - 1) * H * esz, plan["logits"] + (T - 1) * plan["lstride"] * esz, self._sample64)
+        # no PyTorch op on this path (a tiny one costs the host ~36 us here, scripts/host_launch_cost.py): L += T happens inside the
+        # root's select launch, the outputs stay int32 (what the engine installs)
+        return self._e2_levels(head, plan["x"] + (T - 1) * H * esz, plan["logits"] + (T - 1) * plan["lstride"] * esz, self._sample64, advance_L=T)
 
     def fast_step_ok(self, head, n_accepted):
         return (head.top_k == 8 and head.depth <= 7 and self.fc_packed is not None and self.fc_b is not None and 1 <= n_accepted <= MAX_ROWS
@@ -253,8 +255,10 @@ class DeviceHead:
             self._graphs[("extend-in-place", R)] = g
         return g
 
-    def _e2_levels(self, head, p_last_hidden, p_last_logits, sample64):
-        """the tree levels + re-rank after the extension: p_last_* = device addresses of the last accepted row's output state / logits"""
+    def _e2_levels(self, head, p_last_hidden, p_last_logits, sample64, advance_L=0):
+        """the tree levels + re-rank after the extension: p_last_* = device addresses of the last accepted row's output state / logits;
+        advance_L: accepted tokens the extension wrote that L does not count yet.  -> (tokens, parents) int32 [keep + 1], views of
+        persistent buffers (consume before the next draft)"""
         import samd_hip
         depth, keep = head.depth, head.total_tokens
         L, st = self._lib, samd_hip.current_stream()
@@ -267,12 +271,13 @@ class DeviceHead:
         check = samd_hip.check
         ws, ws_bytes = self._e2_ws
         ws_ptr = samd_hip._ptr(ws) if ws_bytes else None
-        torch.add(self.L, 0, out=self.Lw)                  # a first use warms the graph up: it must write tree rows, not accepted ones,
+        if ("level-in-place", 8) not in self._graphs:
+            torch.add(self.L, advance_L, out=self.Lw)      # a first use warms the graph up: it must write tree rows, not accepted ones,
         level_graph = self._level_graph()                  # and come BEFORE rows are staged (the forward transforms b["x"] in place)
         check(L.samd_e2_rowstats(samd_hip._ptr(p_last_logits), dt, 1, V, V, st_ref, ws_ptr, ws_bytes, st))
         pL, pLw, pn = samd_hip._ptr(self.L), samd_hip._ptr(self.Lw), samd_hip._ptr(self.n)
         check(L.samd_e2_select(st_ref, -1, samd_hip._ptr(p_last_hidden), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
-                               samd_hip._ptr(self.relpos_buf), pL, pLw, pn, dt, st))      # also Lw <- L (level 0's rows) and n <- 8
+                               samd_hip._ptr(self.relpos_buf), pL, pLw, pn, int(advance_L), dt, st))      # also L += advance_L, Lw <- L, n <- 8
         b = self.runner._buffers(8)
         for i in range(depth):
             check(L.samd_gemm_skinny(samd_hip._ptr(self.fc_in), samd_hip._ptr(self.fc_packed), 16, n_fc, k_fc, sp, samd_hip._ptr(part), None, dt, st))
@@ -280,7 +285,7 @@ class DeviceHead:
             level_graph.replay()
             check(L.samd_e2_rowstats(samd_hip._ptr(b["logits"]), dt, 8, V, b["logits"].stride(0), st_ref, ws_ptr, ws_bytes, st))
             check(L.samd_e2_select(st_ref, i, samd_hip._ptr(b["x"]), samd_hip._ptr(self.embed), H, self.embed.shape[0], samd_hip._ptr(self.fc_in),
-                                   samd_hip._ptr(self.relpos_buf), pL, pLw, pn, dt, st))   # Lw <- L + 8 (i + 1)
+                                   samd_hip._ptr(self.relpos_buf), pL, pLw, pn, 0, dt, st))   # Lw <- L + 8 (i + 1)
         check(L.samd_e2_finish(st_ref, depth, keep, samd_hip._ptr(sample64), samd_hip._ptr(out[0]), samd_hip._ptr(out[1]), st))
         if head.trace is not None:                         # every top-k decision in the reference's order (parity tests)
             torch.cuda.current_stream().synchronize()
@@ -291,7 +296,7 @@ class DeviceHead:
                 head.trace.append((tv[1 + i], ti[1 + i]))
                 head.trace.append((bv[i], bi[i]))
             head.trace.append((t["rec_final_vals"].cpu(), t["rec_final_idx"].cpu().long()))
-        return out[0].to(torch.long), out[1].to(torch.long)
+        return out[0], out[1]
 
     def _level_graph(self):
         """hipGraph of one 8-row tree-level forward over the fixed buffers (the bucket's x, relpos_buf, mask_buf, Lw, n; visible prefix L)"""

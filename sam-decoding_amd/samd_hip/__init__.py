@@ -119,7 +119,7 @@ _PROTOS = {
     "samd_e2_rowstats_workspace": (C.c_int64, [_I64]),
     "samd_e2_stage_extend": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "samd_e2_rowstats": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _I64, _VP]),
-    "samd_e2_select": (C.c_int, [_VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
+    "samd_e2_select": (C.c_int, [_VP, _I32, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP]),
     "samd_e2_finish": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP]),
     "samd_sum_partials_bias": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_embed_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
