@@ -73,12 +73,20 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
 // run that starts at the cursor's state, next one in the low bits, all-ones once exhausted.  A token that equals the word's
 // next token IS the transition "edge found -> follow, length + 1" of transfer_state (the word repeats what the nodes say), so
 // it costs no memory access; anything else drops the word and goes through the nodes exactly as st_transfer does.  After
-// following a rank-0 edge whose source carries SAMD_RUN the word of the new state is fetched (one 16-byte load that then
-// serves up to W transitions).  W = 8 (u16 tokens) or 4 (u32).  Results are identical to st_transfer's by construction;
+// following a rank-0 edge whose source carries SAMD_RUN, after any edge of rank >= 1, and when a full word has been used up, the
+// word of the new state is fetched (one 16-byte load that then serves up to W transitions).  W = 8 (u16 tokens) or 4 (u32).  Results are identical to st_transfer's by construction;
 // tests/test_gpu_sam.py and test_gpu_fullsize.py compare both with the oracle.
 // ------------------------------------------------------------------------------------------------
-struct ChainWord { unsigned long long lo, hi; };
-__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = ~0ull; return c; }
+struct ChainWord { unsigned long long lo, hi; int used; };     // used = tokens of this word already consumed
+__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = ~0ull; c.used = 0; return c; }
+__device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
+    const uint4 c = S.chain[state];
+    ChainWord w;
+    w.lo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
+    w.hi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
+    w.used = 0;
+    return w;
+}
 
 template <int W>
 __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, ChainWord &cw) {
@@ -90,6 +98,9 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
             idx += 1; len += 1;
             if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
             else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
+            // a FULL word used up: the run may go on -- fetch the new state's word now (one load) instead of finding out through
+            // its node and then fetching the word (two); a word that ended early marks the end of the run
+            if (++cw.used == W) cw = chain_load(S, idx);
             return 1;
         }
     }
@@ -100,6 +111,8 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
         visited++;
         if (idx == 0) {
             int nx = (tok < S.vocab) ? S.root_next[tok] : -1;
+            // (no word is fetched for a landing through the root table: a depth-1 state is rarely left through its rank-0 edge --
+            // measured 0.401 ms per launch with the fetch against 0.374 without)
             if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
             return visited;
         }
@@ -108,11 +121,7 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
         if (hopped) len = w0.y & SAMD_LEN_MASK;
         if (w0.z == tok) {                                   // rank-0 edge
             idx = w0.w; len += 1;
-            if (w0.y & SAMD_RUN) {
-                const uint4 c = S.chain[idx];
-                cw.lo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
-                cw.hi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
-            }
+            if (w0.y & SAMD_RUN) cw = chain_load(S, idx);
             return visited;
         }
         int nx = -1;
@@ -125,7 +134,10 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
             if (nx < 0 && w1.y > SAMD_INLINE_EDGES)
                 nx = spill_search(S.spill + w3.z + SAMD_SPILL_HEAD, w1.y, tok);
         }
-        if (nx >= 0) { idx = nx; len += 1; return visited; }
+        // an edge of rank >= 1 carries no SAMD_RUN flag: the new state's word is fetched unconditionally -- 90 % of all states start a
+        // run of >= 2 (scripts/walk_chain_sim.py), and entering a run without its word costs the node load of its first state on top
+        // (0.361 ms per launch against 0.374)
+        if (nx >= 0) { idx = nx; len += 1; if (nx > 0) cw = chain_load(S, idx); return visited; }
         idx = w0.x; hopped = true;
         if (idx == 0) len = 0;
     }
