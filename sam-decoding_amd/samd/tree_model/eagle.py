@@ -212,6 +212,11 @@ class Eagle(Eagle2):
         flat = torch.cat((start_token.reshape(1).to(torch.long), rows.reshape(-1)))
         return flat[self._flat], self._parents
 
+    def gen_draft_from_step(self, hidden_rows, views, n_accepted, n_rows):
+        """EAGLE-2's device-to-device step path builds EAGLE-2's DYNAMIC tree; the static tree has no such form: always the general
+        path (update() + gen_draft_device())."""
+        return None
+
     def gen_draft(self, start_token: int):
         """eagle.py:55-69 -> (tokens, {}): the static buffers of gen_buffers() apply."""
         st = torch.tensor([start_token], dtype=torch.long, device=self.device)

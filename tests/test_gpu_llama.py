@@ -326,6 +326,12 @@ def test_draft_head_on_device_matches_the_pytorch_head():
         model = S.SamdModel(cfg, runner, S.DraftModel(cfg, tree_model=tm, lm=runner, device="cuda"), eos_token_id=2, dtype=torch.float16, device="cuda")
         seq = model.generate(ids, generation_config=gcfg).output_ids[0]
         assert model.lookup_stats["tree"][0] > 0
+        if method == "eagle":
+            # the static-tree plugin must install ITS tree (EAGLE-2's device-to-device step path builds a dynamic one)
+            assert tm.gen_draft_from_step(None, None, 1, 1) is None
+            d = model.engine.session.read_draft()
+            if d.type == 1 and d.n == len(tm.tree.parents):
+                assert list(d.parent[:d.n])[1:] == [int(p) for p in tm.tree.parents[1:]]
         m = min(len(seq), len(seq_ar))
         diff = [i for i in range(m) if seq[i] != seq_ar[i]]
         assert not diff or (diff[0] > len(prompt) + 4 and _near_tie(lm, seq[:diff[0]], seq[diff[0]], seq_ar[diff[0]])), (method, diff[:3])
