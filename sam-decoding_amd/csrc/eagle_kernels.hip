@@ -12,10 +12,10 @@
 #include <cstdlib>
 #include <cstring>
 #include "samd_common.h"
+#include "topk_device.h"
 
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
 
-#define E2_K 8
 #define E2_MAXDEPTH 7
 #define E2_CAND (E2_K + E2_K * E2_K * E2_MAXDEPTH)      // candidates of all levels
 #define E2_SELECT_WGS 16                                // workgroups of k_e2_select (staging of the fc input rows)
@@ -41,40 +41,6 @@ struct E2State {
     float *rec_final_vals;   // [keep]
     int32_t *rec_final_idx;  // [keep]
 };
-
-__device__ __forceinline__ float e2_f32(_Float16 x) { return (float)x; }
-__device__ __forceinline__ float e2_f32(__bf16 x) { return (float)x; }
-__device__ __forceinline__ float e2_f32(float x) { return x; }
-__device__ __forceinline__ bool e2_before(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
-
-// wave-wide max / min on the DPP network (row_shr 1, 2, 4, 8 inside each row of 16 lanes, row_bcast:15 / :31 across the rows; the
-// result sits in lane 63): ~8 VALU instructions where a __shfl_xor butterfly is 6 dependent LDS-crossbar round trips.  All 64
-// lanes must be active.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ int e2_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
-__device__ __forceinline__ float e2_wave_max(float x) {
-    const int ninf = __builtin_bit_cast(int, -INFINITY);
-#define E2_STEP(CTRL, MASK) x = fmaxf(x, __builtin_bit_cast(float, e2_dpp<CTRL, MASK>(ninf, __builtin_bit_cast(int, x))))
-    E2_STEP(0x111, 0xf); E2_STEP(0x112, 0xf); E2_STEP(0x114, 0xf); E2_STEP(0x118, 0xf); E2_STEP(0x142, 0xa); E2_STEP(0x143, 0xc);
-#undef E2_STEP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
-}
-__device__ __forceinline__ int e2_wave_min(int x) {                 // non-negative values
-#define E2_STEP(CTRL, MASK) x = min(x, e2_dpp<CTRL, MASK>(0x7fffffff, x))
-    E2_STEP(0x111, 0xf); E2_STEP(0x112, 0xf); E2_STEP(0x114, 0xf); E2_STEP(0x118, 0xf); E2_STEP(0x142, 0xa); E2_STEP(0x143, 0xc);
-#undef E2_STEP
-    return __builtin_amdgcn_readlane(x, 63);
-}
-__device__ __forceinline__ float e2_wave_sum(float x) {
-#define E2_STEP(CTRL, MASK) x += __builtin_bit_cast(float, e2_dpp<CTRL, MASK>(0, __builtin_bit_cast(int, x)))
-    E2_STEP(0x111, 0xf); E2_STEP(0x112, 0xf); E2_STEP(0x114, 0xf); E2_STEP(0x118, 0xf); E2_STEP(0x142, 0xa); E2_STEP(0x143, 0xc);
-#undef E2_STEP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
-}
-// the wave's best (value desc, index asc) of one (v, i) per lane; i = 0x7fffffff marks "nothing"
-__device__ __forceinline__ void e2_wave_best(float v, int i, float &out_v, int &out_i) {
-    out_v = e2_wave_max(v);
-    out_i = e2_wave_min(v == out_v ? i : 0x7fffffff);
-}
 
 // per row: log-sum-exp over the vocabulary and the top-8 logits (value desc, index asc) -> top_logp = logit - lse, top_idx.
 // One workgroup of 1024 threads per row; 16-byte vector loads, four in flight per thread (a scalar loop with its data-dependent
@@ -170,91 +136,14 @@ __global__ __launch_bounds__(1024) void k_e2_rowstats(const T *__restrict__ logi
 // the row count).  Stage 1: workgroup (row, split) owns 4096 consecutive elements, 16 per thread in registers; log-sum-exp partial
 // (m, s) and the segment's best 8 by 8 rounds of block arg-max (only the winning thread rescans its 16).  Stage 2: one workgroup per
 // row merges the splits' (m, s) in split order and the <= 64 x 8 candidates the same way.  Order: (value desc, index asc) throughout.
-#define E2_SEG 4096                     // elements per stage-1 workgroup
-#define E2_EPT 16                       // elements per thread (256 threads)
-#define E2_MAXSPLIT 64
-
-// The best 8 of a 256-thread workgroup's elements (N per thread, in registers), (value desc, index asc), left in res_v / res_i of
-// wave 0.  Every wave first finds ITS best 8 without a barrier: 8 rounds of wave arg-max over the lanes' current best; a lane keeps
-// its best and second best, so the winner usually just promotes its second (a rescan of its N elements, run by one lane while 63
-// wait, only when it wins again: scripts/probes/top8_probe.hip -- the rescan was 60 % of a round, the block barrier + LDS exchange
-// of a block-wide round another 25 %).  Then one barrier and wave 0 merges the 4 x 8 candidates, one per lane.
-template <int N>
-__device__ __forceinline__ void e2_block_top8(float (&v)[N], int (&id)[N], float (&res_v)[E2_K], int (&res_i)[E2_K], float *sv, int *si) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float b1v, b2v; int b1i, b2i;
-    auto scan = [&]() {
-        b1v = b2v = -INFINITY; b1i = b2i = 0x7fffffff;
-#pragma unroll
-        for (int q = 0; q < N; q++) {
-            if (e2_before(v[q], id[q], b1v, b1i)) { b2v = b1v; b2i = b1i; b1v = v[q]; b1i = id[q]; }
-            else if (e2_before(v[q], id[q], b2v, b2i)) { b2v = v[q]; b2i = id[q]; }
-        }
-    };
-    scan();
-    bool have2 = true;
-#pragma unroll 1
-    for (int round = 0; round < E2_K; round++) {
-        float wv; int wi;
-        e2_wave_best(b1v, b1i, wv, wi);
-        if (lane == 0) { sv[wave * E2_K + round] = wv; si[wave * E2_K + round] = wi; }
-        if (b1i == wi && wi != 0x7fffffff) {               // indices are unique: this lane holds the winner
-#pragma unroll
-            for (int q = 0; q < N; q++) if (id[q] == wi) { v[q] = -INFINITY; id[q] = 0x7fffffff; }
-            if (have2) { b1v = b2v; b1i = b2i; have2 = false; }
-            else { scan(); have2 = true; }
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float cv = lane < 4 * E2_K ? sv[lane] : -INFINITY; int ci = lane < 4 * E2_K ? si[lane] : 0x7fffffff;
-        if (ci == 0x7fffffff) cv = -INFINITY;
-#pragma unroll
-        for (int round = 0; round < E2_K; round++) {
-            float wv; int wi;
-            e2_wave_best(cv, ci, wv, wi);
-            res_v[round] = wv; res_i[round] = wi;
-            if (ci == wi) { cv = -INFINITY; ci = 0x7fffffff; }
-        }
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_e2_rowstats_part(const T *__restrict__ logits, long long vocab, long long stride, int n_split,
                                                           float *__restrict__ part_ms, float *__restrict__ part_v, int *__restrict__ part_i) {
     const int row = blockIdx.x, split = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T *x = logits + (size_t)row * stride;
     const long long seg0 = (long long)split * E2_SEG;
-    constexpr int VEC = 16 / sizeof(T), NV = E2_EPT / VEC;
     float v[E2_EPT]; int id[E2_EPT];
-    const bool vec_ok = ((((size_t)x) & 15) == 0);
-    if (vec_ok) {
-        uint4 raw[NV];
-#pragma unroll
-        for (int u = 0; u < NV; u++) {
-            const long long e0 = seg0 + ((long long)u * 256 + tid) * VEC;
-            if (e0 + VEC <= vocab) raw[u] = *reinterpret_cast<const uint4 *>(x + e0);
-        }
-#pragma unroll
-        for (int u = 0; u < NV; u++) {
-            const long long e0 = seg0 + ((long long)u * 256 + tid) * VEC;
-            const T *e = reinterpret_cast<const T *>(&raw[u]);
-#pragma unroll
-            for (int q = 0; q < VEC; q++) {
-                const long long g = e0 + q;
-                const bool in = g < vocab;
-                v[u * VEC + q] = !in ? -INFINITY : (e0 + VEC <= vocab ? e2_f32(e[q]) : e2_f32(x[g]));
-                id[u * VEC + q] = in ? (int)g : 0x7fffffff;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < E2_EPT; q++) {
-            const long long g = seg0 + (long long)q * 256 + tid;
-            const bool in = g < vocab;
-            v[q] = in ? e2_f32(x[g]) : -INFINITY; id[q] = in ? (int)g : 0x7fffffff;
-        }
-    }
+    e2_load_segment<T>(x, vocab, seg0, v, id);
     float m = -INFINITY, s = 0.f;
 #pragma unroll
     for (int q = 0; q < E2_EPT; q++) m = fmaxf(m, v[q]);

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include "samd_common.h"
+#include "topk_device.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { samd_set_error("%s: %s", #x, hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
@@ -672,6 +673,7 @@ struct samd_recycle {
     int32_t *d_table;       // [vocab][8]
     uint8_t *d_present;     // [vocab]
     int32_t *d_tmp;         // [tmp_rows][8] top-8 of the rows of one update
+    float *d_part_v; int32_t *d_part_i; int32_t n_split;     // [tmp_rows][n_split][8] candidates of the split top-8 (n_split = 0: one workgroup per row)
     int32_t *d_child_off, *d_children, *d_level_off, *d_level_nodes;
 };
 
@@ -722,6 +724,48 @@ __global__ __launch_bounds__(256) void k_topk8_rows(const T *__restrict__ logits
             if (bslot >= 0) si[bslot] = 0x7fffffff;          // consumed
         }
         __syncthreads();
+    }
+}
+
+// The same result from rows x ceil(vocab / 4096) workgroups + one merge workgroup per row (topk_device.h; the form EAGLE-2's
+// rowstats use): the one-workgroup-per-row kernel above is VALU-bound on its CU -- scalar 2-byte loads, and with 64 lanes per wave
+// some lane inserts into its sorted list at almost every element: 118 us for the 61 rows of a Token-Recycle step at a 32 k
+// vocabulary, against 12 us for this form.
+template <typename T>
+__global__ __launch_bounds__(256) void k_topk8_part(const T *__restrict__ logits, int rows, long long vocab, long long stride, const int *__restrict__ d_rows,
+                                                    int n_split, float *__restrict__ part_v, int *__restrict__ part_i) {
+    const int row = blockIdx.x, split = blockIdx.y;
+    if ((d_rows && row >= d_rows[0]) || row >= rows) return;
+    __shared__ float sv[4 * E2_K]; __shared__ int si[4 * E2_K];
+    float v[E2_EPT]; int id[E2_EPT];
+    e2_load_segment<T>(logits + (size_t)row * stride, vocab, (long long)split * E2_SEG, v, id);
+    float res_v[E2_K]; int res_i[E2_K];
+    e2_block_top8<E2_EPT>(v, id, res_v, res_i, sv, si);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < E2_K; k++) { part_v[((size_t)row * n_split + split) * E2_K + k] = res_v[k]; part_i[((size_t)row * n_split + split) * E2_K + k] = res_i[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_topk8_merge(int rows, const int *__restrict__ d_rows, int n_split, const float *__restrict__ part_v,
+                                                     const int *__restrict__ part_i, int *__restrict__ out) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if ((d_rows && row >= d_rows[0]) || row >= rows) return;
+    __shared__ float sv[4 * E2_K]; __shared__ int si[4 * E2_K];
+    float v[2]; int id[2];
+    const int n_cand = n_split * E2_K;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int c = tid + 256 * q;
+        v[q] = c < n_cand ? part_v[(size_t)row * n_cand + c] : -INFINITY;
+        id[q] = c < n_cand ? part_i[(size_t)row * n_cand + c] : 0x7fffffff;
+        if (id[q] == 0x7fffffff) v[q] = -INFINITY;
+    }
+    float out_v[E2_K]; int out_i[E2_K];
+    e2_block_top8<2>(v, id, out_v, out_i, sv, si);
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < E2_K; k++) out[(size_t)row * 8 + k] = out_i[k] == 0x7fffffff ? 0 : out_i[k];
     }
 }
 
@@ -1026,6 +1070,12 @@ int samd_recycle_create(int32_t vocab, const int32_t *h_child_offsets, const int
     bool ok = hipMalloc((void **)&t->d_table, (size_t)vocab * 8 * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&t->d_present, (size_t)vocab) == hipSuccess;
     ok = ok && hipMalloc((void **)&t->d_tmp, (size_t)t->tmp_rows * 8 * 4) == hipSuccess;
+    t->n_split = (vocab + E2_SEG - 1) / E2_SEG;
+    if (t->n_split > E2_MAXSPLIT) t->n_split = 0;
+    if (t->n_split) {
+        ok = ok && hipMalloc((void **)&t->d_part_v, (size_t)t->tmp_rows * t->n_split * E2_K * 4) == hipSuccess;
+        ok = ok && hipMalloc((void **)&t->d_part_i, (size_t)t->tmp_rows * t->n_split * E2_K * 4) == hipSuccess;
+    }
     ok = ok && hipMalloc((void **)&t->d_child_off, (n_nodes + 1) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&t->d_children, std::max(1, n_child) * 4) == hipSuccess;
     ok = ok && hipMalloc((void **)&t->d_level_off, (n_levels + 1) * 4) == hipSuccess;
@@ -1042,7 +1092,7 @@ int samd_recycle_create(int32_t vocab, const int32_t *h_child_offsets, const int
 
 void samd_recycle_free(samd_recycle_t *t) {
     if (!t) return;
-    void *ptrs[] = { t->d_table, t->d_present, t->d_tmp, t->d_child_off, t->d_children, t->d_level_off, t->d_level_nodes };
+    void *ptrs[] = { t->d_table, t->d_present, t->d_tmp, t->d_part_v, t->d_part_i, t->d_child_off, t->d_children, t->d_level_off, t->d_level_nodes };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     free(t);
 }
@@ -1052,6 +1102,14 @@ int samd_recycle_update(samd_recycle_t *t, const int32_t *d_tokens, const void *
     if (!t || !d_tokens || !d_logits || n < 0 || n > t->tmp_rows || vocab < 8 || vocab > t->vocab) { samd_set_error("samd_recycle_update: invalid argument"); return SAMD_E_INVALID; }
     if (n == 0) return SAMD_OK;
     hipStream_t st = (hipStream_t)stream;
+    // the split form needs the segments of THIS call's vocabulary to fit the table's workspace (vocab <= t->vocab holds)
+    const int n_split = t->n_split ? (int)((vocab + E2_SEG - 1) / E2_SEG) : 0;
+    if (n_split && (dtype == SAMD_F16 || dtype == SAMD_BF16)) {
+        const dim3 grid(n, n_split);
+        if (dtype == SAMD_F16) hipLaunchKernelGGL(k_topk8_part<_Float16>, grid, dim3(256), 0, st, (const _Float16 *)d_logits, n, (long long)vocab, (long long)row_stride, d_n, n_split, t->d_part_v, t->d_part_i);
+        else hipLaunchKernelGGL(k_topk8_part<__bf16>, grid, dim3(256), 0, st, (const __bf16 *)d_logits, n, (long long)vocab, (long long)row_stride, d_n, n_split, t->d_part_v, t->d_part_i);
+        hipLaunchKernelGGL(k_topk8_merge, dim3(n), dim3(256), 0, st, n, d_n, n_split, (const float *)t->d_part_v, (const int *)t->d_part_i, t->d_tmp);
+    } else
     switch (dtype) {
     case SAMD_F16: hipLaunchKernelGGL(k_topk8_rows<_Float16>, dim3(n), dim3(256), 0, st, (const _Float16 *)d_logits, n, (long long)vocab, (long long)row_stride, d_n, t->d_tmp); break;
     case SAMD_BF16: hipLaunchKernelGGL(k_topk8_rows<__bf16>, dim3(n), dim3(256), 0, st, (const __bf16 *)d_logits, n, (long long)vocab, (long long)row_stride, d_n, t->d_tmp); break;

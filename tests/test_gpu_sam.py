@@ -510,3 +510,36 @@ def test_tree_buffers_malformed_parents_terminate():
     assert list(d.position[:n]) == want["tree_position_ids"][0].tolist()
     ret = np.asarray(d.retrieve[:d.n_leaves * d.max_depth]).reshape(d.n_leaves, d.max_depth)
     assert ret.tolist() == want["tree_retrieve_indices"].tolist()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("vocab,rows", [(512, 7), (32000, 61), (4097, 3), (128256, 9)])
+def test_recycle_update_split_topk_matches_torch(dtype, vocab, rows):
+    """TokenRecycle.update (token_recycle.py:40-48) over half-precision logits takes the split top-8 (k_topk8_part / _merge): the
+    table rows equal logits.topk(8).indices in (value desc, index asc) order -- half precision produces exact ties --, a token that
+    occurs twice keeps its LAST row, and rows past the device-side count are ignored."""
+    g = torch.Generator(device="cuda").manual_seed(vocab + rows)
+    logits = (torch.randn((rows, vocab), generator=g, device="cuda") * 3).to(dtype)
+    if vocab == 4097:
+        logits[:, -1] = 20.0                                  # the best element sits alone in the last segment
+    tokens = torch.randperm(vocab, generator=g, device="cuda")[:rows].to(torch.int32)
+    if rows > 2:
+        tokens[rows - 1] = tokens[0]                          # later row wins
+    off = np.zeros(2, np.int32); ch = np.zeros(1, np.int32)
+    h = samd_hip.C.c_void_p()
+    samd_hip.check(samd_hip.lib().samd_recycle_create(vocab, samd_hip._ptr(off), samd_hip._ptr(ch), 1, samd_hip.C.byref(h)))
+    n_live = torch.tensor([rows - 1 if vocab == 512 else rows], dtype=torch.int32, device="cuda")      # one case with a device-side row count
+    samd_hip.check(samd_hip.lib().samd_recycle_update(h, samd_hip._ptr(tokens), samd_hip._ptr(logits), samd_hip.torch_dtype_code(dtype), rows,
+                                                      samd_hip._ptr(n_live), vocab, vocab, samd_hip.current_stream()))
+    table = np.zeros((vocab, 8), np.int32); present = np.zeros(vocab, np.uint8)
+    samd_hip.check(samd_hip.lib().samd_recycle_export(h, samd_hip._ptr(table), samd_hip._ptr(present), samd_hip.current_stream()))
+    samd_hip.lib().samd_recycle_free(h)
+    want = torch.argsort(-logits.float(), dim=-1, stable=True)[:, :8].cpu().numpy()
+    live = int(n_live.item())
+    toks = tokens.cpu().numpy()
+    expect = {}
+    for r in range(live):
+        expect[int(toks[r])] = want[r]
+    assert int(present.sum()) == len(expect)
+    for t, row in expect.items():
+        assert present[t] == 1 and table[t].tolist() == row.tolist(), (t, table[t], row)
