@@ -282,6 +282,19 @@ int samd_kv_compact_indices(void *const *d_tensors, int32_t n_tensors, int32_t n
 int samd_session_set_cache_length(samd_session_t *s, int32_t length, void *stream);
 int samd_session_get_cache_length(samd_session_t *s, int32_t *h_out, void *stream);   /* host result */
 
+/* L2 warm-up hint: the projection that FOLLOWS a glue launch on the stream.  The glue launch then carries one extra workgroup per
+ * workgroup of that samd_gemm_skinny launch, which reads the first kb_per_workgroup KiB of its weight stream (packed layout) into
+ * the L2 of the XCD that will run it -- HBM idles during the glue, and what a kernel reads stays in the XCD L2s for the next
+ * kernel (csrc/warm_device.h, scripts/probes/l2_retain_probe.hip).  Purely a speed hint: results never depend on it.
+ * No reference counterpart (the reference's forward is HF's; call sites SO/samd_model.py:134-138). */
+typedef struct samd_warm {
+    const void *d_packed_w;        /* samd_gemm_pack_weights output of the next projection; NULL = no warm-up */
+    int32_t N, K, splits;          /* its shape and split-K factor (samd_gemm_splits; 1 for samd_gemm_skinny_silu / lm_head) */
+    int32_t kb_per_workgroup;      /* KiB to warm per projection workgroup (<= 0: none) */
+    int32_t delay;                 /* the warm workgroups first sleep delay x 64 cycles, so that the glue's own loads queue first */
+    int32_t where;                 /* samd_tree_attention_warm: 0 = warm from the split launch, 1 = from the merge launch */
+} samd_warm_t;
+
 /* tree-mask attention of the n draft tokens over L cached + n new keys
  * -- SO/model_patch/llama.py:82-96 (mask semantics) + the SDPA call it feeds.
  * q [n_q_pad][H][D], k_cache/v_cache [H_kv][max_len][D] (new rows already written at [L, L+n)),
@@ -293,6 +306,11 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                         int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
                         const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
+/* the same; its merge launch also warms the L2 for the output projection that follows (next may be NULL) */
+int samd_tree_attention_warm(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype,
+                             int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                             const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
+                             void *d_workspace, int64_t workspace_bytes, const samd_warm_t *next, void *stream);
 
 /* The attention block of one decoder layer in ONE launch (csrc/attn_kernels.hip): RoPE on q and k, the K/V row write of
  * SamdStaticCache.update (SO/cache.py:103-115) at [write_pos, write_pos + n), tree-mask attention (SO/model_patch/llama.py:82-96 +
@@ -391,6 +409,9 @@ int samd_embed_rows(const int32_t *d_tokens, const void *d_table, void *d_out, i
 /* LlamaRMSNorm; if d_delta != NULL first x += delta (residual add) and store x back */
 int samd_rmsnorm(void *d_x, const void *d_delta, const void *d_weight, void *d_out, int32_t rows, int32_t hidden, float eps,
                  int32_t dtype, int32_t n_partials, int64_t partial_stride, void *stream);
+/* the same, plus the warm-up workgroups for the projection that consumes d_out (next may be NULL) */
+int samd_rmsnorm_warm(void *d_x, const void *d_delta, const void *d_weight, void *d_out, int32_t rows, int32_t hidden, float eps,
+                      int32_t dtype, int32_t n_partials, int64_t partial_stride, const samd_warm_t *next, void *stream);
 /* rotary embedding of q,k at positions L + rel_pos[r] (SO/samd_model.py:127-132) and
  * SamdStaticCache.update (SO/cache.py:103-115): K/V rows written at [L, L+n).  d_qkv [rows][(H+2Hkv)*D]. */
 int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,

@@ -7,6 +7,7 @@
 #include <vector>
 #include "samd_common.h"
 #include "topk_device.h"
+#include "warm_device.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { samd_set_error("%s: %s", #x, hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
@@ -137,13 +138,18 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
                                                         const typename TT::elem *__restrict__ vc, float *__restrict__ ws,
                                                         int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
                                                         const unsigned long long *__restrict__ mask, const int *__restrict__ d_L,
-                                                        const int *__restrict__ d_n, float scale_log2) {
+                                                        const int *__restrict__ d_n, float scale_log2, WarmArgs warm) {
     typedef typename TT::elem E;
     typedef typename TT::vec8 V8;
     __shared__ __attribute__((aligned(16))) E Vt[ATT_D * VT_STRIDE];
     __shared__ __attribute__((aligned(16))) E Pw[4 * 16 * P_STRIDE];
 
     const int h = blockIdx.x, split = blockIdx.y;
+    if (split >= ATT_SPLITS) {               // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
+        const unsigned a = warm_next_projection(warm, (split - ATT_SPLITS) * n_heads + h);
+        if (a == 0x9E3779B9u && n_q_pad < 0) ws[0] = 0.f;         // never true: keeps the loads alive
+        return;
+    }
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lg = l >> 4;
     const int row_base = 16 * w;
     // loads that do not depend on L / n go out first (Q fragments, mask rows), together with the two scalars
@@ -309,8 +315,13 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 
 template <typename E>
 __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
-                                                      const int *__restrict__ d_L, const int *__restrict__ d_n) {
+                                                      const int *__restrict__ d_L, const int *__restrict__ d_n, WarmArgs warm) {
     const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    if (h >= n_heads) {                      // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
+        const unsigned a = warm_next_projection(warm, (h - n_heads) * n_q_pad + row);
+        if (a == 0x9E3779B9u && n_q_pad < 0) out[0] = (E)0.f;     // never true: keeps the loads alive
+        return;
+    }
     // every split's (m, l, O[d]) is loaded before anything is consumed, and before the two scalars that say how many
     // splits ran are known: one memory round trip for the whole kernel.  Splits that did not run hold older partials
     // (the workspace always has ATT_SPLITS slots); they are ignored below.
@@ -989,6 +1000,19 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                         int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
                         const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
                         void *stream) {
+    return samd_tree_attention_warm(d_q, d_k_cache, d_v_cache, d_out, dtype, n_q_pad, n_heads, n_kv_heads, head_dim, max_len, d_mask, d_cache_length, d_n,
+                                    scale, d_workspace, workspace_bytes, nullptr, stream);
+}
+
+int samd_tree_attention_warm(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
+                             int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
+                             const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
+                             const samd_warm_t *next, void *stream) {
+    // the output projection's warm-up rides on the split launch (the longest glue launch of a layer) or on the merge launch
+    const WarmArgs none = warm_args(nullptr);
+    const WarmArgs wa_split = next && next->where == 0 ? warm_args(next) : none, wa = next && next->where != 0 ? warm_args(next) : none;
+    const int warm_rows = n_q_pad > 0 ? (warm_blocks(wa) + n_q_pad - 1) / n_q_pad : 0;       // extra blockIdx.y rows of the merge launch
+    const int warm_splits = (warm_blocks(wa_split) + n_heads - 1) / n_heads;                 // extra blockIdx.y rows of the split launch
     if (!d_q || !d_k_cache || !d_v_cache || !d_out || !d_mask || !d_cache_length || !d_n || !d_workspace) { samd_set_error("samd_tree_attention: null pointer"); return SAMD_E_INVALID; }
     if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 ||
         (dtype != SAMD_F16 && dtype != SAMD_BF16) || workspace_bytes < samd_tree_attention_workspace(n_q_pad, n_heads, head_dim)) {
@@ -999,15 +1023,15 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
     const float scale_log2 = scale * 1.4426950408889634f;
     float *ws = (float *)d_workspace;
     if (dtype == SAMD_F16) {
-        hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
+        hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
                            (const _Float16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
-                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
-        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n);
+                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa);
     } else {
-        hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
+        hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
                            (const __bf16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
-                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2);
-        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n);
+                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa);
     }
     LAUNCHCHK();
     return SAMD_OK;

@@ -256,7 +256,11 @@ class Eagle2(TreeModel):
         if runner is None or not hasattr(runner, "forward_rows") or os.environ.get("SAMD_EAGLE_DEVICE_HEAD", "1") == "0":
             return None
         if self.model.head_dim != 128 or str(self.model.device).startswith("cpu"):
-            return None
+            # a base model on the library's kernels never gets a PyTorch draft head behind its back (no fallback)
+            from samd_hip import SamdError
+            raise SamdError(f"the draft head of a LlamaRunner base model runs on the gfx950 kernels, which need head_dim 128 and a "
+                            f"GPU-resident head (got head_dim {self.model.head_dim} on {self.model.device}); set "
+                            f"SAMD_EAGLE_DEVICE_HEAD=0 to ask for the PyTorch head explicitly")
         from .device_head import DeviceHead
         return DeviceHead(self.model, runner)
 

@@ -47,6 +47,12 @@ class E2State(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _NAMES]
 
 
+class Warm(C.Structure):
+    """samd_warm_t: the projection that follows a glue launch (L2 warm-up hint, include/samd_hip.h)"""
+    _fields_ = [("d_packed_w", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("kb_per_workgroup", C.c_int32),
+                ("delay", C.c_int32), ("where", C.c_int32)]
+
+
 class VerdictHost(C.Structure):
     """samd_verdict_host_t"""
     _fields_ = [("best", C.c_int32), ("accept", C.c_int32), ("next_node", C.c_int32), ("next_token", C.c_int32),
@@ -107,6 +113,8 @@ _PROTOS = {
     "samd_tree_attention_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_tree_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
                                       _VP, _I64, _VP]),
+    "samd_tree_attention_warm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
+                                           _VP, _I64, _VP, _VP]),
     "samd_rope_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_attention_block": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _VP, _F32, _VP]),
     "samd_tree_attention_rope_workspace": (_I64, [_I32, _I32, _I32]),
@@ -124,6 +132,7 @@ _PROTOS = {
     "samd_sum_partials_bias": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_embed_rows": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "samd_rmsnorm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _I32, _I64, _VP]),
+    "samd_rmsnorm_warm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _I32, _I64, _VP, _VP]),
     "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
     "samd_silu_mul": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I64, _VP]),
     "samd_gemm_splits": (C.c_int, [_I32, _I32, _I32]),

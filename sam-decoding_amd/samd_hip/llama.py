@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import (F16, BF16, MAX_DRAFT, SamdError, Session, _ptr, check, current_stream, lib, require_gpu,
+from . import (F16, BF16, MAX_DRAFT, SamdError, Session, Warm, _ptr, check, current_stream, lib, require_gpu,
                torch_dtype_code)
 
 
@@ -89,6 +89,12 @@ class LlamaRunner:
         # does not fit (say a fine-tune's 32001-row lm_head) goes to the library GEMM on its own, the others keep the kernel
         streams = lambda t: bool(native_gemm) and t.shape[0] % 128 == 0 and t.shape[1] % 256 == 0
         self.native_gemm_max_rows = int(os.environ.get("SAMD_NATIVE_GEMM_MAX_ROWS", 64))     # tuning knob; see forward_rows
+        # L2 warm-up (csrc/warm_device.h): the glue launch in front of a projection also reads the first KiB of every workgroup's
+        # weight stream into the consuming XCD's L2 while HBM idles.  KiB per projection workgroup; 0 = off, the default: measured
+        # zero-sum (profiles/r03_l2_warm.md -- the projections get faster by what the glue launches get slower).
+        self.warm_kb = int(os.environ.get("SAMD_L2_WARM_KB", 0))
+        self.warm_delay = int(os.environ.get("SAMD_L2_WARM_DELAY", 0))        # x 64 cycles before the warm workgroups' first load
+        self.warm_where = int(os.environ.get("SAMD_L2_WARM_WHERE", 0))        # output projection: 0 = from the attention splits, 1 = from their merge
         # the attention block of a layer (profiles/r02_attention_variants.md has the per-layer times at Vicuna-7B head geometry):
         #   "split"  = samd_rope_kv_write_cs (per-row cos | sin prepared once per forward: one memory round trip instead of two),
         #              samd_tree_attention over 16 KV splits, its merge -- three launches, row-major V cache;
@@ -268,6 +274,14 @@ class LlamaRunner:
         L, s, b, dt, st = lib(), self.shape, self._buffers(R), self.dt, current_stream()
         RP, part = b["rows_pad"], b["part"]
 
+        def hint(w, wp, fused=False, is_head=False):
+            """samd_warm_t of the projection (w row-major, wp packed) that follows a glue launch, or None"""
+            if wp is None or RP > self.native_gemm_max_rows or self.warm_kb <= 0:
+                return None
+            n, k = w.shape
+            sp = 1 if (fused or is_head) else L.samd_gemm_splits(n, k, RP)
+            return C.byref(Warm(wp.data_ptr(), n, k, sp, self.warm_kb, self.warm_delay, self.warm_where))
+
         def gemm(a, w, wp, out):
             """out = a @ w.T (wp = w in the packed layout); returns (operand for the consumer, n_partials, partial_stride)."""
             n, k = w.shape
@@ -301,7 +315,8 @@ class LlamaRunner:
             wp = packed[li]
             raw_in = head and li == 0                             # eagle2_model.py:516-519: no input layer-norm in the head's layer
             if not raw_in:
-                check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
+                check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride,
+                                          hint(w["wqkv"], wp.get("wqkv")), st))
             src, n_p, stride = gemm(b["x"] if raw_in else b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
             if block:
                 # RoPE + K row / V^T column write + tree attention + merge of the tile partials: one launch (csrc/attn_kernels.hip)
@@ -319,18 +334,20 @@ class LlamaRunner:
                     check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
                                                _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
                                                s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
-                check(L.samd_tree_attention(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
-                                            s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
-                                            _ptr(b["ws"]), b["ws_bytes"], st))
+                check(L.samd_tree_attention_warm(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
+                                                 s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                                                 _ptr(b["ws"]), b["ws_bytes"], hint(w["wo"], wp.get("wo")), st))
             src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"])
-            check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride, st))
+            check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride,
+                                      hint(w["wgu"], wp.get("wgu"), fused=True) if self.fused_mlp else None, st))
             if self.fused_mlp and RP <= self.native_gemm_max_rows:
                 check(L.samd_gemm_skinny_silu(_ptr(b["h"]), _ptr(wp["wgu"]), RP, 2 * s.inter, s.hidden, _ptr(b["act"]), dt, st))
             else:
                 src, n_p, stride = gemm(b["h"], w["wgu"], None, b["gu"])           # wgu is only ever packed for the fused form
                 check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
             delta, dn, dstride = gemm(b["act"], w["wdown"], wp.get("wdown"), b["d"])
-        check(L.samd_rmsnorm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride, st))
+        check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride,
+                                  hint(self.w["lm_head"], self.wp["lm_head"] if self.wp else None, is_head=True), st))
         # (for a draft head the call above only folds the last projection into the residual stream; its norm output is unused)
         gemm(b["x"] if head else b["h"], self.w["lm_head"], self.wp["lm_head"] if self.wp else None, b["logits"])
         if not head:                                              # a draft head's callers rank the logits themselves
