@@ -502,6 +502,7 @@ def main():
         next(it)
     for v in model.lookup_stats.values():
         v[0] = v[1] = 0
+    model.engine.bucket_steps.clear()
     # setup, not a timed step: the hipGraph of every row bucket exists before the timed region (a bucket first met inside it
     # would add its one-off capture, ~20 ms, to a 0.7 s measurement; capture records the launches without executing them)
     if model.engine.use_graphs:
@@ -523,6 +524,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     stats = {k: list(v) for k, v in model.lookup_stats.items()}
+    bucket_hist = {str(k): v for k, v in sorted(model.engine.bucket_steps.items())}     # timed steps per row bucket
 
     tokens_total, dt_max, per_rank = parallel.reduce_throughput(tokens, dt)      # SUM of tokens, MAX of time over ranks
 
@@ -587,7 +589,7 @@ def main():
                        "hipgraphs": not args.no_graphs},
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
-            "per_rank": per_rank,
+            "per_rank": per_rank, "bucket_histogram": bucket_hist,
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
             "step_breakdown_by_rows": breakdown, "step_breakdown_named": named,
             # SURVEY.md 8(d) end-to-end proxy: speed-up = accepted tokens x T_AR / T_step with THIS run's measured step times

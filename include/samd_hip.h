@@ -422,7 +422,7 @@ int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_
 int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,
                   int64_t partial_stride, void *stream);
 
-/* weight-streaming skinny GEMM of the verify forward: out[m][n] = sum_k A[m][k] * W[n][k], m < rows_pad in {16,32,64},
+/* weight-streaming skinny GEMM of the verify forward: out[m][n] = sum_k A[m][k] * W[n][k], m < rows_pad in {16,32,48,64},
  * W = an nn.Linear weight [N][K] (what the reference runs through HF's q/k/v/o/gate/up/down/lm_head projections,
  * call sites SO/samd_model.py:102-106, :134-138).  N % 128 == 0, K % 256 == 0.  The kernel reads W in the PACKED layout
  * that samd_gemm_pack_weights writes once at load time (64 KiB blocks of 128 columns x 256 k in lane order, so that every

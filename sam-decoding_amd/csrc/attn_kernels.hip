@@ -386,8 +386,8 @@ int samd_attention_block(const void *d_qkv, int32_t n_partials, int64_t partial_
     hipStream_t st = (hipStream_t)stream;
     const float scale_log2 = scale * 1.4426950408889634f;
     const dim3 grid(n_heads, (n_q_pad + 15) / 16), block(64 * AB_WAVES);
-#define GO(TT, NP, ET) do { static const hipError_t attr_ = hipFuncSetAttribute((const void *)k_attn_block<TT, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS_BYTES); \
-        if (attr_ != hipSuccess) { samd_set_error("samd_attention_block: cannot reserve %d bytes of LDS", (int)AB_LDS_BYTES); return SAMD_E_HIP; } \
+#define GO(TT, NP, ET) do { static unsigned long long done_ = 0ull; \
+        if (samd_reserve_lds((const void *)k_attn_block<TT, NP>, AB_LDS_BYTES, &done_) != hipSuccess) { samd_set_error("samd_attention_block: cannot reserve %d bytes of LDS on this device", (int)AB_LDS_BYTES); return SAMD_E_HIP; } \
         hipLaunchKernelGGL((k_attn_block<TT, NP>), grid, block, AB_LDS_BYTES, st, (const ET *)d_qkv, n_partials, (long long)partial_stride, d_cs, \
         (ET *)d_k_cache, (ET *)d_vt_cache, (ET *)d_out, n_q_pad, n_heads, n_kv_heads, (long long)max_len, (const unsigned long long *)d_mask, d_write_pos, \
         d_visible_len, d_n, scale_log2); } while (0)

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(1024) void k_e2_rowstats(const T *__restrict__ logi
     for (int k = 0; k < E2_K; k++) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
     float m = -INFINITY, s = 0.f;
     auto take = [&](float v, int id) {
-        if (v > m) { s = s * __expf(m - v) + 1.f; m = v; } else s += __expf(v - m);
+        // a -inf logit (masked vocabulary entry) adds nothing; without the guard exp(-inf - -inf) = NaN poisons the row's lse
+        if (v > m) { s = s * __expf(m - v) + 1.f; m = v; } else if (v != -INFINITY) s += __expf(v - m);
         if (!e2_before(v, id, bv[E2_K - 1], bi[E2_K - 1])) return;
 #pragma unroll
         for (int k = 0; k < E2_K; k++)

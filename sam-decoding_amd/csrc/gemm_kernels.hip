@@ -50,7 +50,7 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // silu(gate) * up [rows][N/2] -- LlamaMLP's activation without a launch, a 2N-wide intermediate or its re-read.
 // DEPTH = weight chunks (+ their A tiles) in flight whenever a wave waits; DEPTH + 1 LDS buffers (dynamic LDS: 128 KiB at 64 rows).
 template <typename TT, int RT, int EPI, int DEPTH>
-__global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 || DEPTH > 2 ? 2 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
+__global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                         float *__restrict__ partial, typename TT::elem *__restrict__ out,
                                                         int K, int N, int n_chunks, int n_splits) {
     typedef typename TT::elem E;
@@ -133,6 +133,10 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 || DEPTH > 2 ? 2 : GEMM_WA
             else if constexpr (RT == 2)
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:8192\n\t"
                              "s_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]) : "v"(a0), "v"(a1));
+            else if constexpr (RT == 3)
+                asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %6 offset:8192\n\tds_read_b128 %3, %7 offset:8192\n\t"
+                             "ds_read_b128 %4, %6 offset:16384\n\tds_read_b128 %5, %7 offset:16384\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]) : "v"(a0), "v"(a1));
             else
                 asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %9 offset:8192\n\t"
                              "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %9 offset:16384\n\tds_read_b128 %6, %8 offset:24576\n\t"
@@ -147,12 +151,12 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT == 4 || DEPTH > 2 ? 2 : GEMM_WA
             // 64 rows: refill as soon as this k block's operands are consumed -- the loads trickle into the memory pipe between
             // the k blocks instead of arriving as one burst after a load-free compute window (all 8 waves compute at once):
             // gate|up 40.5 -> 39.8 us; neutral at 16 / 32 rows, which keep the burst (profiles/r02_gemm_rows64.md)
-            if (RT == 4 && c + DEPTH < c1) {
+            if (RT >= 3 && c + DEPTH < c1) {
                 load_wb(cur, c + DEPTH, b);
                 if (b < XV) stage_xi(c + DEPTH, buf == 0 ? NB - 1 : buf - 1, b);
             }
         }
-        if (RT != 4 && c + DEPTH < c1) { load_w(cur, c + DEPTH); stage_x(c + DEPTH, buf == 0 ? NB - 1 : buf - 1); }
+        if (RT < 3 && c + DEPTH < c1) { load_w(cur, c + DEPTH); stage_x(c + DEPTH, buf == 0 ? NB - 1 : buf - 1); }
     };
     if (c0 < c1) {
 #pragma unroll
@@ -222,7 +226,8 @@ template <typename TT, int RT, int EPI, int DEPTH>
 static hipError_t gemm_launch(dim3 grid, hipStream_t st, const void *A, const void *W, float *partial, void *out, int K, int N, int chunks, int splits) {
     constexpr int lds = (DEPTH + 1) * 16 * RT * GEMM_KC * 2;
     if constexpr (lds > 65536) {
-        static const hipError_t attr = hipFuncSetAttribute((const void *)k_gemm_skinny<TT, RT, EPI, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        static unsigned long long done = 0ull;                     // per-device (samd_common.h)
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_skinny<TT, RT, EPI, DEPTH>, lds, &done);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL((k_gemm_skinny<TT, RT, EPI, DEPTH>), grid, dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, partial,
@@ -234,7 +239,7 @@ template <int EPI>
 static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t st, const void *A, const void *W, float *partial, void *out, int K, int N, int chunks,
                                 int splits) {
 #define GO(TT, RT, D) return gemm_launch<TT, RT, EPI, D>(grid, st, A, W, partial, out, K, N, chunks, splits)
-#define ROWS(TT) do { if (rows_pad == 16) GO(TT, 1, 2); else if (rows_pad == 32) GO(TT, 2, 2); else GO(TT, 4, 2); } while (0)
+#define ROWS(TT) do { if (rows_pad == 16) GO(TT, 1, 2); else if (rows_pad == 32) GO(TT, 2, 2); else if (rows_pad == 48) GO(TT, 3, 2); else GO(TT, 4, 2); } while (0)
     if (dtype == SAMD_F16) ROWS(GF16); else ROWS(GBF16);
 #undef ROWS
 #undef GO
@@ -264,11 +269,11 @@ int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad) {
 int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits) { return (int64_t)splits * rows_pad * N * 4; }
 
 // out (dtype, [rows_pad][N]) when splits == 1, else fp32 partials [splits][rows_pad][N] in d_partial.
-// rows_pad in {16, 32, 64}; A must hold rows_pad rows (pad rows are read, their products land in pad rows).
+// rows_pad in {16, 32, 48, 64}; A must hold rows_pad rows (pad rows are read, their products land in pad rows).
 int samd_gemm_skinny_silu(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, void *d_out, int32_t dtype, void *stream) {
-    if (!d_A || !d_W || !d_out || (rows_pad != 16 && rows_pad != 32 && rows_pad != 64) || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC ||
+    if (!d_A || !d_W || !d_out || (rows_pad != 16 && rows_pad != 32 && rows_pad != 48 && rows_pad != 64) || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC ||
         K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
-        samd_set_error("samd_gemm_skinny_silu: unsupported shape (rows 16/32/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
+        samd_set_error("samd_gemm_skinny_silu: unsupported shape (rows 16/32/48/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
     }
     const hipError_t e = gemm_dispatch<1>(dtype, rows_pad, dim3(N / GEMM_COLS, 1), (hipStream_t)stream, d_A, d_W, nullptr, d_out, K, N, K / GEMM_KC, 1);
     if (e != hipSuccess) { samd_set_error("samd_gemm_skinny_silu: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
@@ -288,9 +293,9 @@ int samd_gemm_pack_weights(const void *d_W, void *d_packed, int32_t N, int32_t K
 
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
                      void *d_out, int32_t dtype, void *stream) {
-    if (!d_A || !d_W || (rows_pad != 16 && rows_pad != 32 && rows_pad != 64) || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC ||
+    if (!d_A || !d_W || (rows_pad != 16 && rows_pad != 32 && rows_pad != 48 && rows_pad != 64) || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC ||
         K % GEMM_KC != 0 || splits < 1 || splits > K / GEMM_KC || (splits == 1 ? !d_out : !d_partial) || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
-        samd_set_error("samd_gemm_skinny: unsupported shape (rows 16/32/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
+        samd_set_error("samd_gemm_skinny: unsupported shape (rows 16/32/48/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
     }
     const hipError_t e = gemm_dispatch<0>(dtype, rows_pad, dim3(N / GEMM_COLS, splits), (hipStream_t)stream, d_A, d_W, d_partial, splits == 1 ? d_out : nullptr, K, N,
                                           K / GEMM_KC, splits);

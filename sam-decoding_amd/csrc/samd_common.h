@@ -138,3 +138,23 @@ extern "C"
 int samd_static_derive_chain(struct samd_static *s, void *stream);
 
 void samd_set_error(const char *fmt, ...);
+
+#if defined(__HIPCC__)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (kernel, device), not once per
+// process (a process that moves to another device would otherwise launch there without it).  `done` = one bitmask per kernel
+// instantiation (function-local static at the call site); devices >= 64 set it on every call.
+static inline hipError_t samd_reserve_lds(const void *kernel, int bytes, unsigned long long *done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((*done >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {                                   // say what the device offers (a 64 KiB-LDS part cannot run these kernels)
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess)
+            samd_set_error("device %d offers %d bytes of LDS per workgroup, the kernel needs %d (written for gfx950: 160 KiB)", dev, optin, bytes);
+    }
+    if (e == hipSuccess && dev >= 0 && dev < 64) *done |= 1ull << dev;
+    return e;
+}
+#endif

@@ -170,6 +170,7 @@ class DecodeEngine:
         self._report_np = self.report_buf.numpy()
         self.use_graphs = use_graphs
         self._graphs = {}
+        self.bucket_steps = {}               # row bucket -> decode steps run on it (bench.py: bucket_histogram)
         self._views = session.device_views()
         self._n_ptr = self._views["dmeta"] + 4
 
@@ -215,6 +216,7 @@ class DecodeEngine:
     def step(self, n_next):
         """one decode step on the current draft of n_next nodes; returns the report after it."""
         R = self.verifier.bucket(n_next)
+        self.bucket_steps[R] = self.bucket_steps.get(R, 0) + 1
         if not self.use_graphs:
             self._enqueue_step(R)
         else:
@@ -294,6 +296,7 @@ class TreeModelEngine(DecodeEngine):
 
     def step(self, n_next):
         R = self.verifier.bucket(n_next)
+        self.bucket_steps[R] = self.bucket_steps.get(R, 0) + 1
         if not self.use_graphs:
             self._enqueue_step(R)
         else:

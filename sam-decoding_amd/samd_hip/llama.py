@@ -74,7 +74,9 @@ class LlamaShape:
 class LlamaRunner:
     """Own decoder loop over Llama weights resident in HBM.  One instance = one model replica on one GPU."""
 
-    BUCKETS = (1, 8, 16, 32, 64)
+    # row buckets of a decode step (one hipGraph each).  The streaming GEMM's cost goes by 16-row tiles (1 / 8 / 16 rows share the
+    # 16-row tile), so the buckets above 16 follow its tiles: a 33..48-node draft (match length 8..11 at alpha 4) does not pay for 64 rows
+    BUCKETS = (1, 8, 16, 32, 48, 64)
 
     def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None, native_gemm=True, packed_lm_head=None,
                  attention=None):

@@ -52,9 +52,11 @@ def hf_attention_forward(self, hidden_states, position_embeddings=None, attentio
     """Drop-in for transformers' LlamaAttention.forward (the reference patches HF modules through `attn_patch_dict`,
     samd_sam_only/model_patch/__init__.py:1-7): same projections, rotary embedding and cache update as HF, but the attention product
     of a draft step -- bs = 1, <= 64 new rows, head_dim 128, fp16 / bf16, K/V views of a row-major SamdStaticCache, a 4-D additive
-    mask whose new-key block is the tree mask (model_patch/llama.py:94-96) -- runs on samd_tree_attention.  Anything else (prefill
-    chunks > 64 rows, other caches, fp32) goes to HF's eager attention unchanged."""
-    from transformers.models.llama.modeling_llama import apply_rotary_pos_emb, eager_attention_forward
+    mask (additive float, or bool with True = attend) whose new-key block is the tree mask (model_patch/llama.py:94-96) -- runs on
+    samd_tree_attention.  Anything else (prefill chunks > 64 rows, no explicit mask, other caches, fp32) is dispatched exactly as HF's
+    own forward does: the attention interface the model was configured with (`config._attn_implementation`: sdpa applies its own
+    causal rule when transformers dropped the mask; eager only when eager was asked for)."""
+    from transformers.models.llama.modeling_llama import ALL_ATTENTION_FUNCTIONS, apply_rotary_pos_emb, eager_attention_forward
     input_shape = hidden_states.shape[:-1]
     hidden_shape = (*input_shape, -1, self.head_dim)
     q = self.q_proj(hidden_states).view(hidden_shape).transpose(1, 2)
@@ -68,14 +70,17 @@ def hf_attention_forward(self, hidden_states, position_embeddings=None, attentio
     D = self.head_dim
     usable = (q.shape[0] == 1 and n <= samd_hip.MAX_DRAFT and D == 128 and q.dtype in (torch.float16, torch.bfloat16) and q.is_cuda
               and attention_mask is not None and attention_mask.dim() == 4 and attention_mask.shape[-1] >= total
+              and (attention_mask.dtype.is_floating_point or attention_mask.dtype == torch.bool)
               and k.stride(3) == 1 and k.stride(2) == D and v.stride(3) == 1 and v.stride(2) == D and k.stride(1) == v.stride(1)
               and k.stride(1) % D == 0 and not getattr(past_key_values, "v_transposed", False))
     if not usable:
-        out, w = eager_attention_forward(self, q, k, v, attention_mask, dropout=0.0, scaling=self.scaling, **kwargs)
+        interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager_attention_forward)
+        out, w = interface(self, q, k, v, attention_mask, dropout=0.0 if not self.training else self.attention_dropout, scaling=self.scaling, **kwargs)
         return self.o_proj(out.reshape(*input_shape, -1).contiguous()), w
     L = total - n
     H, Hkv, max_len = q.shape[1], k.shape[1], k.stride(1) // D
-    m = (attention_mask[0, 0, :n, L:total] == 0).to(torch.int64)
+    blk = attention_mask[0, 0, :n, L:total]
+    m = (blk if blk.dtype == torch.bool else blk == 0).to(torch.int64)          # bool: True = attend; additive: 0 = attend
     rows = torch.zeros(samd_hip.MAX_DRAFT, dtype=torch.int64, device=q.device)
     rows[:n] = (m << torch.arange(n, device=q.device, dtype=torch.int64)[None, :]).sum(-1)
     n_pad = n

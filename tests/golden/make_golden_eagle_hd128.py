@@ -42,6 +42,12 @@ from eagle_fixture_weights import CFG, call_inputs, head_state, lm_head_weight  
 
 SEEDS = dict(eagle2=86, std=15, odd=7)    # results of the search below, so that regenerating takes seconds (delete an entry to search again)
 STEPS = [13, 1, 4]          # prompt, then accepted-token counts of later steps (the head's KV cache grows)
+# round 3: the same recording for config 4's dtype and for a real vocabulary size
+#   eagle2_hd128_bf16.npz : weights / inputs representable in bf16 (the Llama-3-8B configuration computes in bf16)
+#   eagle2_hd128_v32k.npz : V = 32000 (Vicuna's vocabulary: the row statistics run their split path, 8 workgroups per row)
+# seed = result of the search (most (call, noisy trial) pairs that keep the recorded tree); None = search again
+VARIANTS = dict(bf16=dict(rounding="bf16", vocab=512, steps=[13, 1, 4, 2, 3], seed=None, limit=200, noise=4e-3),
+                v32k=dict(rounding="f16", vocab=32000, steps=[13, 1, 4, 2, 3], seed=None, limit=40, noise=2e-3))
 NOISE, TRIALS = 2e-3, 8
 
 
@@ -80,18 +86,18 @@ class NoisyHead:
         return y
 
 
-def eagle2_run(seed, noise=0.0, trial=0, want_trace=False):
-    cfg = Eagle2Config(**CFG)
+def eagle2_run(seed, noise=0.0, trial=0, want_trace=False, rounding="f16", vocab=512, steps=None):
+    cfg = Eagle2Config(**dict(CFG, vocab_size=vocab))
     cfg.rope_scaling = None
     model = Eagle2Model(cfg, bias=True).float().eval()
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in head_state(seed).items()}, strict=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in head_state(seed, rounding, vocab).items()}, strict=True)
     model.init_tree()
     model.stable_kv = None
     gen = torch.Generator().manual_seed(1000 * seed + trial)
-    head = NoisyHead(torch.from_numpy(lm_head_weight(seed)), noise, gen)
+    head = NoisyHead(torch.from_numpy(lm_head_weight(seed, rounding=rounding, vocab=vocab)), noise, gen)
     outs, traces = [], []
-    for ci, t in enumerate(STEPS):
-        hs, ids = call_inputs(seed, ci, t)
+    for ci, t in enumerate(steps or STEPS):
+        hs, ids = call_inputs(seed, ci, t, rounding, vocab)
         hs = torch.from_numpy(hs)
         if noise:
             hs = hs * (1 + noise * torch.randn(hs.shape, generator=gen))
@@ -169,7 +175,37 @@ def put_trace(out, prefix, calls):
         out[f"{prefix}:k{j}:v"], out[f"{prefix}:k{j}:i"], out[f"{prefix}:k{j}:next"] = v, i, nxt
 
 
+def eagle2_variant(name, rounding, vocab, steps, seed, limit, noise):
+    """seed = the one whose recorded trees survive the most (call, noisy trial) pairs: with five calls per fixture hardly any seed
+    keeps ALL of them under noise, but the GPU test counts calls"""
+    run = lambda s, n, t: eagle2_run(s, n, t, rounding=rounding, vocab=vocab, steps=steps)
+    best = (-1, None)
+    for cand in ([seed] if seed else range(1, limit)):
+        base = run(cand, 0.0, 0)
+        ok = sum(path_set(a[0], a[1], a[2]) == path_set(b[0], b[1], b[2]) for t in range(TRIALS) for a, b in zip(base, run(cand, noise, t)))
+        if ok > best[0]:
+            best = (ok, cand)
+            print(f"    {name}: seed {cand} keeps {ok}/{TRIALS * len(steps)} (call, trial) pairs", flush=True)
+        if ok == TRIALS * len(steps):
+            break
+    ok, seed = best
+    base, traces = eagle2_run(seed, want_trace=True, rounding=rounding, vocab=vocab, steps=steps)
+    out = {"seed": seed, "steps": np.array(steps), "noise": noise, "trials": TRIALS, "robust_pairs": ok, "vocab": vocab,
+           "rounding": np.array(rounding)}
+    for ci, (toks, mask, pos, ret) in enumerate(base):
+        out[f"c{ci}:tokens"], out[f"c{ci}:mask"], out[f"c{ci}:pos"], out[f"c{ci}:retrieve"] = toks, mask, pos, ret
+        put_trace(out, f"c{ci}", traces[ci])
+        print(f"  eagle2_hd128_{name} seed {seed} ({ok}/{TRIALS * len(steps)} (call, noisy trial) pairs keep the tree) call {ci}: tokens[:6]={toks[:6].tolist()} leaves={ret.shape}")
+    f = os.path.join(HERE, f"eagle2_hd128_{name}.npz")
+    np.savez_compressed(f, **out)
+    print("wrote", f, os.path.getsize(f), "bytes")
+
+
 def main():
+    if len(sys.argv) > 1:                     # only the named round-3 variants: python make_golden_eagle_hd128.py bf16 v32k
+        for name in sys.argv[1:]:
+            eagle2_variant(name, **VARIANTS[name])
+        return
     # ---- EAGLE-2 ------------------------------------------------------------------------------------------------
     seed, ok = pick_seed(lambda s, n, t: eagle2_run(s, n, t), known=SEEDS.get("eagle2"), same=same_tree)
     base, traces = eagle2_run(seed, want_trace=True)

@@ -19,11 +19,16 @@ Two layers:
           inside one row swapped ranks, which renumbers nodes but changes nothing the verify step can see;
       (c) a different draft whose FIRST differing top-k decision is a near-tie of the reference: recorded margin
           (value[p] - value[p+1]) <= 2 * TOL_FP16, with all values before it within TOL_FP16.
-    Anything else fails.  The fixtures' seeds were chosen so that the recorded drafts survive 2e-3 relative noise (as trees for
-    EAGLE-2, exactly for EAGLE v1), so (a)/(b) is the expected outcome; at least one call per fixture must end in (a) or (b).
+    Anything else fails, and at least MIN_SAME of a fixture's calls must end in (a) or (b): 80 % for the fp16 head (on the box every
+    call of every fp16 fixture is (a)), 60 % for the bf16 head, whose decisions carry 8x the rounding noise.
+
+Fixtures: eagle2_hd128.npz / eagle_hd128.npz (fp16-representable weights, V = 512), eagle2_hd128_v32k.npz (V = 32000: the row
+statistics take their split path) and eagle2_hd128_bf16.npz (weights and inputs representable in bf16 -- configs[3] computes in
+bf16 -- followed by the bf16 device head).
 
 TOL_FP16 = 0.1 absolute on head logits / log-probabilities.  The head's logits reach |x| ~ 64-128 here, where fp16 values are
-0.0625 apart (the device head's logits are fp16 GEMM outputs), and its output states carry ~1e-3 relative error on top."""
+0.0625 apart (the device head's logits are fp16 GEMM outputs), and its output states carry ~1e-3 relative error on top.
+TOL_BF16 = 0.8 = 8 x TOL_FP16: bf16 keeps 3 mantissa bits fewer."""
 import json
 import os
 
@@ -39,6 +44,8 @@ from eagle_fixture_weights import CFG, call_inputs, head_state, lm_head_weight
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL_FP16 = 0.1
+TOL_BF16 = 0.8
+MIN_SAME = {"f16": 0.8, "bf16": 0.6}
 
 
 def tree_buffers(parents):
@@ -117,7 +124,7 @@ def test_eagle_v1_fp32_on_gpu_matches_recorded_reference(name):
 # ---------------------------------------------------------------------------------------------------------------------
 # 2. the fp16 device head vs the head_dim-128 recordings, decision by decision
 # ---------------------------------------------------------------------------------------------------------------------
-def follow(ref_calls, dev_calls, last_is_a_set=False):
+def follow(ref_calls, dev_calls, last_is_a_set=False, tol=TOL_FP16):
     """compare two top-k decision sequences -> None when every call agrees (indices equal, values within TOL_FP16), else
     (call j, row, position, recorded margin) of the first difference, which must be a near-tie of the reference.
     last_is_a_set: the final call only selects (EAGLE-2 sorts the kept candidates by index afterwards, eagle2_model.py:893-895)."""
@@ -132,10 +139,10 @@ def follow(ref_calls, dev_calls, last_is_a_set=False):
             for p in range(rv2.shape[1]):
                 if ri2[row, p] != di2[row, p]:
                     margin = float(ext[p] - ext[p + 1])
-                    assert margin <= 2 * TOL_FP16, (f"top-k call {j} row {row} position {p}: device chose {di2[row, p]}, reference {ri2[row, p]} "
-                                                    f"with margin {margin:.4f} > 2 x {TOL_FP16}")
+                    assert margin <= 2 * tol, (f"top-k call {j} row {row} position {p}: device chose {di2[row, p]}, reference {ri2[row, p]} "
+                                               f"with margin {margin:.4f} > 2 x {tol}")
                     return j, row, p, margin
-                assert abs(float(rv2[row, p]) - float(dv2[row, p])) <= TOL_FP16, (j, row, p, float(rv2[row, p]), float(dv2[row, p]))
+                assert abs(float(rv2[row, p]) - float(dv2[row, p])) <= tol, (j, row, p, float(rv2[row, p]), float(dv2[row, p]))
     return None
 
 
@@ -143,19 +150,19 @@ def ref_trace(z, prefix):
     return [(z[f"{prefix}:k{j}:v"], z[f"{prefix}:k{j}:i"], z[f"{prefix}:k{j}:next"]) for j in range(int(z[f"{prefix}:n_topk"]))]
 
 
-def device_head_for(seed, head_cls):
-    """the seeded head in fp16 on a LlamaRunner whose lm_head is the fixture's (the base model's layers are irrelevant here)"""
+def device_head_for(seed, head_cls, dtype=torch.float16, rounding="f16", vocab=512):
+    """the seeded head in `dtype` on a LlamaRunner whose lm_head is the fixture's (the base model's layers are irrelevant here)"""
     from samd_hip.llama import LlamaRunner
     from samd.tree_model.device_head import DeviceHead
     cfg = dict(hidden_size=CFG["hidden_size"], intermediate_size=CFG["intermediate_size"], num_attention_heads=CFG["num_attention_heads"],
-               num_key_value_heads=CFG["num_key_value_heads"], vocab_size=CFG["vocab_size"], rms_norm_eps=CFG["rms_norm_eps"], rope_theta=10000.0)
-    head = head_cls(cfg, dtype=torch.float16, device="cuda", bias=True)
-    head.load_state({k: torch.from_numpy(v) for k, v in head_state(seed).items()})
+               num_key_value_heads=CFG["num_key_value_heads"], vocab_size=vocab, rms_norm_eps=CFG["rms_norm_eps"], rope_theta=10000.0)
+    head = head_cls(cfg, dtype=dtype, device="cuda", bias=True)
+    head.load_state({k: torch.from_numpy(v) for k, v in head_state(seed, rounding, vocab).items()})
     base_cfg = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=2, head_dim=128,
-                    vocab_size=512, max_position_embeddings=512, rms_norm_eps=1e-6)
-    runner = LlamaRunner.random_init(base_cfg, 256, torch.float16, seed=1)
-    runner.w["lm_head"].copy_(torch.from_numpy(lm_head_weight(seed)).to(torch.float16))
-    samd_hip.check(samd_hip.lib().samd_gemm_pack_weights(samd_hip._ptr(runner.w["lm_head"]), samd_hip._ptr(runner.wp["lm_head"]), 512, 256,
+                    vocab_size=vocab, max_position_embeddings=512, rms_norm_eps=1e-6)
+    runner = LlamaRunner.random_init(base_cfg, 256, dtype, seed=1)
+    runner.w["lm_head"].copy_(torch.from_numpy(lm_head_weight(seed, rounding=rounding, vocab=vocab)).to(dtype))
+    samd_hip.check(samd_hip.lib().samd_gemm_pack_weights(samd_hip._ptr(runner.w["lm_head"]), samd_hip._ptr(runner.wp["lm_head"]), vocab, 256,
                                                          samd_hip.current_stream()))
     torch.cuda.synchronize()
     return head, runner, DeviceHead(head, runner)
@@ -170,17 +177,21 @@ def path_set(tokens, mask, pos):
     return out
 
 
-def test_eagle2_device_head_follows_recorded_reference():
+@pytest.mark.parametrize("fixture,kind", [("eagle2_hd128.npz", "f16"), ("eagle2_hd128_v32k.npz", "f16"), ("eagle2_hd128_bf16.npz", "bf16")])
+def test_eagle2_device_head_follows_recorded_reference(fixture, kind):
     from samd.tree_model.eagle2 import Eagle2Head
-    z = np.load(os.path.join(HERE, "golden", "eagle2_hd128.npz"))
+    z = np.load(os.path.join(HERE, "golden", fixture))
     seed = int(z["seed"])
-    head, runner, dh = device_head_for(seed, Eagle2Head)
+    vocab = int(z["vocab"]) if "vocab" in z.files else 512
+    dtype, tol = (torch.float16, TOL_FP16) if kind == "f16" else (torch.bfloat16, TOL_BF16)
+    head, runner, dh = device_head_for(seed, Eagle2Head, dtype, kind, vocab)
     dh.reset()
     good, notes = 0, []
+    n_calls = len(z["steps"].tolist())
     for ci, t in enumerate(z["steps"].tolist()):
-        hs, ids = call_inputs(seed, ci, t)
+        hs, ids = call_inputs(seed, ci, t, kind, vocab)
         head.trace = []
-        toks, parents = head.topk_generate_device(dh, torch.from_numpy(hs).cuda().half(), torch.from_numpy(ids).cuda())
+        toks, parents = head.topk_generate_device(dh, torch.from_numpy(hs).cuda().to(dtype), torch.from_numpy(ids).cuda())
         torch.cuda.synchronize()
         dev_calls, head.trace = head.trace, None
         mask, pos, ret = tree_buffers(parents.tolist())
@@ -192,11 +203,13 @@ def test_eagle2_device_head_follows_recorded_reference():
             notes.append(f"call {ci}: same tree, other numbering")
             good += 1
         else:
-            where = follow(ref_trace(z, f"c{ci}"), dev_calls, last_is_a_set=True)       # asserts that the first difference is a near-tie
+            where = follow(ref_trace(z, f"c{ci}"), dev_calls, last_is_a_set=True, tol=tol)       # asserts that the first difference is a near-tie
             assert where is not None, f"call {ci}: drafts differ although every recorded decision matches"
             notes.append(f"call {ci}: near-tie at top-k call {where[0]} row {where[1]} pos {where[2]} (recorded margin {where[3]:.4f})")
-    print(f"eagle2 device head vs recorded reference: " + "; ".join(notes))
-    assert good >= 1
+    summary = f"eagle2 {kind} device head vs recorded reference ({fixture}): " + "; ".join(notes)
+    print(summary)
+    # every call ended in (a), (b) or a proven near-tie (anything else asserted above); most must be the same draft
+    assert good >= MIN_SAME[kind] * n_calls, summary
 
 
 @pytest.mark.parametrize("name", ["std", "odd"])
@@ -224,5 +237,6 @@ def test_eagle_v1_device_head_follows_recorded_reference(name):
         where = follow(ref_trace(z, f"{name}:c{ci}"), dev_calls)                          # asserts that the first difference is a near-tie
         assert where is not None, f"call {ci}: drafts differ although every recorded decision matches"
         notes.append(f"call {ci}: near-tie at top-k call {where[0]} row {where[1]} pos {where[2]} (recorded margin {where[3]:.4f})")
-    print(f"eagle v1 [{name}] device head vs recorded reference: " + "; ".join(notes))
-    assert exact >= 1
+    summary = f"eagle v1 [{name}] device head vs recorded reference: " + "; ".join(notes)
+    print(summary)
+    assert exact >= MIN_SAME["f16"] * len(z["steps"].tolist()), summary

@@ -56,6 +56,31 @@ def test_rowstats_matches_log_softmax_topk(dtype, vocab, rows, split):
     assert (t["row_lse"][:rows] - torch.logsumexp(logits.float(), dim=-1)).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["split", "one-workgroup"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_rowstats_with_masked_vocabulary_entries(dtype, split):
+    """-inf logits (a masked vocabulary) add nothing to the row's log-sum-exp on either path -- also when a thread meets -inf before
+    any finite value (column 0 .. 4095 masked: whole threads / whole splits see only -inf first)"""
+    vocab, rows = 32000, 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    logits = (torch.randn((rows, vocab), generator=g, device="cuda") * 4).to(dtype)
+    logits[:, :4096] = float("-inf")
+    logits[1, 5000:20000] = float("-inf")
+    logits[2, ::2] = float("-inf")
+    t, st = make_state()
+    nbytes = lib().samd_e2_rowstats_workspace(vocab)
+    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda") if split else None
+    check(lib().samd_e2_rowstats(_ptr(logits), torch_dtype_code(dtype), rows, vocab, vocab, C.byref(st), _ptr(ws) if split else None, nbytes if split else 0,
+                                 current_stream()))
+    torch.cuda.synchronize()
+    order = torch.argsort(-logits.float(), dim=-1, stable=True)[:, :8]
+    want_v = torch.gather(torch.log_softmax(logits.float(), dim=-1), 1, order)
+    assert torch.equal(t["top_idx"].view(8, 8)[:rows].long(), order)
+    assert torch.isfinite(t["row_lse"][:rows]).all()
+    assert (t["top_logp"].view(8, 8)[:rows] - want_v).abs().max().item() < 2e-4
+    assert (t["row_lse"][:rows] - torch.logsumexp(logits.float(), dim=-1)).abs().max().item() < 2e-4
+
+
 def test_expansion_kernels_match_the_pytorch_loop():
     """same head, same accepted tokens: the kernel path (samd_e2_*) and Eagle2Head._expand_levels give the same draft"""
     from eagle_fixture_weights import call_inputs

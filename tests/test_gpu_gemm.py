@@ -28,7 +28,7 @@ def run(A, W, rows_pad, splits, dtype):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
-@pytest.mark.parametrize("rows_pad,N,K,splits", [(16, 128, 256, 1), (16, 4096, 4096, 4), (32, 1024, 768, 3), (64, 12288, 4096, 2),
+@pytest.mark.parametrize("rows_pad,N,K,splits", [(16, 128, 256, 1), (16, 4096, 4096, 4), (32, 1024, 768, 3), (64, 12288, 4096, 2), (48, 12288, 4096, 2), (48, 4096, 11008, 8), (48, 256, 512, 1),
                                                  (64, 4096, 11008, 8), (64, 32000, 4096, 1), (32, 22016, 4096, 1), (16, 128, 2816, 11)])
 def test_gemm_matches_fp32_reference(dtype, tol, rows_pad, N, K, splits):
     g = torch.Generator(device="cuda").manual_seed(N + K + rows_pad)
@@ -42,7 +42,7 @@ def test_gemm_matches_fp32_reference(dtype, tol, rows_pad, N, K, splits):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("rows_pad,inter,K", [(16, 64, 256), (16, 11008, 4096), (32, 1408, 768), (64, 2816, 1024)])
+@pytest.mark.parametrize("rows_pad,inter,K", [(16, 64, 256), (16, 11008, 4096), (32, 1408, 768), (64, 2816, 1024), (48, 11008, 4096), (48, 192, 256)])
 def test_gemm_silu_epilogue_matches_reference(dtype, tol, rows_pad, inter, K):
     """samd_gemm_skinny_silu = LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) with the model dtype's roundings."""
     g = torch.Generator(device="cuda").manual_seed(inter + K + rows_pad)
@@ -73,7 +73,7 @@ def test_gemm_random_chunk_and_split_counts(seed):
         chunks = int(rng.integers(1, 21))
         K, N = 256 * chunks, 128 * int(rng.integers(1, 9))
         splits = int(rng.integers(1, chunks + 1))
-        rows_pad = int(rng.choice([16, 32, 64]))
+        rows_pad = int(rng.choice([16, 32, 48, 64]))
         dtype, tol = ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2))[int(rng.integers(0, 2))]
         g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
         A = torch.randn((rows_pad, K), generator=g, device="cuda").to(dtype)
@@ -103,7 +103,7 @@ def test_gemm_rejects_bad_shapes():
     o = torch.zeros((16, 128), device="cuda", dtype=torch.float16)
     ok = lambda *args: L.samd_gemm_skinny(samd_hip._ptr(a), samd_hip._ptr(w), *args, None, samd_hip._ptr(o), samd_hip.F16, None)
     assert ok(16, 128, 256, 1) == 0
-    assert ok(8, 128, 256, 1) != 0         # rows_pad must be 16 / 32 / 64
+    assert ok(8, 128, 256, 1) != 0         # rows_pad must be 16 / 32 / 48 / 64
     assert ok(16, 100, 256, 1) != 0        # N % 128
     assert ok(16, 128, 200, 1) != 0        # K % 256
     assert ok(16, 128, 256, 2) != 0        # more splits than chunks

@@ -427,10 +427,13 @@ def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
     assert (outs["wide"][5] - outs["chunked"][5]).abs().max().item() < 3e-2          # final-norm hidden states of every prompt token
 
 
-def test_attn_patch_dict_forward_is_a_drop_in_for_hf_attention():
+@pytest.mark.parametrize("impl,bool_mask", [("eager", False), ("sdpa", False), ("sdpa", True)])
+def test_attn_patch_dict_forward_is_a_drop_in_for_hf_attention(impl, bool_mask):
     """samd_sam_only.model_patch.attn_patch_dict (the reference's patch registry, model_patch/__init__.py:1-7): binding its
     LlamaAttention.forward keeps an HF model + SamdStaticCache producing HF's logits while a <= 64-row tree step runs on
-    samd_tree_attention (fp16 tolerance 3e-2 against the unpatched fp32 model)."""
+    samd_tree_attention (fp16 tolerance 3e-2 against the unpatched fp32 model).  With the HF default implementation (sdpa)
+    transformers hands the prompt pass NO mask (is_causal is left to SDPA): the patched forward must dispatch that pass the way HF
+    does, not to a mask-less eager product; the tree step's mask may also be boolean (True = attend)."""
     import types
     from transformers import DynamicCache
     from transformers.models.llama.modeling_llama import LlamaAttention
@@ -438,6 +441,7 @@ def test_attn_patch_dict_forward_is_a_drop_in_for_hf_attention():
     from samd_sam_only.model_patch import attn_patch_dict
     lm32 = tiny_llama(2, seed=21)
     lm = tiny_llama(2, seed=21).half()
+    lm.config._attn_implementation = impl
     rng = np.random.default_rng(21)
     prompt = rng.integers(3, 512, 50).tolist()
     n, L = 19, len(prompt)
@@ -474,5 +478,6 @@ def test_attn_patch_dict_forward_is_a_drop_in_for_hf_attention():
         lm(input_ids=ids, past_key_values=cache, use_cache=True, cache_position=torch.arange(L, device="cuda"))
         cache.set_length()
         got = lm(input_ids=torch.tensor([toks], device="cuda"), position_ids=torch.tensor([[L + d for d in depth]], device="cuda"),
-                 attention_mask=mask4d(torch.float16), past_key_values=cache, use_cache=True, cache_position=torch.arange(L, L + n, device="cuda")).logits[0]
+                 attention_mask=(mask4d(torch.float16) == 0) if bool_mask else mask4d(torch.float16), past_key_values=cache, use_cache=True,
+                 cache_position=torch.arange(L, L + n, device="cuda")).logits[0]
     assert calls and (got.float() - want).abs().max().item() < TOL

@@ -39,3 +39,27 @@ def random_parents(rng, n, shape):
         else:
             anc.append(int(rng.integers(0, i)))
     return anc
+
+
+def toy_tokenizer_dir(path, n_words=120):
+    """a word-level `transformers` tokenizer saved under `path` (what tools.gen_sam's --model_name points at); returns the words"""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    words = [f"w{i}" for i in range(n_words)]
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    for w in words:
+        vocab[w] = len(vocab)
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>").save_pretrained(path)
+    return words
+
+
+def toy_dialogues(rng, words, n=50):
+    """{"prompt", "response"} records over the toy vocabulary with shared phrases (so that the automaton has real structure)"""
+    phrases = [" ".join(words[int(j)] for j in rng.integers(0, len(words), int(rng.integers(3, 9)))) for _ in range(12)]
+    out = []
+    for _ in range(n):
+        pick = lambda k: " ".join(phrases[int(j)] for j in rng.integers(0, len(phrases), k))
+        out.append({"prompt": pick(int(rng.integers(1, 4))) + " ", "response": pick(int(rng.integers(1, 5)))})
+    return out
