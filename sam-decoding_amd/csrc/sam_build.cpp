@@ -269,6 +269,8 @@ void samd_static_free(samd_static_t *s) {
         if (s->d_text) (void)hipFree(s->d_text);
     }
     if (s->d_chain) (void)hipFree(s->d_chain);
+    if (s->d_root16) (void)hipFree(s->d_root16);
+    if (s->d_d1hash) (void)hipFree(s->d_d1hash);
     free(s);
 }
 

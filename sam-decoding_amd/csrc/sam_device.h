@@ -88,14 +88,19 @@ __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
     return w;
 }
 
+// position of the cursor's state in the ROOT-CHILD HASH (samd_common.h): valid (slots > 0) only while the cursor sits on the state it
+// reached through the root table
+struct RootChild { int base, slots; };
+__device__ __forceinline__ RootChild rootchild_none() { RootChild r; r.base = 0; r.slots = 0; return r; }
+
 template <int W>
-__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, ChainWord &cw) {
-    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); return 1; }
+__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, ChainWord &cw, RootChild &rc) {
+    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); rc.slots = 0; return 1; }
     {   // register path
         const unsigned next = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
         const unsigned term = W == 8 ? 0xFFFFu : 0xFFFFFFFFu;
         if (next != term && next == (unsigned)tok) {
-            idx += 1; len += 1;
+            idx += 1; len += 1; rc.slots = 0;
             if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
             else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
             // a FULL word used up: the run may go on -- fetch the new state's word now (one load) instead of finding out through
@@ -107,10 +112,31 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
     cw = chain_none();
     int visited = 0;
     bool hopped = false;
+    if (rc.slots) {
+        // on a high-degree child of the root, reached through the root table: ONE probe of its hashed block decides (all its edges are
+        // there).  No edge = the reference's visit of this state plus the hop to its suffix link, which is the root.
+        const uint32_t m = (uint32_t)rc.slots;
+        const SamEdge *tab = S.d1hash + rc.base;
+        uint32_t h = samd_spill_hash(tok, m);
+        int nx = -1;
+        for (uint32_t probes = 0; probes < m; probes++) {
+            const SamEdge e = tab[h];
+            if (e.tok == tok) { nx = e.dst; break; }
+            if (e.tok == -1) break;
+            h = (h + 1) & (m - 1);
+        }
+        rc.slots = 0;
+        if (nx >= 0) { idx = nx; len += 1; cw = chain_load(S, idx); return 1; }
+        visited = 1; idx = 0; len = 0; hopped = true;
+    }
     for (;;) {
         visited++;
         if (idx == 0) {
-            int nx = (tok < S.vocab) ? S.root_next[tok] : -1;
+            int nx = -1;
+            if (tok < S.vocab) {
+                if (S.root16) { const uint4 r = S.root16[tok]; nx = (int)r.x; rc.base = (int)r.y; rc.slots = nx >= 0 ? (int)r.z : 0; }
+                else nx = S.root_next[tok];
+            }
             // (no word is fetched for a landing through the root table: a depth-1 state is rarely left through its rank-0 edge --
             // measured 0.401 ms per launch with the fetch against 0.374 without)
             if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }

@@ -67,6 +67,16 @@ struct StaticDev {
     int32_t n_states, vocab, n_text, kind;
     const uint4 *chain;         // chain words (may be null: every transition then goes through the nodes)
     int32_t chain_w;            // tokens per chain word: 8 (u16) or 4 (u32)
+    // ROOT-CHILD HASH (device-only, derived at upload; may be null).  The states one token below the root are where a walk lands after
+    // every mismatch, and in a real corpus they have the highest degrees of the automaton (every token that ever followed t): resolving
+    // a transition there through the node costs its line, its tail and a probe of its spill block -- three dependent round trips, two
+    // HBM lines.  root16[tok] = {dst, base, slots, 0} extends the dense root table (root_next) by the position of a hashed block that
+    // holds ALL edges of dst (ranks 0..4 included; slots = power of two >= 2 x deg, samd_spill_hash, linear probing, empty = (-1,-1);
+    // slots = 0 for children of degree <= 5, which resolve inside their node line anyway).  A cursor that just landed through the root
+    // table carries (base, slots) and resolves its next token with ONE probe: found -> the edge; not found -> no edge at all, and the
+    // suffix link of a root child is the root (its shortest string has length 1), so the node is never loaded.
+    const uint4 *root16;
+    const SamEdge *d1hash;
 };
 
 // ---- session (per request) -------------------------------------------------------------------
@@ -129,6 +139,8 @@ struct samd_static {
     int uploaded;
     int borrowed;               // device image owned by the caller (samd_static_adopt_device)
     void *d_chain;              // chain words, derived on the device from d_nodes (always owned by the handle)
+    void *d_root16, *d_d1hash;  // root-child hash (StaticDev), derived with the chain words; owned by the handle
+    int64_t n_d1hash;           // its slots
 };
 
 // sam_kernels.hip: (re)derive the chain words from the device image; called by upload / adopt and lazily by the walks

@@ -81,6 +81,8 @@ _PROTOS = {
     "samd_static_adopt_device": (C.c_int, [_VP, _VP, _VP]),
     "samd_static_walk": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "samd_static_walk_counted": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
+    "samd_static_walk_streams": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
+    "samd_static_walk_streams_counted": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "samd_session_create": (C.c_int, [_I32, _VP]),
     "samd_session_free": (None, [_VP]),
     "samd_session_reset": (C.c_int, [_VP, _VP]),
@@ -348,6 +350,15 @@ class StaticAutomaton:
                                                  current_stream()))
         else:
             check(lib().samd_static_walk(self._h, _ptr(cursors), _ptr(tokens), B, T, int(commit), _ptr(trace), current_stream()))
+
+
+    def walk_streams(self, cursors, tokens, commit=True, trace=None, visited=None):
+        """cursors int32 [B,2] (cuda), tokens int32 [B,T] (cuda, stream-major); trace int32 [B,T,2]."""
+        B, T = tokens.shape
+        if visited is not None:
+            check(lib().samd_static_walk_streams_counted(self._h, _ptr(cursors), _ptr(tokens), B, T, int(commit), _ptr(visited), current_stream()))
+        else:
+            check(lib().samd_static_walk_streams(self._h, _ptr(cursors), _ptr(tokens), B, T, int(commit), _ptr(trace), current_stream()))
 
 
 class Session:

@@ -37,6 +37,24 @@ def draft_tuple(d):
 # --------------------------------------------------------------------------------------------------
 # static walk (batched, lane per stream)
 # --------------------------------------------------------------------------------------------------
+def check_stream_major_walk(prod, toks_tb, want_trace, want_cursors, want_visited=None, start=None):
+    """samd_static_walk_streams (stream-major tokens, decoupled lanes, cursors handed out inside a wave) must give the trace, the
+    final cursors and the visited-state count of the time-major kernel; lookup mode must leave the cursors alone."""
+    T, B = toks_tb.shape
+    toks_bt = torch.as_tensor(np.ascontiguousarray(np.asarray(toks_tb).T)).cuda()
+    cur = torch.zeros((B, 2), dtype=torch.int32, device="cuda") if start is None else start.clone()
+    trace = torch.full((B, T, 2), -7, dtype=torch.int32, device="cuda")
+    prod.walk_streams(cur, toks_bt, commit=True, trace=trace)
+    assert torch.equal(trace.permute(1, 0, 2).cpu(), torch.as_tensor(np.asarray(want_trace)).to(torch.int32)), "trace"
+    assert torch.equal(cur.cpu(), want_cursors.cpu()), "final cursors"
+    cur2 = torch.zeros((B, 2), dtype=torch.int32, device="cuda") if start is None else start.clone()
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.walk_streams(cur2, toks_bt, commit=False, visited=visited)
+    assert cur2.abs().sum().item() == 0 if start is None else torch.equal(cur2, start)
+    if want_visited is not None:
+        assert int(visited.item()) == want_visited
+
+
 def test_static_walk_golden(golden):
     for case in golden("sam_traces.json.gz")["static_so"]:
         sam = samd_hip.StaticAutomaton.build(case["docs"], case["eos"], 0).upload()
@@ -46,9 +64,10 @@ def test_static_walk_golden(golden):
         sam.walk(cur, dev(q).reshape(-1, 1), commit=True, trace=trace)
         assert trace[:, 0].cpu().tolist() == case["walk"], case["name"]
         assert cur[0].cpu().tolist() == case["walk"][-1]
+        check_stream_major_walk(sam, np.asarray(q, dtype=np.int32).reshape(-1, 1), trace.cpu().numpy(), cur)
 
 
-@pytest.mark.parametrize("vocab,B,T", [(6, 300, 40), (200, 1000, 64), (5000, 4096, 32), (70000, 2048, 32)])   # >= 65535: 4-token chain words
+@pytest.mark.parametrize("vocab,B,T", [(6, 300, 40), (200, 1000, 64), (5000, 4096, 32), (70000, 2048, 32), (200, 777, 13), (5000, 70000, 16)])   # >= 65535: 4-token chain words
 def test_static_walk_batched_vs_oracle(vocab, B, T):
     rng = np.random.default_rng(vocab)
     docs = [markov_stream(rng, 300, vocab=vocab) for _ in range(30)] + [[i] for i in range(vocab)]
@@ -79,6 +98,12 @@ def test_static_walk_batched_vs_oracle(vocab, B, T):
     before = cur.clone()
     prod.walk(cur, dev(toks), commit=False)
     assert torch.equal(cur, before)
+    # the stream-major kernel: same trace, cursors and visited-state count; also from non-root start cursors (a second pass)
+    check_stream_major_walk(prod, toks, got, cur, int(visited.item()))
+    trace2 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    cur3 = cur.clone()
+    prod.walk(cur3, dev(toks[::-1].copy()), commit=True, trace=trace2)
+    check_stream_major_walk(prod, toks[::-1].copy(), trace2.cpu().numpy(), cur3, start=cur)
 
 
 @pytest.mark.parametrize("base", [3, 66000])
@@ -108,6 +133,7 @@ def test_static_walk_long_runs_use_chain_words(base):
         for t in range(T):
             i, l = ora.transfer_state(i, l, int(toks[t, b]))
             assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (b, t)
+    check_stream_major_walk(prod, toks, got, cur)
 
 
 def test_static_walk_empty_and_ragged():
@@ -119,6 +145,13 @@ def test_static_walk_empty_and_ragged():
     assert cur.abs().sum().item() == 0
     # negative / huge token ids fall back to the root like an absent key
     prod.walk(cur, dev([[3, -1, 10 ** 9], [4, 3, 3]]))
+    assert cur.cpu().tolist() == [[2, 2], [1, 1], [1, 1]]
+    # the stream-major entry point: empty batch, no tokens, the same three streams
+    prod.walk_streams(torch.zeros((0, 2), dtype=torch.int32, device="cuda"), torch.zeros((0, 4), dtype=torch.int32, device="cuda"))
+    cur = torch.zeros((3, 2), dtype=torch.int32, device="cuda")
+    prod.walk_streams(cur, torch.zeros((3, 0), dtype=torch.int32, device="cuda"))
+    assert cur.abs().sum().item() == 0
+    prod.walk_streams(cur, dev([[3, 4], [-1, 3], [10 ** 9, 3]]))
     assert cur.cpu().tolist() == [[2, 2], [1, 1], [1, 1]]
 
 
