@@ -133,16 +133,7 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
     sam.walk(cursors, d_toks, commit=False, visited=visited)
     torch.cuda.synchronize()
     n_visited = int(visited.item())
-    ms_lockstep = hip_time_ms(lambda: sam.walk(cursors, d_toks, commit=False), iters)      # k_static_walk: time-major, lock-step lanes (r01/r02)
-    # the kernel that is priced: the same B x T transitions from stream-major tokens [B][T], lanes decoupled (k_static_walk_streams);
-    # it must visit exactly the same states
-    d_toks_bt = d_toks.t().contiguous()
-    visited.zero_()
-    sam.walk_streams(cursors, d_toks_bt, commit=False, visited=visited)
-    torch.cuda.synchronize()
-    if int(visited.item()) != n_visited:
-        raise SystemExit(f"walk kernels disagree on the visited states: {int(visited.item())} vs {n_visited}")
-    ms = hip_time_ms(lambda: sam.walk_streams(cursors, d_toks_bt, commit=False), iters)
+    ms = hip_time_ms(lambda: sam.walk(cursors, d_toks, commit=False), iters)
     alg_bytes = 16.0 * n_visited
     gbps = alg_bytes / (ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC passes of the same kernel and configuration (collected separately with
@@ -155,7 +146,7 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
             traffic = int(pmc["fetch_bytes_per_launch"] * pmc["fetch_size_correction"] + pmc["write_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
-    return dict(bound="hbm", kernel="k_static_walk_streams", lockstep_kernel_ms=round(ms_lockstep, 4), achieved=round(gbps, 2), peak=HBM_PEAK_GBPS, unit="GB/s",
+    return dict(bound="hbm", kernel="k_static_walk", achieved=round(gbps, 2), peak=HBM_PEAK_GBPS, unit="GB/s",
                 frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=traffic, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
                 visited_states=n_visited, alg_bytes_per_launch=int(alg_bytes), transitions_per_s=round(B * T / (ms * 1e-3), 1),
                 line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2),

@@ -123,9 +123,8 @@ int samd_static_walk_counted(const samd_static_t *sam, int32_t *d_cursors, const
                              int32_t commit, uint64_t *d_visited, void *stream);
 
 /* The same walk over STREAM-MAJOR tokens: d_tokens int32 [B][T] (stream b's tokens contiguous -- what a caller that holds B token
- * sequences has), d_trace (optional) int32 [B][T][2].  Results are identical to samd_static_walk's; the kernel behind it lets
- * every lane run its own transfer_state chain (no lock-step over the token index) and hands cursors out dynamically inside a
- * wavefront, which is what bench.py's `roofline` times (csrc/sam_kernels.hip, k_static_walk_streams).  -- SO/sam/static_sam.py:98-125 */
+ * sequences has), d_trace (optional) int32 [B][T][2].  Results are identical to samd_static_walk's: the token matrix is transposed
+ * on the device (and the trace back), then the same kernel runs.  -- SO/sam/static_sam.py:98-125 */
 int samd_static_walk_streams(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
                              int32_t commit, int32_t *d_trace, void *stream);
 int samd_static_walk_streams_counted(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,

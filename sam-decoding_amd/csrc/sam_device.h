@@ -169,6 +169,21 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
     }
 }
 
+// n committed transitions of one cursor (transfer_tokens, static_sam.py:118-120) -- the single-wavefront kernels' form: all lanes
+// run the same cursor (uniform addresses: one request per load), with the chain words and the root-child hash when the automaton
+// has them, so that a run of tokens that follows the corpus costs one load per 8 (4) tokens instead of one per token
+__device__ __forceinline__ void st_transfer_tokens(const StaticDev &S, int &idx, int &len, const int *toks, int n) {
+    if (S.chain && S.chain_w == 8) {
+        ChainWord cw = chain_none(); RootChild rc = rootchild_none();
+        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, idx, len, toks[i], cw, rc);
+    } else if (S.chain) {
+        ChainWord cw = chain_none(); RootChild rc = rootchild_none();
+        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, idx, len, toks[i], cw, rc);
+    } else {
+        for (int i = 0; i < n; i++) st_transfer(S, idx, len, toks[i]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dynamic automaton (single wavefront, uniform control flow)
 // reference: samd_sam_only/sam/dyn_sam.py:50-114 (identical in samd/sam/dyn_sam.py:41-97)
@@ -413,14 +428,19 @@ __device__ __forceinline__ int tree_draft(StepShared &sh, const StaticDev &S, in
         m++;
         if (m == n) break;
         // expand: the first min(K, 8, deg) successors in top-k order, one lane each
+        // everything whose address is known from the popped state goes out in ONE round trip: the node's words, this lane's inline edge
+        // and its child count from the top-k count table (samd_common.h); only a state of degree > 5 needs a second one (spill head)
         const int4 *np = reinterpret_cast<const int4 *>(S.nodes + sh.pop_idx);
         const int4 w1 = np[1];                                      // {aux = cnt_endpos, deg, e1}
+        const int le = lane < SAMD_INLINE_EDGES ? lane : 0;
+        const int2 ie = *reinterpret_cast<const int2 *>(reinterpret_cast<const int *>(np) + SAMD_EDGE_WORD(le));
+        const int sp = reinterpret_cast<const int *>(np)[14];
+        const int cnt_pre = S.topk_cnt ? S.topk_cnt[(size_t)sh.pop_idx * SAMD_TOPK + (lane & (SAMD_TOPK - 1))] : 0;
         int kk = w1.y < SAMD_TOPK ? w1.y : SAMD_TOPK; kk = kk < K ? kk : K;
         if (lane < kk) {
-            int tk, ds;
-            if (lane < SAMD_INLINE_EDGES) { const int *e = reinterpret_cast<const int *>(np) + SAMD_EDGE_WORD(lane); tk = e[0]; ds = e[1]; }
-            else { const int sp = reinterpret_cast<const int *>(np)[14]; const SamEdge ed = S.spill[sp + lane - SAMD_INLINE_EDGES]; tk = ed.tok; ds = ed.dst; }
-            sh.c_tok[lane] = tk; sh.c_dst[lane] = ds; sh.c_cnt[lane] = S.nodes[ds].aux;
+            int tk = ie.x, ds = ie.y;
+            if (lane >= SAMD_INLINE_EDGES) { const SamEdge ed = S.spill[sp + lane - SAMD_INLINE_EDGES]; tk = ed.tok; ds = ed.dst; }
+            sh.c_tok[lane] = tk; sh.c_dst[lane] = ds; sh.c_cnt[lane] = S.topk_cnt ? cnt_pre : S.nodes[ds].aux;
         }
         __syncthreads();
         if (lane == 0) {

@@ -17,6 +17,7 @@ static inline StaticDev static_view(const samd_static_t *s) {
     v.n_states = (int32_t)s->n_states; v.vocab = (int32_t)s->vocab; v.n_text = (int32_t)s->n_text; v.kind = s->kind;
     v.chain = (const uint4 *)s->d_chain; v.chain_w = s->vocab < 65535 ? 8 : 4;
     v.root16 = (const uint4 *)s->d_root16; v.d1hash = (const SamEdge *)s->d_d1hash;
+    v.topk_cnt = (const int32_t *)s->d_topk_cnt;
     return v;
 }
 
@@ -55,198 +56,6 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
     if (visited_total) {
         for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
         if ((threadIdx.x & 63) == 0 && visited) atomicAdd(visited_total, visited);
-    }
-}
-
-// ================================================================================================
-// batched walk, STREAM-MAJOR tokens, lanes decoupled (round 3).  scripts/walk_sched_sim.py replays bench.py's workload through
-// st_transfer_chain's rule: a lane needs 21.6 dependent memory rounds for its 16 tokens on average, but a wave of k_static_walk
-// (lock-step: at every token all 64 lanes wait for the slowest) spends 82 -- and even fully decoupled lanes leave the wave waiting
-// for its slowest LANE (49 rounds).  So here (a) a lane is a little state machine -- per loop iteration it advances on its chain
-// word as far as registers allow, then issues at most ONE memory request group (root-table entry | node word 0 | node words 1-3 |
-// two spill slots | chain word), all lanes wait ONCE, and each interprets what it asked for; (b) a wave owns a contiguous range of
-// cursors and a lane that finishes one takes the next (wave-uniform counter, ballot rank -- no atomics), so every lane stays busy
-// until the range is used up; (c) a cursor's tokens are read 16 at a time as ONE 64-byte line (stream-major [B][T], what a caller
-// that holds B token sequences has anyway), requested one window ahead and parked in LDS, so no lane ever waits for tokens.
-// The transitions, the visited-state count and the chain-word fetch rule are st_transfer_chain's, statement for statement.
-// ================================================================================================
-enum { N_NONE = 0, N_ROOT, N_NODE, N_TAIL, N_SPILL, N_CHAIN };
-#define WALK_WIN 16            // tokens per window = one 64-byte line of a stream-major token row
-
-template <int W, bool TRACE>
-__global__ __launch_bounds__(256) void k_static_walk_streams(StaticDev S, int32_t *__restrict__ cursors, const int32_t *__restrict__ tokens,
-                                                             int B, int T, int commit, int32_t *__restrict__ trace,
-                                                             unsigned long long *__restrict__ visited_total, int per_wave) {
-    __shared__ int tokwin[4][WALK_WIN][64];                  // [wave][slot][lane]: any slots of 64 lanes = 64 different 4-byte columns
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long wg = (long long)blockIdx.x * 4 + wave;
-    long long next = wg * per_wave;                          // wave-uniform: first cursor nobody has taken yet
-    long long c_end = next + per_wave; c_end = c_end < B ? c_end : B;
-    int (*win)[64] = tokwin[wave];
-    const int32_t *tok_last = tokens + ((size_t)B * T - WALK_WIN);      // last address a 64-byte window load may start at (the launcher checks B * T >= 16)
-    const int root_last = S.vocab - 4;                       // (the launcher sends vocabularies < 4 to the lock-step kernel)
-
-    int b = -1, t = 0, wend = 0, idx = 0, len = 0, tok = 0, need = N_NONE, lnk = 0;
-    bool hopped = false;
-    ChainWord cw = chain_none();
-    int sp_base = 0, sp_h = 0, sp_m = 4, sp_probes = 0, root_at = 0;
-    // the window requested ahead: cursor nb, tokens [nt0, nt0 + 16) of it, and its stored cursor
-    bool have_next = false, want_prefetch = true;
-    int nb = -1, nt0 = 0, nshift = 0;
-    uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
-    int2 pc = make_int2(0, 0);
-    unsigned long long visited = 0;
-    const unsigned term = W == 8 ? 0xFFFFu : 0xFFFFFFFFu;
-
-    auto emit = [&]() { if (TRACE) reinterpret_cast<int2 *>(trace)[(size_t)b * T + t] = make_int2(idx, len); t++; };
-
-    for (;;) {
-        // ---- A1. window switch (at most one per iteration) ------------------------------------------------------------------
-        if (need == N_NONE && (b < 0 || t == wend)) {
-            const bool cursor_done = b >= 0 && t == T;
-            if (cursor_done && commit) reinterpret_cast<int2 *>(cursors)[b] = make_int2(idx, len);
-            if (have_next && nb >= 0) {
-                // slot j holds token nt0 + j; a window loaded `nshift` tokens early (end of the matrix) has it at position j + nshift
-                const int sh = nshift;
-                win[(0 - sh) & 15][lane] = (int)p0.x; win[(1 - sh) & 15][lane] = (int)p0.y; win[(2 - sh) & 15][lane] = (int)p0.z; win[(3 - sh) & 15][lane] = (int)p0.w;
-                win[(4 - sh) & 15][lane] = (int)p1.x; win[(5 - sh) & 15][lane] = (int)p1.y; win[(6 - sh) & 15][lane] = (int)p1.z; win[(7 - sh) & 15][lane] = (int)p1.w;
-                win[(8 - sh) & 15][lane] = (int)p2.x; win[(9 - sh) & 15][lane] = (int)p2.y; win[(10 - sh) & 15][lane] = (int)p2.z; win[(11 - sh) & 15][lane] = (int)p2.w;
-                win[(12 - sh) & 15][lane] = (int)p3.x; win[(13 - sh) & 15][lane] = (int)p3.y; win[(14 - sh) & 15][lane] = (int)p3.z; win[(15 - sh) & 15][lane] = (int)p3.w;
-                if (nt0 == 0) { idx = pc.x; len = pc.y; cw = chain_none(); }
-                b = nb; t = nt0; wend = nt0 + WALK_WIN < T ? nt0 + WALK_WIN : T;
-                have_next = false; want_prefetch = true;
-            } else if (have_next || b < 0 || cursor_done) { b = -1; have_next = false; }     // range used up / nothing requested yet
-        }
-        // ---- A2. advance without memory: negative tokens and chain-word transitions, up to the window's end -------------------
-#pragma unroll 1
-        for (int s = 0; s <= W; s++) {
-            if (need != N_NONE || b < 0 || t == wend) break;
-            tok = win[t & (WALK_WIN - 1)][lane];
-            if (tok < 0) { idx = 0; len = 0; cw = chain_none(); visited++; emit(); continue; }    // no state has an edge on a negative token
-            const unsigned nx = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
-            if (nx != term && nx == (unsigned)tok) {                                             // register path of st_transfer_chain
-                idx += 1; len += 1; visited++;
-                if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
-                else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
-                emit();
-                if (++cw.used == W) need = N_CHAIN;
-                continue;
-            }
-            cw = chain_none(); hopped = false;
-            need = idx == 0 ? N_ROOT : N_NODE;
-        }
-        if (__ballot(b >= 0 || have_next || want_prefetch) == 0ull) break;       // every lane idle, nothing in flight
-
-        // ---- B. issue: every lane one 16-byte request (idle lanes re-read a line they hold), tails and windows on top -----------
-        // Branch-free on purpose: loads inside divergent branches make the compiler's wait-count pass put a full wait in front of
-        // each of them (first version of this kernel: 11 vmcnt(0) per iteration, 0.73 ms per launch).
-        const uint4 *a0 = reinterpret_cast<const uint4 *>(S.nodes + idx);
-        if (need == N_ROOT) {
-            int g = (tok < S.vocab ? tok : 0) & ~3; g = g < root_last ? g : root_last;
-            root_at = g; a0 = reinterpret_cast<const uint4 *>(S.root_next + g);
-        }
-        a0 = need == N_TAIL ? a0 + 1 : a0;
-        // two adjacent slots of the hashed block per request; at the block's last slot the pair is (last - 1, last): never past the end
-        a0 = need == N_SPILL ? reinterpret_cast<const uint4 *>(S.spill + sp_base + SAMD_SPILL_HEAD + (sp_h + 1 < sp_m ? sp_h : sp_h - 1)) : a0;
-        a0 = need == N_CHAIN ? S.chain + idx : a0;
-        const uint4 ld0 = *a0;
-        uint4 ld1 = make_uint4(0, 0, 0, 0), ld2 = ld1;
-        if (__ballot(need == N_TAIL) != 0ull) {               // wave-uniform
-            const uint4 *a1 = need == N_TAIL ? a0 + 1 : a0, *a2 = need == N_TAIL ? a0 + 2 : a0;
-            ld1 = *a1; ld2 = *a2;
-        }
-        {
-            // next window of the same cursor, or the first window of a new one (rank among the lanes that ask now)
-            const bool same = want_prefetch && b >= 0 && wend < T;
-            const bool fresh = want_prefetch && !same;
-            const unsigned long long fm = __ballot(fresh);
-            if (__ballot(want_prefetch) != 0ull) {            // wave-uniform
-                int qb = nb, qt = nt0;
-                if (same) { qb = b; qt = wend; }
-                else if (fresh) {
-                    const long long mine = next + __popcll(fm & ((1ull << lane) - 1ull));
-                    qb = mine < c_end ? (int)mine : -1; qt = 0;
-                }
-                const int rb = qb >= 0 ? qb : 0;
-                const int32_t *row = tokens + (size_t)rb * T + qt;
-                // a window that would run past the end of the token matrix (the last cursor's last window) is read from the last 64
-                // bytes of the matrix instead and rotated into place when it is written to LDS (`shift` slots)
-                const int32_t *r0 = row <= tok_last ? row : tok_last;
-                if (want_prefetch) {
-                    nshift = (int)(row - r0);
-                    if ((T & 3) == 0) {
-                        p0 = *reinterpret_cast<const uint4 *>(r0); p1 = *reinterpret_cast<const uint4 *>(r0 + 4);
-                        p2 = *reinterpret_cast<const uint4 *>(r0 + 8); p3 = *reinterpret_cast<const uint4 *>(r0 + 12);
-                    } else {                                  // rows that are not 16-byte aligned: 4-byte loads
-                        p0 = make_uint4(r0[0], r0[1], r0[2], r0[3]); p1 = make_uint4(r0[4], r0[5], r0[6], r0[7]);
-                        p2 = make_uint4(r0[8], r0[9], r0[10], r0[11]); p3 = make_uint4(r0[12], r0[13], r0[14], r0[15]);
-                    }
-                    pc = reinterpret_cast<const int2 *>(cursors)[rb];
-                    nb = qb; nt0 = qt; have_next = true; want_prefetch = false;
-                }
-            }
-            next += __popcll(fm);
-        }
-
-        // ---- C. interpret (one wait for everything issued above) ----------------------------------------------------------------
-        if (need == N_CHAIN) {
-            cw.lo = (unsigned long long)ld0.x | ((unsigned long long)ld0.y << 32);
-            cw.hi = (unsigned long long)ld0.z | ((unsigned long long)ld0.w << 32);
-            cw.used = 0; need = N_NONE;
-        } else if (need != N_NONE) {
-            int found = -1;                      // >= 0: edge target; -2: no edge here, follow the suffix link
-            bool chain_after = false;
-            if (need == N_ROOT) {
-                visited++;
-                const int k = tok - root_at;
-                int nx = k == 0 ? (int)ld0.x : (k == 1 ? (int)ld0.y : (k == 2 ? (int)ld0.z : (int)ld0.w));
-                nx = tok < S.vocab ? nx : -1;
-                if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
-                emit(); need = N_NONE;            // (no chain word after a landing through the root table: st_transfer_chain)
-            } else if (need == N_NODE) {
-                visited++;
-                if (hopped) len = (int)ld0.y & SAMD_LEN_MASK;
-                lnk = (int)ld0.x;
-                if ((int)ld0.z == tok) { found = (int)ld0.w; chain_after = ((int)ld0.y & SAMD_RUN) != 0; }
-                else if (!((int)ld0.y & SAMD_SINGLE)) need = N_TAIL;
-                else found = -2;
-            } else if (need == N_TAIL) {
-                int nx = -1;
-                nx = ((int)ld0.z == tok) ? (int)ld0.w : nx;       // w1 = {aux, deg, e1}
-                nx = ((int)ld1.x == tok) ? (int)ld1.y : nx;       // w2 = {e2, e3}
-                nx = ((int)ld1.z == tok) ? (int)ld1.w : nx;
-                nx = ((int)ld2.x == tok) ? (int)ld2.y : nx;       // w3 = {e4, spill, reserved}
-                if (nx < 0 && (int)ld0.y > SAMD_INLINE_EDGES) {
-                    sp_base = (int)ld2.z; sp_m = (int)samd_spill_slots((int)ld0.y); sp_h = (int)samd_spill_hash(tok, (uint32_t)sp_m); sp_probes = 0;
-                    need = N_SPILL;
-                } else { found = nx >= 0 ? nx : -2; chain_after = true; }
-            } else {                                              // N_SPILL: slots sp_h and sp_h + 1 of the open-addressing block
-                const bool second = sp_h + 1 < sp_m;
-                const int t0 = second ? (int)ld0.x : (int)ld0.z, d0 = second ? (int)ld0.y : (int)ld0.w, t1 = (int)ld0.z, d1 = (int)ld0.w;
-                if (t0 == tok) found = d0;
-                else if (t0 == -1) found = -2;
-                else if (second && t1 == tok) found = d1;
-                else if (second && t1 == -1) found = -2;
-                else {
-                    sp_probes += second ? 2 : 1;
-                    sp_h = (sp_h + (second ? 2 : 1)) & (sp_m - 1);
-                    if (sp_probes >= sp_m) found = -2;
-                }
-                chain_after = true;
-            }
-            if (found >= 0) {                                     // "edge found: follow, length + 1"
-                idx = found; len += 1; emit();
-                need = (chain_after && idx > 0) ? N_CHAIN : N_NONE;
-            } else if (found == -2) {                             // "state <- link, length <- states[link].length"
-                idx = lnk; hopped = true;
-                if (idx == 0) len = 0;
-                need = idx == 0 ? N_ROOT : N_NODE;
-            }
-        }
-    }
-    if (visited_total) {
-        for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
-        if (lane == 0 && visited) atomicAdd(visited_total, visited);
     }
 }
 
@@ -346,7 +155,7 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         dyn_add_tokens(D, sh.accepted, a);
         if (A.have_static) {
             int is = D.meta[M_ST_IDX], ms = D.meta[M_ST_LEN];
-            for (int i = 0; i < a; i++) st_transfer(S, is, ms, sh.accepted[i]);
+            st_transfer_tokens(S, is, ms, sh.accepted, a);
             if (lane == 0) { D.meta[M_ST_IDX] = is; D.meta[M_ST_LEN] = ms; }
         }
         wave_mem_sync();
@@ -361,7 +170,7 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
     }
     if (A.ops & OP_ST_WALK) {
         int is = D.meta[M_ST_IDX], ms = D.meta[M_ST_LEN];
-        if (A.have_static) for (int i = 0; i < n_in; i++) st_transfer(S, is, ms, A.tokens[i]);
+        if (A.have_static) st_transfer_tokens(S, is, ms, A.tokens, n_in);
         else if (n_in > 0) { is = 0; ms = 0; }
         if (A.commit && lane == 0) { D.meta[M_ST_IDX] = is; D.meta[M_ST_LEN] = ms; }
         if (A.out2 && lane == 0) { A.out2[0] = is; A.out2[1] = ms; }
@@ -458,6 +267,30 @@ __global__ __launch_bounds__(64) void k_scripted_argmax(SessionDev D, const int3
     out[i] = res;
 }
 
+// stream-major entry points: d_tokens int32 [B][T] (what a caller that holds B token sequences has), d_trace int32 [B][T][2].  The walk
+// kernel wants time-major tokens (a wavefront's 64 lanes then read 256 contiguous bytes per token index), so the matrix is transposed
+// on the device first (LDS tiles, both sides coalesced: ~25 us for 2^20 x 16) and the trace back afterwards.  A kernel that reads
+// stream-major rows directly -- lanes decoupled, one flattened state machine per lane, cursors handed out dynamically inside a wave --
+// was built and measured in round 3 (commit af39a33, profiles/r03_walk.md): identical results, but 2.6x the instructions and 0.57 ms
+// per launch against 0.33 ms for this path.
+template <int WIDTH>
+__global__ __launch_bounds__(256) void k_transpose_i32(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int rows, int cols) {   // dst[c][r] = src[r][c]
+    __shared__ int32_t tile[WIDTH][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;             // 32 x 8 threads, 32 x 32 tile
+    const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const long long r = r0 + j, c = c0 + tx;
+        if (r < rows && c < cols)
+            for (int k = 0; k < WIDTH; k++) tile[k][j][tx] = src[((size_t)r * cols + c) * WIDTH + k];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const long long c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols)
+            for (int k = 0; k < WIDTH; k++) dst[((size_t)c * rows + r) * WIDTH + k] = tile[k][tx][j];
+    }
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -536,6 +369,27 @@ __global__ __launch_bounds__(256) void k_d1_fill(const SamNode *__restrict__ nod
     for (uint32_t k = 0; k < SAMD_SPILL_HEAD + slots; k++) put(sp[k].tok, sp[k].dst);
 }
 
+// top-k counts (samd_common.h): one thread per (state, rank)
+__global__ __launch_bounds__(256) void k_topk_counts(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, long long n_states, int32_t *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_states * SAMD_TOPK) return;
+    const long long s = i / SAMD_TOPK; const int k = (int)(i % SAMD_TOPK);
+    const int *w = reinterpret_cast<const int *>(nodes + s);
+    int dst = -1;
+    if (k < w[5]) dst = k < SAMD_INLINE_EDGES ? w[SAMD_EDGE_WORD(k) + 1] : spill[w[14] + k - SAMD_INLINE_EDGES].dst;
+    out[i] = dst >= 0 ? nodes[dst].aux : 0;
+}
+
+static int derive_topk_counts(samd_static_t *s, hipStream_t st) {
+    static const bool enabled = [] { const char *e = getenv("SAMD_TOPK_COUNTS"); return !(e && e[0] == '0'); }();       // A/B switch, read once
+    if (!enabled || s->kind != SAMD_KIND_COUNT) return SAMD_OK;
+    const long long n = (long long)s->n_states * SAMD_TOPK;
+    if (!s->d_topk_cnt && hipMalloc(&s->d_topk_cnt, (size_t)n * 4) != hipSuccess) { s->d_topk_cnt = nullptr; samd_set_error("hipMalloc(top-k counts) failed"); return SAMD_E_HIP; }
+    hipLaunchKernelGGL(k_topk_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s->d_nodes, s->d_spill, (long long)s->n_states, (int32_t *)s->d_topk_cnt);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { samd_set_error("top-k count derivation failed"); return SAMD_E_HIP; }
+    return SAMD_OK;
+}
+
 static int derive_root_hash(samd_static_t *s, hipStream_t st) {
     static const bool enabled = [] { const char *e = getenv("SAMD_ROOT_HASH"); return !(e && e[0] == '0'); }();      // A/B switch, read once
     if (!enabled || s->vocab < 1 || s->vocab > (1 << 24)) return SAMD_OK;
@@ -584,7 +438,8 @@ int samd_static_derive_chain(samd_static_t *s, void *stream) {
     else hipLaunchKernelGGL(k_build_chain<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
     LAUNCHCHK();
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { samd_set_error("chain-word derivation failed"); return SAMD_E_HIP; }
-    return derive_root_hash(s, (hipStream_t)stream);
+    const int rc = derive_root_hash(s, (hipStream_t)stream);
+    return rc != SAMD_OK ? rc : derive_topk_counts(s, (hipStream_t)stream);
 }
 
 int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
@@ -609,51 +464,21 @@ int samd_static_walk_counted(const samd_static_t *sam, int32_t *d_cursors, const
     return SAMD_OK;
 }
 
-// fewer than 16 tokens in all, or a vocabulary below 4 ids: the lock-step kernel on a time-major copy (B * T < 16 elements, or a toy automaton)
-__global__ void k_transpose_small(const int32_t *src, int32_t *dst, int rows, int cols, int width) {      // dst[c][r] = src[r][c], `width` ints per element
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int r = i / cols, c = i % cols;
-    for (int k = 0; k < width; k++) dst[((size_t)c * rows + r) * width + k] = src[((size_t)r * cols + c) * width + k];
-}
-static int walk_streams_small(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T, int32_t commit,
-                              int32_t *d_trace, uint64_t *d_visited, void *stream) {
-    hipStream_t st = (hipStream_t)stream;
-    int32_t *tm = nullptr, *tr = nullptr;
-    const size_t n = (size_t)B * T;
-    if (hipMallocAsync((void **)&tm, n * 4, st) != hipSuccess) { samd_set_error("samd_static_walk_streams: scratch allocation failed"); return SAMD_E_HIP; }
-    if (d_trace && hipMallocAsync((void **)&tr, n * 8, st) != hipSuccess) { (void)hipFreeAsync(tm, st); samd_set_error("samd_static_walk_streams: scratch allocation failed"); return SAMD_E_HIP; }
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_transpose_small, dim3(blocks), dim3(256), 0, st, d_tokens, tm, B, T, 1);
-    launch_walk(sam, (B + 255) / 256, 256, st, d_cursors, tm, B, T, commit, tr, (unsigned long long *)d_visited);
-    if (d_trace) hipLaunchKernelGGL(k_transpose_small, dim3(blocks), dim3(256), 0, st, tr, d_trace, T, B, 2);
-    (void)hipFreeAsync(tm, st);
-    if (tr) (void)hipFreeAsync(tr, st);
-    LAUNCHCHK();
-    return SAMD_OK;
-}
-
-// stream-major form: d_tokens int32 [B][T], d_trace int32 [B][T][2]; lanes decoupled, cursors handed out dynamically inside a wave
 static int walk_streams(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T, int32_t commit,
                         int32_t *d_trace, uint64_t *d_visited, void *stream) {
     if (!sam || !sam->uploaded || B < 0 || T < 0) { samd_set_error("samd_static_walk_streams: invalid argument"); return SAMD_E_INVALID; }
     if (B == 0 || T == 0) return SAMD_OK;
     if (!d_cursors || !d_tokens) { samd_set_error("samd_static_walk_streams: null pointer"); return SAMD_E_INVALID; }
-    if (!sam->d_chain) { samd_set_error("samd_static_walk_streams: chain words missing (upload / adopt derives them)"); return SAMD_E_INVALID; }
-    if (sam->vocab < 4 || (long long)B * T < 16) return walk_streams_small(sam, d_cursors, d_tokens, B, T, commit, d_trace, d_visited, stream);
-    // cursors per wave: enough waves to fill the chip a few times over (256 CUs x 32 wave slots), each with several cursors per lane
-    // so that the dynamic hand-out has something to balance; SAMD_WALK_PER_WAVE overrides (read once)
-    static const int env_pw = [] { const char *e = getenv("SAMD_WALK_PER_WAVE"); return e ? atoi(e) : 0; }();
-    int per_wave = env_pw > 0 ? env_pw : 256;
-    while (per_wave > 64 && env_pw <= 0 && (long long)(B + per_wave - 1) / per_wave < 4096) per_wave >>= 1;
-    const long long waves = ((long long)B + per_wave - 1) / per_wave;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
-    const StaticDev v = static_view(sam);
-#define GO(WW, TR) hipLaunchKernelGGL((k_static_walk_streams<WW, TR>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, d_cursors, d_tokens, B, T, commit, d_trace, \
-                                      (unsigned long long *)d_visited, per_wave)
-    if (v.chain_w == 8) { if (d_trace) GO(8, true); else GO(8, false); }
-    else { if (d_trace) GO(4, true); else GO(4, false); }
-#undef GO
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *tm = nullptr, *tr = nullptr;
+    const size_t n = (size_t)B * T;
+    if (hipMallocAsync((void **)&tm, n * 4, st) != hipSuccess) { samd_set_error("samd_static_walk_streams: scratch allocation failed"); return SAMD_E_HIP; }
+    if (d_trace && hipMallocAsync((void **)&tr, n * 8, st) != hipSuccess) { (void)hipFreeAsync(tm, st); samd_set_error("samd_static_walk_streams: scratch allocation failed"); return SAMD_E_HIP; }
+    hipLaunchKernelGGL(k_transpose_i32<1>, dim3((T + 31) / 32, (B + 31) / 32), dim3(256), 0, st, d_tokens, tm, B, T);
+    launch_walk(sam, (B + 255) / 256, 256, st, d_cursors, tm, B, T, commit, tr, (unsigned long long *)d_visited);
+    if (d_trace) hipLaunchKernelGGL(k_transpose_i32<2>, dim3((B + 31) / 32, (T + 31) / 32), dim3(256), 0, st, tr, d_trace, T, B);
+    (void)hipFreeAsync(tm, st);
+    if (tr) (void)hipFreeAsync(tr, st);
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -77,6 +77,10 @@ struct StaticDev {
     // suffix link of a root child is the root (its shortest string has length 1), so the node is never loaded.
     const uint4 *root16;
     const SamEdge *d1hash;
+    // TOP-K COUNTS (device-only, derived at upload; may be null): topk_cnt[8 s + k] = cnt_endpos of state s's rank-k successor, the
+    // numerators of the best-first tree's child probabilities (static_sam.py:205-210).  Without it an expansion is two dependent round
+    // trips (the parent's node for the edges, then the children's nodes for their counts); with it one.
+    const int32_t *topk_cnt;
 };
 
 // ---- session (per request) -------------------------------------------------------------------
@@ -140,6 +144,7 @@ struct samd_static {
     int borrowed;               // device image owned by the caller (samd_static_adopt_device)
     void *d_chain;              // chain words, derived on the device from d_nodes (always owned by the handle)
     void *d_root16, *d_d1hash;  // root-child hash (StaticDev), derived with the chain words; owned by the handle
+    void *d_topk_cnt;           // top-k counts (StaticDev), KIND_COUNT only; owned by the handle
     int64_t n_d1hash;           // its slots
 };
 

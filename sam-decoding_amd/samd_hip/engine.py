@@ -194,6 +194,27 @@ class DecodeEngine:
         self.verifier.compact(self.session)
         self.session.report_async(self.report_buf)
 
+    def _ingest_beside(self, ids, prefill):
+        """DraftModel.update(prompt) -- dyn add_tokens + static transfer_tokens (SO/draft.py:62-67; 2.8 us per token, one wavefront) --
+        on a second stream WHILE the LM prefills the prompt: the two touch disjoint state (automata + cursors vs KV cache, cache length,
+        start token), and the first lookup waits for both.  SAMD_INGEST_STREAM=0: serially on the decode stream, as round 2 did."""
+        s = self.session
+        cur = torch.cuda.current_stream()
+        if os.environ.get("SAMD_INGEST_STREAM", "1") == "0":
+            prefill()
+            s.add_tokens(ids)
+            s.static_walk(self.static, ids, ids.numel(), commit=True)
+            return
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(cur)                           # the session reset and `ids` are ordered before the ingest
+        with torch.cuda.stream(self._side):
+            s.add_tokens(ids)
+            s.static_walk(self.static, ids, ids.numel(), commit=True)
+        ids.record_stream(self._side)
+        prefill()
+        cur.wait_stream(self._side)
+
     # ---- public ---------------------------------------------------------------------------------------
     def start(self, input_ids):
         """DraftModel.reset + SamdModel.prefill (SO/samd_model.py:96-114) + the first lookup of the decode loop."""
@@ -203,9 +224,7 @@ class DecodeEngine:
         if self.recycle is not None:
             on_chunk = lambda toks, logits, n, hidden: self._recycle_update(toks, logits, n, None)
         ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
-        self.verifier.prefill(s, ids, on_chunk)
-        s.add_tokens(ids)                                    # DraftModel.update(prompt): dyn add_tokens ...
-        s.static_walk(self.static, ids, ids.numel(), commit=True)     # ... and static transfer_tokens (SO/draft.py:62-67)
+        self._ingest_beside(ids, lambda: self.verifier.prefill(s, ids, on_chunk))
         s.draft(self.static, self.params, self._views["start_token"])
         if self.recycle is not None:
             self._install_tree()
@@ -287,9 +306,7 @@ class TreeModelEngine(DecodeEngine):
         self.tm.reset()
         ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
         hidden = []
-        self.verifier.prefill(s, ids, lambda toks, logits, n, h: hidden.append(h[:n].clone()))
-        s.add_tokens(ids)
-        s.static_walk(self.static, ids, ids.numel(), commit=True)
+        self._ingest_beside(ids, lambda: self.verifier.prefill(s, ids, lambda toks, logits, n, h: hidden.append(h[:n].clone())))
         self.tm.update(tokens=ids.to(torch.long), last_hidden_states=torch.cat(hidden, dim=0))
         s.draft(self.static, self.params, self._views["start_token"])
         return self._maybe_tree(self._report())
