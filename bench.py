@@ -335,6 +335,15 @@ def named_breakdown(model, lm, prompt, n_steps=48):
             "non_lm_share": round(1.0 - tot[0] / max(sum(tot), 1e-9), 4)}
 
 
+def variant_projection(variant, ar_tps, ms_per_step):
+    """speed-up the measured step cost of a plugin variant would give at the mean accepted tokens the reference publishes for it"""
+    mat = {"token_recycle": 3.03, "eagle2": 4.62}.get(variant)
+    if mat is None:
+        return None
+    return {"published_mat": mat, "speedup": round(mat * (1e3 / ar_tps) / ms_per_step, 2),
+            "basis": "published mean accepted tokens (README.md:55-57) x this run's autoregressive step / this run's ms_per_step"}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def launch_command(n_gpus, argv, port=None):
     """the torch.distributed.run command line for N ranks of this script on one node (one process per GPU, RCCL over xGMI)."""
@@ -438,7 +447,10 @@ def main():
     # rank 0 builds the automaton; the other ranks receive the flat image over RCCL (north_star: shared static SAM broadcast)
     auto = samd_hip.StaticAutomaton.build_flat(flat, off, EOS, samd_hip.KIND_COUNT) if rank == 0 else None
     build_s = time.perf_counter() - t_setup
+    t_bc = time.perf_counter()
     auto = parallel.broadcast_static(auto, src=0) if world > 1 else auto.upload()
+    torch.cuda.synchronize()
+    broadcast_ms = (time.perf_counter() - t_bc) * 1e3          # world > 1: RCCL broadcast of the image + adopt; world 1: host -> HBM upload
     sam_info = auto.info()
     sam = SO.sam.StaticSAM._from_automaton(auto)
 
@@ -448,7 +460,8 @@ def main():
         mcfg["num_hidden_layers"] = args.layers
     max_len = mcfg["max_position_embeddings"]                 # 2048 (Vicuna) / 8192 (Llama-3): evaluation/inference_samd.py:152-163
     runner = LlamaRunner.random_init(mcfg, max_len, dtype, seed=0)
-    lm = ScriptedAcceptance(runner, VOCAB, max_len) if args.acceptance == "scripted" else runner
+    # Token Recycle learns from the top-8 of every verified row: its scripted model also ranks the source's continuations
+    lm = ScriptedAcceptance(runner, VOCAB, max_len, ranked_logits=args.variant == "token_recycle") if args.acceptance == "scripted" else runner
 
     if args.variant == "sam_only":
         samd_cfg = SO.SamdConfig(**cfg)
@@ -589,7 +602,15 @@ def main():
                        "hipgraphs": not args.no_graphs},
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
-            "per_rank": per_rank, "bucket_histogram": bucket_hist,
+            "per_rank": [dict(r, ms_per_step=round(r["seconds"] / args.steps * 1e3, 4)) for r in per_rank], "bucket_histogram": bucket_hist,
+            "static_sam_distribution": {"how": "RCCL broadcast from rank 0 + samd_static_adopt_device" if world > 1 else "host image -> HBM upload",
+                                        "ms": round(broadcast_ms, 2), "bytes": int(sam_info["device_bytes"])},
+            # samd[EAGLE2] / samd[EAGLE] run a RANDOM-INIT draft head (no EAGLE weights exist on the box): its drafts are noise, so
+            # `value` and `speedup_vs_ar` of such a run price the plugin PATH (head forwards + 63-node verify), they are not a result of
+            # the method.  What the path would deliver at the accepted-token counts the reference publishes (README.md:55-57) follows
+            # from this run's measured step time: speed-up = MAT x T_AR / T_step.
+            "cost_only": args.variant in ("eagle2", "eagle"),
+            "projected_speedup_of_this_variant": variant_projection(args.variant, ar_tps, dt_max / args.steps * 1e3),
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
             "step_breakdown_by_rows": breakdown, "step_breakdown_named": named,
             # SURVEY.md 8(d) end-to-end proxy: speed-up = accepted tokens x T_AR / T_step with THIS run's measured step times

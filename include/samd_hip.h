@@ -277,6 +277,12 @@ int samd_session_step(samd_session_t *s, const samd_static_t *sam, const samd_pa
  * residual flag, status (1 = ran out of uniforms)}.  Rounding follows torch on tensors of the same dtype. */
 int samd_posterior_sampled(const void *d_probs, int32_t dtype, const int64_t *d_candidates, int32_t n_candidates, int32_t depth, int64_t vocab,
                            const double *d_uniforms, int32_t n_uniforms, void *d_work, int32_t *d_out, void *stream);
+/* the same with ONE probability row per draft node instead of one per (candidate, position) cell: d_probs [n_rows][vocab], cell
+ * (row, position) reads node d_rowmap[row * depth + position] (the retrieve table, SO/samd_model.py:144; -1 = the last node).  The
+ * warpers then run over <= 64 rows instead of leaves x depth (a 60-leaf tree of depth 10: 600 top-p sorts before). */
+int samd_posterior_sampled_nodes(const void *d_probs, int32_t dtype, const int32_t *d_rowmap, int32_t n_rows, const int64_t *d_candidates,
+                                 int32_t n_candidates, int32_t depth, int64_t vocab, const double *d_uniforms, int32_t n_uniforms,
+                                 void *d_work, int32_t *d_out, void *stream);
 int samd_kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tensors, int32_t n_heads, int64_t max_len,
                     int32_t head_dim, int32_t elem_bytes, void *stream);
 
@@ -456,6 +462,13 @@ int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t
  * d_target int32[n_target]; d_out int32[64]. */
 int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_target, int32_t vocab, int32_t *d_out,
                          void *stream);
+
+/* the same hook for callers that learn from the logits (bench.py --variant token_recycle): on top of the model's own row of draft node
+ * i it writes the scripted arg-max as the best entry and, below it, the four successors of the node's two-token context in the bench's
+ * sparse order-2 Markov source (bench._succ) in rank order -- a model that continues the text also ranks its plausible continuations.
+ * d_argmax int32[64] (samd_scripted_argmax's output), d_logits [64][row_stride] of dtype.  Tests and bench only. */
+int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int64_t row_stride,
+                         int32_t markov_vocab, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token Recycle (S/tree_model/token_recycle/token_recycle.py:18-63)

@@ -291,6 +291,28 @@ __global__ __launch_bounds__(256) void k_transpose_i32(const int32_t *__restrict
     }
 }
 
+// scripted verifier, logits form (bench.py --variant token_recycle): besides the arg-max, a model that continues the text also RANKS
+// the plausible continuations -- which is what Token Recycle learns from (token_recycle.py:40-48: top-8 of every verified row).  For
+// draft node i with context (a, b) = (its parent's token | the last committed token, its own token) the row gets, on top of the model's
+// own logits: the scripted arg-max (samd_scripted_argmax) as the best entry, then the sparse order-2 Markov source's four successors of
+// (a, b) in rank order (bench._succ, the same hash) -- the distribution the synthetic corpus and requests are drawn from.
+template <typename T>
+__global__ __launch_bounds__(64) void k_scripted_logits(SessionDev D, const int32_t *__restrict__ argmax, T *__restrict__ logits, long long stride,
+                                                        int markov_vocab) {
+    const int i = blockIdx.x, n = D.dmeta[D_N];
+    if (i >= n || threadIdx.x > 4) return;
+    const int b = D.tokens[i], par = D.parent[i];
+    const int nc = D.meta[M_NTEXT] - 1;
+    const int a = par >= 0 ? D.tokens[par] : (nc > 0 ? D.text[nc] : 0);           // text[0] is the sentinel: text[nc] = last committed token
+    T *row = logits + (size_t)i * stride;
+    const int c = (int)threadIdx.x - 1;
+    if (c < 0) { row[argmax[i]] = (T)96.f; return; }
+    unsigned long long h = ((unsigned long long)(unsigned)a * 1000003ull + (unsigned long long)(unsigned)b * 10007ull + (unsigned long long)c * 7919ull + 12345ull) & 0x7FFFFFFFull;
+    h = (h * 2654435761ull) & 0xFFFFFFFFull;
+    const int tok = 3 + (int)(h % (unsigned long long)(markov_vocab - 3));
+    if (tok != argmax[i]) row[tok] = (T)(64.f - 4.f * (float)c);
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -738,6 +760,17 @@ int samd_session_get_cache_length(samd_session_t *s, int32_t *h_out, void *strea
 int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_target, int32_t vocab, int32_t *d_out, void *stream) {
     if (!s || !d_target || !d_out || n_target < 0 || vocab < 4) return SAMD_E_INVALID;
     hipLaunchKernelGGL(k_scripted_argmax, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, s->dev, d_target, n_target, vocab, d_out);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int64_t row_stride, int32_t markov_vocab, void *stream) {
+    if (!s || !d_argmax || !d_logits || markov_vocab < 4 || row_stride < markov_vocab) return SAMD_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_scripted_logits<_Float16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (_Float16 *)d_logits, (long long)row_stride, markov_vocab);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_scripted_logits<__bf16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (__bf16 *)d_logits, (long long)row_stride, markov_vocab);
+    else if (dtype == SAMD_F32) hipLaunchKernelGGL(k_scripted_logits<float>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (float *)d_logits, (long long)row_stride, markov_vocab);
+    else return SAMD_E_INVALID;
     LAUNCHCHK();
     return SAMD_OK;
 }

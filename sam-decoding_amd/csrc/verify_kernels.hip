@@ -830,7 +830,8 @@ __global__ __launch_bounds__(64) void k_recycle_draft(const int *__restrict__ ta
 // accumulated in fp32 and rounded to T, every quotient is rounded to T, r is compared in T.
 template <typename T>
 __global__ __launch_bounds__(1024) void k_posterior_sampled(const T *__restrict__ probs, const long long *__restrict__ cand, int C, int D, long long V,
-                                                            const double *__restrict__ uniforms, int n_uniforms, T *__restrict__ work, int *__restrict__ out) {
+                                                            const double *__restrict__ uniforms, int n_uniforms, T *__restrict__ work, int *__restrict__ out,
+                                                            const int *__restrict__ rowmap, int n_rows) {
     __shared__ long long prefix[64];
     __shared__ int seen[1024];
     __shared__ int s_action, s_tok, s_row, s_anchor;
@@ -854,7 +855,11 @@ __global__ __launch_bounds__(1024) void k_posterior_sampled(const T *__restrict_
         __syncthreads();
         const int anchor = s_anchor;
         if (anchor < 0) break;
-        const T *src = probs + ((size_t)anchor * D + (n_acc - 1)) * V;
+        // rowmap: probs holds one row per DRAFT NODE and cell (row, position) reads node rowmap[row * D + position]; -1 = the last
+        // node (the reference gathers logits[retrieve] with -1 entries, samd_model.py:144).  Without it: one row per cell.
+        size_t prow = (size_t)anchor * D + (n_acc - 1);
+        if (rowmap) { const int m = rowmap[prow]; prow = (size_t)(m < 0 || m >= n_rows ? n_rows - 1 : m); }
+        const T *src = probs + prow * V;
         for (long long i = tid; i < V; i += blockDim.x) work[i] = src[i];
         __syncthreads();
         int n_seen = 0, row = 0;
@@ -949,16 +954,22 @@ static int kv_compact(samd_session_t *s, void *const *d_tensors, int32_t n_tenso
 
 int samd_posterior_sampled(const void *d_probs, int32_t dtype, const int64_t *d_candidates, int32_t n_candidates, int32_t depth, int64_t vocab,
                            const double *d_uniforms, int32_t n_uniforms, void *d_work, int32_t *d_out, void *stream) {
-    if (!d_probs || !d_candidates || n_candidates < 1 || depth < 1 || depth > 64 || vocab < 1 || !d_uniforms || n_uniforms < 0 || !d_work || !d_out) {
+    return samd_posterior_sampled_nodes(d_probs, dtype, nullptr, 0, d_candidates, n_candidates, depth, vocab, d_uniforms, n_uniforms, d_work, d_out, stream);
+}
+
+int samd_posterior_sampled_nodes(const void *d_probs, int32_t dtype, const int32_t *d_rowmap, int32_t n_rows, const int64_t *d_candidates, int32_t n_candidates,
+                                 int32_t depth, int64_t vocab, const double *d_uniforms, int32_t n_uniforms, void *d_work, int32_t *d_out, void *stream) {
+    if (!d_probs || !d_candidates || n_candidates < 1 || depth < 1 || depth > 64 || vocab < 1 || !d_uniforms || n_uniforms < 0 || !d_work || !d_out ||
+        (d_rowmap && n_rows < 1)) {
         samd_set_error("samd_posterior_sampled: invalid argument (depth <= 64)"); return SAMD_E_INVALID;
     }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SAMD_F32) hipLaunchKernelGGL(k_posterior_sampled<float>, dim3(1), dim3(1024), 0, st, (const float *)d_probs, (const long long *)d_candidates, n_candidates, depth,
-                                              (long long)vocab, d_uniforms, n_uniforms, (float *)d_work, d_out);
+                                              (long long)vocab, d_uniforms, n_uniforms, (float *)d_work, d_out, d_rowmap, n_rows);
     else if (dtype == SAMD_F16) hipLaunchKernelGGL(k_posterior_sampled<_Float16>, dim3(1), dim3(1024), 0, st, (const _Float16 *)d_probs, (const long long *)d_candidates, n_candidates,
-                                                   depth, (long long)vocab, d_uniforms, n_uniforms, (_Float16 *)d_work, d_out);
+                                                   depth, (long long)vocab, d_uniforms, n_uniforms, (_Float16 *)d_work, d_out, d_rowmap, n_rows);
     else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_posterior_sampled<__bf16>, dim3(1), dim3(1024), 0, st, (const __bf16 *)d_probs, (const long long *)d_candidates, n_candidates,
-                                                    depth, (long long)vocab, d_uniforms, n_uniforms, (__bf16 *)d_work, d_out);
+                                                    depth, (long long)vocab, d_uniforms, n_uniforms, (__bf16 *)d_work, d_out, d_rowmap, n_rows);
     else { samd_set_error("samd_posterior_sampled: bad dtype"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;

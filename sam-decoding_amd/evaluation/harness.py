@@ -114,28 +114,36 @@ def get_model_answers(model, tokenizer, forward_func: Callable, model_id: str, q
 def run_eval(model, tokenizer, forward_func: Callable, model_id: str, question_file: str, question_begin: Optional[int],
              question_end: Optional[int], answer_file: str, max_new_tokens: int, num_choices: int = 1, template: str = "vicuna",
              **kwargs):
-    """eval_vicuna.py:20-69 with torch.distributed ranks in place of Ray actors."""
+    """eval_vicuna.py:20-69 with torch.distributed ranks in place of Ray actors: every rank answers a contiguous chunk of the
+    questions (parallel.shard_bounds = the reference's chunking), then the answer records and the accept lengths of all ranks are
+    ALL-GATHERED over the process group (RCCL on GPUs: the only collective of the whole evaluation -- BASELINE.json's north star) and
+    rank 0 writes the one answer file.  Every rank returns the accept lengths of ALL questions, in question order."""
     import torch.distributed as dist
-    from samd_hip.parallel import shard_bounds
+    from samd_hip.parallel import gather_results, shard_bounds
     questions = load_questions(question_file, question_begin, question_end)
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
     lo, hi = shard_bounds(len(questions), world, rank)
-    part = answer_file if world == 1 else f"{answer_file}.rank{rank}"
+    part = answer_file if world == 1 else f"{answer_file}.rank{rank}"       # a rank appends as it goes, like the reference's workers
     if world > 1 and os.path.exists(part):
         os.remove(part)
     accept = get_model_answers(model, tokenizer, forward_func, model_id, questions[lo:hi], part, max_new_tokens, num_choices,
                                template=template, **kwargs)
     if distributed:
-        dist.barrier()
+        lines = []
+        if os.path.exists(part):
+            with open(part) as fin:
+                lines = [ln.rstrip("\n") for ln in fin if ln.strip()]
+        records = gather_results([list(ln.encode("utf-8")) for ln in lines])      # per rank: its records as byte rows
+        accept_all = gather_results([list(accept)])
+        accept = [a for per_rank in accept_all for row in per_rank for a in row]
         if rank == 0:
             with open(answer_file, "a") as fout:
-                for r in range(world):
-                    p = f"{answer_file}.rank{r}"
-                    if os.path.exists(p):
-                        with open(p) as fin:
-                            fout.write(fin.read())
-                        os.remove(p)
+                for per_rank in records:
+                    for row in per_rank:
+                        fout.write(bytes(row).decode("utf-8") + "\n")
+        if os.path.exists(part):
+            os.remove(part)
         dist.barrier()
     if rank == 0 and os.path.exists(answer_file):
         reorg_answer_file(answer_file)

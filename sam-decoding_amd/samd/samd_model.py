@@ -108,7 +108,12 @@ class SamdModel(_SoSamdModel):
             candidate_logits = tree_logits.squeeze(0)[self.tree_retrieve_indices]
             candidate_hidden = tree_hidden.apply(lambda x: x[self.tree_retrieve_indices])
             candidate_indices = OptionalTensor(self.tree_retrieve_indices)
-        best_candidate, accept_length, sample_p = eval_posterior(candidate_logits, candidates.candidate_tokens, self.gen_config)
+        if self.gen_config.greedy:
+            best_candidate, accept_length, sample_p = eval_posterior(candidate_logits, candidates.candidate_tokens, self.gen_config)
+        else:                                   # sampling: warp the <= 64 node rows, read them through the retrieve table
+            from samd_sam_only.posterior import eval_posterior_nodes
+            best_candidate, accept_length, sample_p = eval_posterior_nodes(tree_logits.squeeze(0), candidate_indices.data,
+                                                                           candidates.candidate_tokens, self.gen_config)
         new_tokens = self.update_state(input_ids.squeeze(0), tree_logits.squeeze(0), best_candidate, accept_length,
                                        candidates.candidate_tokens, candidate_indices, candidate_hidden)
         self.lookup_stats[candidates.type.value][0] += 1

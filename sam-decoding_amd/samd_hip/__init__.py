@@ -101,6 +101,7 @@ _PROTOS = {
     "samd_session_report_async": (C.c_int, [_VP, _VP, _VP]),
     "samd_session_set_start_token": (C.c_int, [_VP, _VP, _VP]),
     "samd_scripted_argmax": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP]),
+    "samd_scripted_logits": (C.c_int, [_VP, _VP, _VP, _I32, _I64, _I32, _VP]),
     "samd_session_device_views": (C.c_int, [_VP, _VP]),
     "samd_tree_buffers": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_argmax_rows": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),
@@ -126,6 +127,7 @@ _PROTOS = {
     "samd_kv_compact_vt": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
     "samd_kv_compact_indices_vt": (C.c_int, [_VP, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_posterior_sampled": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I64, _VP, _I32, _VP, _VP, _VP]),
+    "samd_posterior_sampled_nodes": (C.c_int, [_VP, _I32, _VP, _I32, _VP, _I32, _I32, _I64, _VP, _I32, _VP, _VP, _VP]),
     "samd_e2_rowstats_workspace": (C.c_int64, [_I64]),
     "samd_e2_stage_extend": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _VP]),
     "samd_e2_rowstats": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _I64, _VP]),
@@ -423,6 +425,9 @@ class Session:
     def report_async(self, h_pinned):
         """enqueue the D2H copy of the per-step report block into a pinned int32[REPORT_INTS] tensor."""
         check(lib().samd_session_report_async(self._h, _ptr(h_pinned), current_stream()))
+
+    def scripted_logits(self, d_argmax, logits, markov_vocab):
+        check(lib().samd_scripted_logits(self._h, _ptr(d_argmax), _ptr(logits), torch_dtype_code(logits.dtype), logits.stride(0), markov_vocab, current_stream()))
 
     def scripted_argmax(self, d_target, n_target, vocab, d_out):
         check(lib().samd_scripted_argmax(self._h, _ptr(d_target), n_target, vocab, _ptr(d_out), current_stream()))

@@ -121,8 +121,11 @@ class ScriptedAcceptance:
     LM on its own decodes degenerate loops.  The target buffer has a fixed address and length so the step stays one
     hipGraph across requests."""
 
-    def __init__(self, runner, vocab, target_len):
+    def __init__(self, runner, vocab, target_len, ranked_logits=False):
         self.runner, self.vocab, self.target_len = runner, int(vocab), int(target_len)
+        # ranked_logits: the verify rows also carry the source's plausible continuations below the scripted arg-max
+        # (samd_scripted_logits) -- for plugins that learn from the logits (Token Recycle's top-8 table)
+        self.ranked_logits = bool(ranked_logits)
         self.target = torch.zeros(self.target_len, dtype=torch.int32, device=runner.device)
         self.pf_mask = runner.pf_mask
         self._prompt_len = 0
@@ -141,6 +144,8 @@ class ScriptedAcceptance:
     def verify(self, session, R):
         b = self.runner.verify(session, R)
         session.scripted_argmax(self.target, self.target_len, self.vocab, b["argmax"])
+        if self.ranked_logits:
+            session.scripted_logits(b["argmax"], b["logits"], self.vocab)
         return b
 
     def compact(self, session):

@@ -202,15 +202,31 @@ class LlamaRunner:
             return t.detach().to(device=dev, dtype=dtype).contiguous()
         m = lm.model
         layers = []
+        # The runner reads q|k|v and gate|up as ONE matrix each.  When the HF module already lives on this device in this dtype, its
+        # separate projection weights are re-pointed at row slices of the concatenated matrices (same values, the module keeps working),
+        # so the model exists once row-major (+ once packed) instead of the HF copy + the concatenated copy + the packed copy.
+        # SAMD_SHARE_HF_WEIGHTS=0 leaves the module untouched.
+        share = os.environ.get("SAMD_SHARE_HF_WEIGHTS", "1") != "0"
+
+        def fuse(linears):
+            ws = [l.weight for l in linears]
+            cat = get(torch.cat(ws, dim=0))
+            if share and all(w.device == cat.device and w.dtype == cat.dtype for w in ws):
+                r = 0
+                for l in linears:
+                    n = l.weight.shape[0]
+                    l.weight.data = cat[r:r + n]
+                    r += n
+            return cat
         for lyr in m.layers:
             a, f = lyr.self_attn, lyr.mlp
             for lin in (a.q_proj, a.k_proj, a.v_proj, a.o_proj, f.gate_proj, f.up_proj, f.down_proj):
                 if getattr(lin, "bias", None) is not None:
                     raise SamdError("LlamaRunner: projection biases are not supported")
             layers.append(dict(
-                wqkv=get(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)),
+                wqkv=fuse((a.q_proj, a.k_proj, a.v_proj)),
                 wo=get(a.o_proj.weight),
-                wgu=get(torch.cat([f.gate_proj.weight, f.up_proj.weight], dim=0)),
+                wgu=fuse((f.gate_proj, f.up_proj)),
                 wdown=get(f.down_proj.weight),
                 ln1=get(lyr.input_layernorm.weight), ln2=get(lyr.post_attention_layernorm.weight)))
         weights = dict(embed=get(m.embed_tokens.weight), layers=layers, norm=get(m.norm.weight), lm_head=get(lm.lm_head.weight))

@@ -95,6 +95,51 @@ def _sampled(logits, candidates, config):
     return torch.tensor(best, dtype=torch.long, device=dev), torch.tensor(n_acc, dtype=torch.long, device=dev), sample_p.view(1, -1)
 
 
+def _sampled_nodes(node_logits, retrieve, candidates, config):
+    """_sampled_device with ONE warped row per draft node: node_logits [n, V] are the verify forward's rows, retrieve [C, D] (or None
+    for a sequence draft: cell (0, j) = node j) says which node a candidate cell stands on (-1 = the last node, samd_model.py:144).
+    HF's warpers (a top-p sort per row) and the softmax then run over n <= 64 rows instead of C * D gathered ones, and no
+    [C, D, V] tensor is materialised."""
+    import numpy as np
+    n, V = node_logits.shape
+    C_, D = candidates.shape
+    probs = torch.softmax(config.logits_processor(None, node_logits), dim=-1).contiguous()
+    rowmap = (retrieve.to(torch.int32) if retrieve is not None else torch.arange(D, dtype=torch.int32, device=node_logits.device).view(1, D)).contiguous()
+    cand = candidates.to(torch.long).contiguous()
+    n_u = C_ * D + 8
+    state = random.getstate()
+    u = torch.from_numpy(np.asarray([random.random() for _ in range(n_u)], dtype=np.float64)).to(node_logits.device)
+    work = torch.empty(V, dtype=probs.dtype, device=node_logits.device)
+    out = torch.zeros(5, dtype=torch.int32, device=node_logits.device)
+    samd_hip.check(samd_hip.lib().samd_posterior_sampled_nodes(samd_hip._ptr(probs), samd_hip.torch_dtype_code(probs.dtype), samd_hip._ptr(rowmap), n,
+                                                               samd_hip._ptr(cand), C_, D, V, samd_hip._ptr(u), n_u, samd_hip._ptr(work), samd_hip._ptr(out),
+                                                               samd_hip.current_stream()))
+    best, n_acc, used, residual, status = out.tolist()
+    random.setstate(state)
+    for _ in range(used):
+        random.random()
+    if status:
+        raise samd_hip.SamdError("samd_posterior_sampled ran out of uniforms")
+    if residual:
+        sample_p = work
+    else:
+        node = int(rowmap[best, n_acc - 1])
+        sample_p = torch.softmax(node_logits[node if 0 <= node < n else n - 1], dim=0)
+    dev = candidates.device
+    return torch.tensor(best, dtype=torch.long, device=dev), torch.tensor(n_acc, dtype=torch.long, device=dev), sample_p.view(1, -1)
+
+
+def eval_posterior_nodes(node_logits, retrieve, candidates, config):
+    """eval_posterior for callers that still hold the verify forward's per-node rows and the retrieve table (SamdModel.decode): the
+    gather logits[retrieve] of samd_model.py:144 is not materialised.  Same results as eval_posterior(node_logits[retrieve], ...)."""
+    usable = (not config.greedy and node_logits.is_cuda and candidates.shape[1] <= 64
+              and node_logits.dtype in (torch.float16, torch.bfloat16, torch.float32))
+    if usable:
+        return _sampled_nodes(node_logits, retrieve, candidates, config)
+    gathered = node_logits[retrieve] if retrieve is not None else node_logits.unsqueeze(0)
+    return eval_posterior(gathered, candidates, config)
+
+
 def _sampled_device(logits, candidates, config):
     """the same walk in ONE kernel (samd_posterior_sampled) and one host round trip, where the reference issues a device
     synchronisation per examined token (`x.item()`, `r <= acp` on a device scalar): HF's warpers and the softmax run over all

@@ -27,7 +27,7 @@ from .draft import DraftModel
 from .model_patch import patch_dict
 from .model_patch.llama import mask_rows_u64
 from .samd_config import ForwardState, ForwardType, MaskState, SamdConfig
-from .utils import CandidateType, OptionalTensor, SamdGenerationConfig, eval_posterior, gen_candidates
+from .utils import CandidateType, OptionalTensor, SamdGenerationConfig, eval_posterior, eval_posterior_nodes, gen_candidates
 
 Outputs = namedtuple('Outputs', ['output_ids', 'decode_tokens', 'decode_steps', 'accepet_length_per_step'])
 
@@ -178,13 +178,12 @@ class SamdModel(nn.Module):
             rel = self.tree_position_ids[0]
             mask_rows = mask_rows_u64(self.tree_attn_mask)
         tree_logits = self.verifier.forward_tokens(self.draft.session(), candidates.tokens[0], rel, mask_rows, n, length).unsqueeze(0)
-        if candidates.type == CandidateType.sequence:
-            candidate_logits = tree_logits
-            candidate_indices = OptionalTensor(None)
-        else:
-            candidate_logits = tree_logits.squeeze(0)[self.tree_retrieve_indices]
-            candidate_indices = OptionalTensor(self.tree_retrieve_indices)
-        best_candidate, accept_length, sample_p = eval_posterior(candidate_logits, candidates.candidate_tokens, self.gen_config)
+        # (the reference gathers candidate_logits = tree_logits[retrieve] here, samd_model.py:140-146; eval_posterior_nodes reads the
+        # per-node rows through the retrieve table instead, so sampling warps <= 64 rows and no [leaves, depth, V] tensor exists)
+        is_tree = candidates.type != CandidateType.sequence
+        candidate_indices = OptionalTensor(self.tree_retrieve_indices if is_tree else None)
+        best_candidate, accept_length, sample_p = eval_posterior_nodes(tree_logits.squeeze(0), self.tree_retrieve_indices if is_tree else None,
+                                                                       candidates.candidate_tokens, self.gen_config)
         new_tokens = self.update_state(best_candidate, accept_length, candidates.candidate_tokens, candidate_indices)
         self.lookup_stats[candidates.type.value][0] += 1
         self.lookup_stats[candidates.type.value][1] += len(new_tokens)

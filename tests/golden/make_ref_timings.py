@@ -32,7 +32,9 @@ from samd_sam_only.sam import DynSAM, StaticSAM                       # noqa: E4
 from samd_sam_only.draft import CandidateType, DraftModel            # noqa: E402
 import bench                                                          # noqa: E402  (synthetic corpus / request generators only)
 
-CORPUS_TOKENS = 1 << 17          # CPython builds ~30 us/token: the full 2^22 corpus would take minutes and ~10 GB of objects
+# bench.py's own corpus size by default (2^22 tokens: ~2 minutes of CPython and ~10 GB of Python objects for the build; round 2 used
+# 2^17, which made this column a different workload from the port's and the GPU's).  REF_CORPUS_TOKENS overrides.
+CORPUS_TOKENS = int(os.environ.get("REF_CORPUS_TOKENS", 1 << 22))
 EOS = 2
 
 

@@ -174,3 +174,39 @@ def test_sampling_posterior_kernel_follows_the_loop_in_half_precision(dtype):
         assert (int(b0), int(a0), r0) == (int(b1), int(a1), r1), trial
         tol = 2.0 ** (-9 if dtype == torch.float16 else -6)
         assert (p0.float() - p1.float()).abs().max().item() <= tol * max(1e-3, p0.float().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_sampling_posterior_per_node_rows_equal_the_gathered_form(dtype):
+    """eval_posterior_nodes (one warped row per draft node, cells read through the retrieve table -- samd_posterior_sampled_nodes) takes
+    the decisions of eval_posterior on the gathered [leaves, depth, V] logits the reference builds (samd_model.py:140-146), incl.
+    -1 retrieve entries (last node's row, pad token 0) and sequence drafts; same generator position, same distribution."""
+    from samd_sam_only.sam.static_sam import gen_buffers
+    from samd_sam_only.utils import SamdGenerationConfig, eval_posterior, eval_posterior_nodes
+    from util import random_parents
+    rng = np.random.default_rng(17)
+    g = torch.Generator(device="cuda").manual_seed(17)
+    V = 3000
+    for trial in range(10):
+        n = int(rng.integers(2, 40))
+        seq = trial % 4 == 3
+        tokens = torch.from_numpy(rng.integers(3, 14, n)).cuda()
+        node_logits = torch.randn((n, V), generator=g, device="cuda") * 2
+        node_logits[:, 3:14] += 5
+        node_logits = node_logits.to(dtype)
+        if seq:
+            retrieve, cand = None, tokens.view(1, n)
+            gathered = node_logits.unsqueeze(0)
+        else:
+            retrieve = gen_buffers(random_parents(rng, n, ["bushy", "random", "star"][trial % 3]))["tree_retrieve_indices"]
+            cand = torch.cat((tokens, torch.zeros(1, dtype=torch.long, device="cuda")))[retrieve]
+            gathered = node_logits[retrieve]
+        cfg = SamdGenerationConfig(greedy=False, temperature=0.8, top_p=float(rng.choice([0.0, 0.9])), top_k=int(rng.choice([0, 50])))
+        random.seed(500 + trial)
+        b0, a0, p0 = eval_posterior(gathered, cand, cfg)
+        r0 = random.random()
+        random.seed(500 + trial)
+        b1, a1, p1 = eval_posterior_nodes(node_logits, retrieve, cand, cfg)
+        r1 = random.random()
+        assert (int(b0), int(a0), r0) == (int(b1), int(a1), r1), trial
+        assert torch.equal(p0, p1), trial

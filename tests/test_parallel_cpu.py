@@ -67,6 +67,57 @@ def test_broadcast_shard_gather_world2():
         assert flat == want                                   # every rank sees all results, in request order
 
 
+def _eval_worker(rank, world, port, qfile, ans, q):
+    for p in (ROOT, os.path.join(ROOT, "sam-decoding_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from evaluation import run_eval
+        from test_harness_cpu import ToyTokenizer
+        tok = ToyTokenizer()
+        seen = []
+
+        def forward(inputs, model, tokenizer, max_new_tokens):
+            n = len(inputs.input_ids[0])
+            seen.append(n)
+            new = [tok._id(w) for w in f"answer of rank {rank} </s>".split()]
+            return [inputs.input_ids[0].tolist() + new], len(new), 2, [n % 5 + 1, 1]
+
+        acc = run_eval(object(), tok, forward, "toy", qfile, None, None, ans, max_new_tokens=8)
+        q.put((rank, len(seen), acc))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_eval_shards_and_gathers_world2(tmp_path):
+    """run_eval under a 2-rank gloo group: contiguous question chunks (eval_vicuna.py:50-65), records and accept lengths gathered
+    over the process group, rank 0 writes ONE answer file ordered by question id, no per-rank files are left behind."""
+    import json
+    qs = [{"question_id": 10 + i, "category": "qa", "turns": [f"question number {i}"]} for i in range(5)]
+    qfile = tmp_path / "q.jsonl"
+    qfile.write_text("".join(json.dumps(x) + "\n" for x in qs))
+    ans = tmp_path / "out" / "a.jsonl"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, str(qfile), str(ans), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows = [json.loads(l) for l in ans.read_text().splitlines()]
+    assert [r["question_id"] for r in rows] == [10, 11, 12, 13, 14]
+    who = [r["choices"][0]["turns"][0] for r in rows]
+    assert who == ["answer of rank 0"] * 2 + ["answer of rank 1"] * 3          # chunk = 5 // 2, remainder to the last rank
+    assert res[0][1] == 3 * 1 + 2 and res[1][1] == 3 * 1 + 3                  # 3 warm-up passes + own questions
+    assert res[0][2] == res[1][2] and len(res[0][2]) == 2 * 5                 # every rank holds all accept lengths, in question order
+    assert sorted(os.listdir(tmp_path / "out")) == ["a.jsonl"]
+
+
 def test_shard_bounds_cover_everything():
     from samd_hip import parallel
     for n in (0, 1, 7, 80, 481):
