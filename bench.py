@@ -117,6 +117,16 @@ def hip_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def walk_source_sha16():
+    """hash of the sources of the SAM traversal kernel: profiles/walk_pmc.json (scripts/pmc_walk.sh) carries the one its counters were
+    collected under"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("sam_kernels.hip", "sam_device.h", "samd_common.h"):
+        h.update(open(os.path.join(ROOT, "sam-decoding_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
     """the SAM traversal kernel in batched-streams form: B independent cursors x T tokens per launch."""
     import torch
@@ -138,16 +148,18 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
     gbps = alg_bytes / (ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC passes of the same kernel and configuration (collected separately with
     # rocprofv3 --pmc, scripts/pmc_walk.sh; profiles/walk_pmc.json) -- null when the configuration differs
-    traffic = None
+    traffic, traffic_from = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "walk_pmc.json")))
         c = pmc["config"]
-        if (c["corpus_tokens"], c["streams"], c["tokens_per_stream"]) == (sam_tokens, B, T):
+        traffic_from = {"commit": pmc.get("commit"), "kernel_source_sha16": pmc.get("kernel_source_sha16"), "current_source_sha16": walk_source_sha16()}
+        # the counters must belong to THIS configuration and to THESE kernel sources; otherwise the field is null, not a stale number
+        if (c["corpus_tokens"], c["streams"], c["tokens_per_stream"]) == (sam_tokens, B, T) and pmc.get("kernel_source_sha16") == walk_source_sha16():
             traffic = int(pmc["fetch_bytes_per_launch"] * pmc["fetch_size_correction"] + pmc["write_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
     return dict(bound="hbm", kernel="k_static_walk", achieved=round(gbps, 2), peak=HBM_PEAK_GBPS, unit="GB/s",
-                frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=traffic, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
+                frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=traffic, traffic_from=traffic_from, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
                 visited_states=n_visited, alg_bytes_per_launch=int(alg_bytes), transitions_per_s=round(B * T / (ms * 1e-3), 1),
                 line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2),
                 # the walk is request-bound: one 64-byte request per visited state carries 16 algorithmic bytes

@@ -29,6 +29,13 @@ for f in glob.glob(d + "/walk_trace/*kernel_stats.csv"):
 for line in open(d + "/walk_trace.txt"):
     if line.startswith("{'bound'"):
         out["bench_roofline"] = eval(line)
+# the sources the counters belong to: bench.py nulls `roofline.traffic` when the tree's kernel sources hash differently
+import hashlib, os
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+h = hashlib.sha256()
+for name in ("sam_kernels.hip", "sam_device.h", "samd_common.h"):
+    h.update(open(os.path.join(root, "sam-decoding_amd", "csrc", name), "rb").read())
+out["kernel_source_sha16"] = h.hexdigest()[:16]
 print(json.dumps(out))
 json.dump(out, open(d + "/walk_summary.json", "w"), indent=1)
 PY
