@@ -452,6 +452,17 @@ int samd_gemm_skinny_silu(const void *d_A, const void *d_W, int32_t rows_pad, in
                           void *stream);
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad);
 int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits);
+/* The q|k|v projection with RoPE and SamdStaticCache.update's row write (SO/cache.py:103-115) as its epilogue -- what samd_gemm_skinny
+ * (q|k|v weights) + samd_rope_kv_write_cs do in two launches and a round trip of fp32 partial sums.  d_W64 = the [q|k|v] weight
+ * matrix ((n_heads + 2 n_kv_heads) * 128 rows, K columns) packed by samd_gemm_pack_qkv64 (64-column tiles holding 32 rotate_half
+ * pairs of one head each); d_cs = samd_rope_rows' per-row cos | sin; q_out [rows][n_heads][128]; K / V rows go to
+ * [n_kv_heads][max_len][128] caches at [L, L + n).  One workgroup per tile, no split-K: worth it when there are >= ~150 tiles
+ * (a 32-head MHA model has 192; the runner keeps the two-launch path otherwise).  Call sites replaced: SO/samd_model.py:134-138
+ * (the q/k/v projections, rotary embedding and cache update inside HF's LlamaAttention.forward). */
+int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total, int32_t K, void *stream);
+int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length,
+                       const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t n_heads, int32_t n_kv_heads,
+                       int32_t head_dim, int64_t max_len, int32_t dtype, void *stream);
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
                      void *d_out, int32_t dtype, void *stream);
 

@@ -207,6 +207,158 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     }
 }
 
+// ================================================================================================
+// q|k|v projection with RoPE and the K/V row write as its epilogue (round 3): the k_rope_kv launch and the fp32 split-K partials of the
+// q|k|v projection disappear (Vicuna-7B: 5 us and 1.5 MB written + read back per layer).  An epilogue needs COMPLETE sums, so no split-K
+// across workgroups: the launch gets its workgroups from 64-column tiles instead -- (H + 2 H_kv) x 2 of them, 192 for a 32-head MHA
+// model -- and the two halves of every 256-k chunk go to two wave groups of the same workgroup (waves 0-3: k blocks 0,1; waves 4-7:
+// k blocks 2,3; 16 columns each), whose accumulators meet in LDS after the stream.  A tile holds 32 complete rotate_half PAIRS of one
+// head -- head columns {32 half + i, 64 + 32 half + i : i < 32} -- so the rotation needs nothing from another workgroup; the row
+// permutation is applied once, when the weights are packed (samd_gemm_pack_qkv64).
+//   PACKED LAYOUT (64-column tiles): block (tile t, chunk c) = 32 KiB contiguous at ((t * K/256 + c) * 2048) uint4 units; unit
+//   (2 bl + j) * 512 + tid holds Wperm[64 t + 16 cg + n][256 c + 64 (2 kh + bl) + 16 g + 8 j .. +7] for tid = 64 (4 kh + cg) + 16 g + n.
+// The stream itself is k_gemm_skinny's: LDS-DMA'd A chunks shared by all waves, hand-issued nt weight loads with DEPTH chunks in flight
+// (32 KiB chunks: DEPTH 4 = the same 128 KiB per workgroup), counted waits, bare barriers.
+// ================================================================================================
+template <typename TT, int RT, int DEPTH>
+__global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void k_gemm_qkv_rope(
+        const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W, int K, int n_chunks,
+        const float *__restrict__ cs, const int *__restrict__ d_L, const int *__restrict__ d_n,
+        typename TT::elem *__restrict__ q_out, typename TT::elem *__restrict__ k_cache, typename TT::elem *__restrict__ v_cache,
+        int H, int Hkv, long long max_len) {
+    typedef typename TT::elem E;
+    typedef typename TT::vec8 V8;
+    constexpr int R = 16 * RT;
+    constexpr int NT = 64 * GEMM_WAVES;
+    constexpr int XV = (R * 32) / NT;              // 16-byte units per thread to stage one A chunk
+    constexpr int NB = DEPTH + 1;
+    constexpr int WL = 4;                          // weight loads per lane and chunk
+    extern __shared__ __attribute__((aligned(1024))) char gemm_lds[];
+    E (*xs)[R][GEMM_KC] = reinterpret_cast<E (*)[R][GEMM_KC]>(gemm_lds);
+
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4, cg = w & 3, kh = w >> 2;
+    const char *wtile = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * 32768;
+    const uint32_t wlane = (uint32_t)tid * 16;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)&xs[0][0][0];
+    // the scalars and this thread's cos | sin are requested now and used after the stream
+    const int n_rows = d_n[0], L = d_L[0];
+
+    floatx4 acc[RT];
+#pragma unroll
+    for (int mt = 0; mt < RT; mt++) acc[mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 wr[DEPTH][2][2];
+    auto load_wb = [&](u32x4 (&dst)[2][2], int c, int bl) {
+        const char *p = wtile + (size_t)c * 32768;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[bl][j]) : "v"(wlane), "s"(p + 8192 * (2 * bl + j)) : "memory");
+    };
+    auto stage_xi = [&](int c, int buf, int i) {
+        const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
+        const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
+        E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        asm volatile("" ::: "memory");
+    };
+    auto issue = [&](u32x4 (&dst)[2][2], int c, int buf) {
+        load_wb(dst, c, 0); load_wb(dst, c, 1);
+#pragma unroll
+        for (int i = 0; i < XV; i++) stage_xi(c, buf, i);
+    };
+    auto landed = [&](int younger) {               // memory ops retire in issue order: chunk c has landed when only the younger ones may still fly
+        if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (WL + XV)) : "memory");
+        else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (WL + XV)) : "memory");
+        else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + XV) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto phase = [&](u32x4 (&cur)[2][2], int c, int buf) {
+        landed(n_chunks - 1 - c);
+        const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
+#pragma unroll
+        for (int bl = 0; bl < 2; bl++) {
+            const int b = 2 * kh + bl;
+            const uint32_t a0 = xbase + (uint32_t)((8 * b + 2 * g) ^ n) * 16, a1 = xbase + (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;
+            u32x4 r[RT][2];
+            if constexpr (RT == 1)
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]) : "v"(a0), "v"(a1));
+            else if constexpr (RT == 2)
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:8192\n\t"
+                             "s_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]) : "v"(a0), "v"(a1));
+            else if constexpr (RT == 3)
+                asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %6 offset:8192\n\tds_read_b128 %3, %7 offset:8192\n\t"
+                             "ds_read_b128 %4, %6 offset:16384\n\tds_read_b128 %5, %7 offset:16384\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]) : "v"(a0), "v"(a1));
+            else
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %9 offset:8192\n\t"
+                             "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %9 offset:16384\n\tds_read_b128 %6, %8 offset:24576\n\t"
+                             "ds_read_b128 %7, %9 offset:24576\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1])
+                             : "v"(a0), "v"(a1));
+#pragma unroll
+            for (int mt = 0; mt < RT; mt++) {
+                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][0]), __builtin_bit_cast(V8, cur[bl][0]), acc[mt]);
+                acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][1]), __builtin_bit_cast(V8, cur[bl][1]), acc[mt]);
+            }
+        }
+        if (c + DEPTH < n_chunks) issue(cur, c + DEPTH, buf == 0 ? NB - 1 : buf - 1);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < n_chunks) issue(wr[d], d, d);
+    {
+        int buf = 0;
+        for (int c = 0; c < n_chunks; c += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++)
+                if (c + d < n_chunks) { phase(wr[d], c + d, buf); buf = buf == NB - 1 ? 0 : buf + 1; }
+        }
+    }
+    // ---- epilogue: the two k halves meet in LDS ([2][R][64] fp32; the A tiles are dead), then RoPE + rounding + row writes -------------
+    float *ex = reinterpret_cast<float *>(gemm_lds);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < RT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) ex[(kh * R + 16 * mt + 4 * g + r) * 64 + 16 * cg + n] = acc[mt][r];     // C layout: lane holds rows 4g + r of column n
+    __syncthreads();
+    const int tile = blockIdx.x, head = tile >> 1, half = tile & 1;
+    for (int i = tid; i < R * 32; i += NT) {
+        const int row = i >> 5, p = i & 31;
+        if (row >= n_rows || L + row >= max_len) continue;                     // rows past the draft / past the cache are not written (k_rope_kv)
+        // sums rounded to the model dtype first, as the projection's own output would have been (k_rope_kv does the same on partials)
+        const float x1 = (float)(E)(ex[row * 64 + p] + ex[(R + row) * 64 + p]);
+        const float x2 = (float)(E)(ex[row * 64 + 32 + p] + ex[(R + row) * 64 + 32 + p]);
+        const int j = 32 * half + p;                                              // position inside the head: j and j + 64
+        if (head >= H + Hkv) {                                                    // V: plain rows
+            E *dst = v_cache + ((size_t)(head - H - Hkv) * max_len + L + row) * 128;
+            dst[j] = (E)x1; dst[j + 64] = (E)x2;
+            continue;
+        }
+        const float c = cs[(size_t)row * 128 + j], sn = cs[(size_t)row * 128 + 64 + j];
+        const E o1 = (E)(x1 * c - x2 * sn), o2 = (E)(x2 * c + x1 * sn);
+        E *dst = head < H ? q_out + ((size_t)row * H + head) * 128 : k_cache + ((size_t)(head - H) * max_len + L + row) * 128;
+        dst[j] = o1; dst[j + 64] = o2;
+    }
+}
+
+// row-major [N][K] -> the 64-column-tile packed layout of k_gemm_qkv_rope, with the head-pair row permutation: packed row 64 t + q
+// = source row 128 (t / 2) + 32 (t % 2) + (q < 32 ? q : 32 + q)   (q in [32, 64) -> head column 64 + 32 half + (q - 32))
+__global__ __launch_bounds__(256) void k_gemm_pack_qkv64(const uint4 *__restrict__ W, uint4 *__restrict__ out, int N, int K) {
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * K / 8;
+    if (u >= total) return;
+    const int n_chunks = K / GEMM_KC;
+    const long long blk = u >> 11;                                   // 2048 units per 32 KiB block
+    const int in = (int)(u & 2047), jj = in >> 9, tid = in & 511, w = tid >> 6, g = (tid >> 4) & 3, n = tid & 15, cg = w & 3, kh = w >> 2;
+    const int t = (int)(blk / n_chunks), c = (int)(blk % n_chunks), bl = jj >> 1, j = jj & 1;
+    const int q = 16 * cg + n;
+    const long long row = 128LL * (t >> 1) + 32 * (t & 1) + (q < 32 ? q : 32 + q), col = 256LL * c + 64 * (2 * kh + bl) + 16 * g + 8 * j;
+    out[u] = W[(row * K + col) / 8];
+}
+
 // row-major [N][K] (2-byte elements) -> packed blocks; one thread moves one 16-byte unit
 __global__ __launch_bounds__(256) void k_gemm_pack(const uint4 *__restrict__ W, uint4 *__restrict__ out, int N, int K) {
     const long long u = (long long)blockIdx.x * 256 + threadIdx.x;          // destination unit
@@ -243,6 +395,20 @@ static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t 
     if (dtype == SAMD_F16) ROWS(GF16); else ROWS(GBF16);
 #undef ROWS
 #undef GO
+}
+
+template <typename TT, int RT, int DEPTH>
+static hipError_t qkv_rope_launch(hipStream_t st, const void *A, const void *W, int K, int tiles, const float *cs, const int *d_L, const int *d_n, void *q, void *k, void *v,
+                                  int H, int Hkv, long long max_len) {
+    constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 2 * 16 * RT * 64 * 4, lds = lds_a > lds_e ? lds_a : lds_e;
+    if constexpr (lds > 65536) {
+        static unsigned long long done = 0ull;
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_qkv_rope<TT, RT, DEPTH>, lds, &done);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
+                       cs, d_L, d_n, (typename TT::elem *)q, (typename TT::elem *)k, (typename TT::elem *)v, H, Hkv, max_len);
+    return hipSuccess;
 }
 
 extern "C" {
@@ -287,6 +453,39 @@ int samd_gemm_pack_weights(const void *d_W, void *d_packed, int32_t N, int32_t K
     }
     const long long units = (long long)N * K / 8;
     hipLaunchKernelGGL(k_gemm_pack, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, N, K);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total, int32_t K, void *stream) {
+    if (!d_W || !d_packed || d_W == d_packed || n_heads_total < 1 || K < GEMM_KC || K % GEMM_KC != 0) {
+        samd_set_error("samd_gemm_pack_qkv64: needs K %% 256 == 0, whole 128-column heads and distinct buffers"); return SAMD_E_INVALID;
+    }
+    const long long units = (long long)n_heads_total * 128 * K / 8;
+    hipLaunchKernelGGL(k_gemm_pack_qkv64, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, n_heads_total * 128, K);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n,
+                       void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                       int32_t dtype, void *stream) {
+    if (!d_A || !d_W64 || !d_cs || !d_cache_length || !d_n || !d_q_out || !d_k_cache || !d_v_cache || head_dim != 128 || n_heads < 1 || n_kv_heads < 1 ||
+        (rows_pad != 16 && rows_pad != 32 && rows_pad != 48 && rows_pad != 64) || K < GEMM_KC || K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_qkv_rope: unsupported shape (rows 16/32/48/64, head_dim 128, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+    }
+    static const int depth_env = [] { const char *e = getenv("SAMD_QKV_DEPTH"); return e ? atoi(e) : 0; }();
+    const int tiles = 2 * (n_heads + 2 * n_kv_heads);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+#define GO(TT, RT, D) e = qkv_rope_launch<TT, RT, D>(st, d_A, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len)
+#define ROWS(TT) do { if (rows_pad == 16) { if (depth_env == 2) GO(TT, 1, 2); else if (depth_env == 3) GO(TT, 1, 3); else GO(TT, 1, 4); } \
+                      else if (rows_pad == 32) { if (depth_env == 2) GO(TT, 2, 2); else GO(TT, 2, 4); } \
+                      else if (rows_pad == 48) GO(TT, 3, 3); else GO(TT, 4, 3); } while (0)
+    if (dtype == SAMD_F16) ROWS(GF16); else ROWS(GBF16);
+#undef ROWS
+#undef GO
+    if (e != hipSuccess) { samd_set_error("samd_gemm_qkv_rope: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -126,9 +126,21 @@ class LlamaRunner:
                 return None
             gate, up = t[:s.inter].view(s.inter // 64, 64, -1), t[s.inter:].view(s.inter // 64, 64, -1)
             return pack(torch.stack([gate, up], dim=1).reshape(2 * s.inter, -1).contiguous())
+        def pack_qkv64(t):
+            """q|k|v in the 64-column-tile layout of samd_gemm_qkv_rope (RoPE + K/V row write as the projection's epilogue, no split-K):
+            taken when the launch then has enough workgroups to stream -- 2 tiles per head, >= 128 of them (Vicuna-7B: 192; a GQA
+            model like Llama-3-8B has 96 and keeps the split-K projection + samd_rope_kv_write_cs)"""
+            heads_total = s.heads + 2 * s.kv_heads
+            if (not streams(t) or self.attention != "split" or 2 * heads_total < 128 or s.head_dim != 128
+                    or os.environ.get("SAMD_QKV_FUSED", "1") == "0"):
+                return None
+            out = torch.empty_like(t)
+            check(lib().samd_gemm_pack_qkv64(_ptr(t), _ptr(out), heads_total, t.shape[1], current_stream()))
+            return out
         # packed_lm_head: a draft head shares the base model's lm_head, packed copy included
         self.wp = dict(lm_head=packed_lm_head if packed_lm_head is not None else pack(weights["lm_head"]),
-                       layers=[dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")}, wgu=pack_gate_up(l["wgu"])) for l in weights["layers"]])
+                       layers=[dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")}, wgu=pack_gate_up(l["wgu"]), wqkv64=pack_qkv64(l["wqkv"]))
+                               for l in weights["layers"]])
         self.native_gemm = self.wp["lm_head"] is not None or any(v is not None for l in self.wp["layers"] for v in l.values())
         if not self.native_gemm:
             self.wp = None
@@ -335,7 +347,13 @@ class LlamaRunner:
             if not raw_in:
                 check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(delta), _ptr(w["ln1"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride,
                                           hint(w["wqkv"], wp.get("wqkv")), st))
-            src, n_p, stride = gemm(b["x"] if raw_in else b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
+            fused_qkv = wp.get("wqkv64") is not None and self.attention == "split" and RP <= self.native_gemm_max_rows and d_vis is None
+            if fused_qkv:
+                # q|k|v projection + RoPE + K/V row write in one launch (csrc/gemm_kernels.hip: k_gemm_qkv_rope)
+                check(L.samd_gemm_qkv_rope(_ptr(b["x"] if raw_in else b["h"]), _ptr(wp["wqkv64"]), RP, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
+                                           _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, self.max_len, dt, st))
+            else:
+                src, n_p, stride = gemm(b["x"] if raw_in else b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
             if block:
                 # RoPE + K row / V^T column write + tree attention + merge of the tile partials: one launch (csrc/attn_kernels.hip)
                 check(L.samd_attention_block(_ptr(src), n_p, stride, _ptr(b["cs"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R,
@@ -345,7 +363,9 @@ class LlamaRunner:
                                                  s.heads, s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
                                                  _ptr(b["ws"]), b["ws_bytes"], st))
             else:
-                if self.attention == "split":
+                if fused_qkv:
+                    pass
+                elif self.attention == "split":
                     check(L.samd_rope_kv_write_cs(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(b["cs"]), _ptr(b["q"]), _ptr(self.kv[li, 0]),
                                                   _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads, s.head_dim, self.max_len, dt, n_p, stride, st))
                 else:

@@ -109,3 +109,63 @@ def test_gemm_rejects_bad_shapes():
     assert ok(16, 128, 256, 2) != 0        # more splits than chunks
     assert L.samd_gemm_splits(4096, 4096, 16) == 8 and L.samd_gemm_splits(4096, 4096, 64) == 8
     assert L.samd_gemm_splits(22016, 4096, 16) == 1 and L.samd_gemm_splits(12288, 4096, 16) == 2      # one balanced wave of workgroups
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("rows_pad,H,Hkv,K,n,L", [(16, 32, 32, 4096, 11, 700), (64, 32, 32, 4096, 60, 1900), (32, 2, 2, 512, 32, 0), (48, 4, 1, 768, 37, 129),
+                                                  (16, 3, 3, 256, 1, 5)])
+def test_qkv_projection_with_rope_epilogue(dtype, tol, rows_pad, H, Hkv, K, n, L):
+    """samd_gemm_qkv_rope (q|k|v projection + RoPE + K/V row write in one launch, 64-column tiles holding rotate_half pairs, no split-K)
+    against fp32 arithmetic, and against the two-launch path it replaces (samd_gemm_skinny + samd_rope_kv_write_cs): q rows < n, K / V
+    rows [L, L + n) of the caches; nothing else may be written."""
+    Lb = samd_hip.lib()
+    D, max_len = 128, 2048
+    g = torch.Generator(device="cuda").manual_seed(rows_pad + H + K)
+    N = (H + 2 * Hkv) * D
+    A = torch.randn((rows_pad, K), generator=g, device="cuda").to(dtype)
+    W = (torch.randn((N, K), generator=g, device="cuda") * (K ** -0.5)).to(dtype)
+    W64 = torch.empty_like(W)
+    samd_hip.check(Lb.samd_gemm_pack_qkv64(samd_hip._ptr(W), samd_hip._ptr(W64), H + 2 * Hkv, K, samd_hip.current_stream()))
+    pos = torch.randint(0, 64, (rows_pad,), generator=g, device="cuda")
+    ang = (L + pos)[:, None].double() * (1.0 / (10000.0 ** (torch.arange(0, D, 2, device="cuda").double() / D)))[None, :]
+    cs = torch.zeros((64, D), dtype=torch.float32, device="cuda")
+    cs[:rows_pad, :64] = ang.cos().float(); cs[:rows_pad, 64:] = ang.sin().float()
+    d_L = torch.tensor([L], dtype=torch.int32, device="cuda")
+    d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    POISON = 7.0
+    q = torch.full((rows_pad, H, D), POISON, device="cuda", dtype=dtype)
+    kc = torch.full((Hkv, max_len, D), POISON, device="cuda", dtype=dtype)
+    vc = torch.full((Hkv, max_len, D), POISON, device="cuda", dtype=dtype)
+    samd_hip.check(Lb.samd_gemm_qkv_rope(samd_hip._ptr(A), samd_hip._ptr(W64), rows_pad, K, samd_hip._ptr(cs), samd_hip._ptr(d_L), samd_hip._ptr(d_n),
+                                         samd_hip._ptr(q), samd_hip._ptr(kc), samd_hip._ptr(vc), H, Hkv, D, max_len, samd_hip.torch_dtype_code(dtype),
+                                         samd_hip.current_stream()))
+    torch.cuda.synchronize()
+    # fp32 reference
+    y = (A.float() @ W.float().t()).to(dtype).float().view(rows_pad, H + 2 * Hkv, D)
+    c, s = cs[:rows_pad, None, :64], cs[:rows_pad, None, 64:]
+    rot = torch.cat((y[..., :64] * c - y[..., 64:] * s, y[..., 64:] * c + y[..., :64] * s), dim=-1)
+    scale = max(1.0, y.abs().max().item())
+    assert (q[:n].float() - rot[:n, :H]).abs().max().item() <= tol * scale
+    assert (kc[:, L:L + n].float() - rot[:n, H:H + Hkv].transpose(0, 1)).abs().max().item() <= tol * scale
+    assert (vc[:, L:L + n].float() - y[:n, H + Hkv:].transpose(0, 1)).abs().max().item() <= tol * scale
+    # nothing else was touched
+    assert (q[n:] == POISON).all() and (kc[:, :L] == POISON).all() and (kc[:, L + n:] == POISON).all()
+    assert (vc[:, :L] == POISON).all() and (vc[:, L + n:] == POISON).all()
+    # the two-launch path on the same inputs (split-K partial sums of samd_gemm_skinny, rotated by samd_rope_kv_write_cs)
+    Wp = torch.empty_like(W)
+    samd_hip.check(Lb.samd_gemm_pack_weights(samd_hip._ptr(W), samd_hip._ptr(Wp), N, K, samd_hip.current_stream()))
+    sp = Lb.samd_gemm_splits(N, K, rows_pad)
+    part = torch.zeros((max(sp, 1), rows_pad, N), device="cuda", dtype=torch.float32)
+    out = torch.zeros((rows_pad, N), device="cuda", dtype=dtype)
+    samd_hip.check(Lb.samd_gemm_skinny(samd_hip._ptr(A), samd_hip._ptr(Wp), rows_pad, N, K, sp, samd_hip._ptr(part), samd_hip._ptr(out),
+                                       samd_hip.torch_dtype_code(dtype), samd_hip.current_stream()))
+    q2, kc2, vc2 = torch.zeros_like(q), torch.zeros_like(kc), torch.zeros_like(vc)
+    rel = torch.zeros(64, dtype=torch.int32, device="cuda")
+    samd_hip.check(Lb.samd_rope_kv_write_cs(samd_hip._ptr(part if sp > 1 else out), samd_hip._ptr(rel), samd_hip._ptr(d_L), samd_hip._ptr(d_n), samd_hip._ptr(cs),
+                                            samd_hip._ptr(q2), samd_hip._ptr(kc2), samd_hip._ptr(vc2), rows_pad, H, Hkv, D, max_len,
+                                            samd_hip.torch_dtype_code(dtype), sp if sp > 1 else 0, rows_pad * N, samd_hip.current_stream()))
+    torch.cuda.synchronize()
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    assert (q[:n].float() - q2[:n].float()).abs().max().item() <= 4 * ulp * scale          # same math, another fp32 summation order
+    assert (kc[:, L:L + n].float() - kc2[:, L:L + n].float()).abs().max().item() <= 4 * ulp * scale
+    assert (vc[:, L:L + n].float() - vc2[:, L:L + n].float()).abs().max().item() <= 4 * ulp * scale
