@@ -174,23 +174,30 @@ def lm_roofline(runner, iters=10, rows=16):
     import torch
     import samd_hip
     from samd_hip import _ptr, check, current_stream
-    if runner.wp is None or not runner.fused_mlp or any(v is None for l in runner.wp["layers"] for v in l.values()):
+    if runner.wp is None or not runner.fused_mlp or any(l[k] is None for l in runner.wp["layers"] for k in ("wqkv", "wo", "wgu", "wdown")):
         return None
     L, s, b = samd_hip.lib(), runner.shape, runner._buffers(rows)
     RP, part, dt = b["rows_pad"], b["part"], runner.dt
     attn2d = b["attn"].view(b["attn"].shape[0], -1)
     nbytes = [0]
 
+    d_L = torch.tensor([512], dtype=torch.int32, device="cuda")
+    d_n = torch.tensor([max(1, rows - 3)], dtype=torch.int32, device="cuda")
+
     def projections():
         st = current_stream()
         nbytes[0] = 0
-        for w, p in zip(runner.w["layers"], runner.wp["layers"]):
+        for li, (w, p) in enumerate(zip(runner.w["layers"], runner.wp["layers"])):
             for a, key, out in ((b["h"], "wqkv", b["qkv"]), (attn2d, "wo", b["o"]), (b["act"], "wdown", b["d"])):
                 n, k = w[key].shape
-                check(L.samd_gemm_skinny(_ptr(a), _ptr(p[key]), RP, n, k, L.samd_gemm_splits(n, k, RP), _ptr(part), _ptr(out), dt, st))
+                if key == "wqkv" and p.get("wqkv64") is not None:          # the launch the runner makes: RoPE + K/V write in the epilogue
+                    check(L.samd_gemm_qkv_rope(_ptr(a), _ptr(p["wqkv64"]), RP, k, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n), _ptr(b["q"]), _ptr(runner.kv[li, 0]),
+                                               _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
+                else:
+                    check(L.samd_gemm_skinny(_ptr(a), _ptr(p[key]), RP, n, k, L.samd_gemm_splits(n, k, RP), _ptr(part), _ptr(out), dt, st))
                 nbytes[0] += n * k * w[key].element_size()
             n, k = w["wgu"].shape
-            check(L.samd_gemm_skinny_silu(_ptr(b["h"]), _ptr(p["wgu"]), RP, n, k, _ptr(b["act"]), dt, st))
+            check(L.samd_gemm_pairs_silu(_ptr(b["h"]), _ptr(p["wgu"]), RP, n // 2, k, _ptr(b["act"]), dt, st))
             nbytes[0] += n * k * w["wgu"].element_size()
 
     projections()
@@ -208,7 +215,7 @@ def lm_roofline(runner, iters=10, rows=16):
             traffic = int((pmc["fetch_bytes_per_layer"] * pmc["fetch_size_correction"] + pmc["write_bytes_per_layer"]) / 4)
     except (OSError, KeyError, ValueError):
         pass
-    return dict(bound="hbm", kernel=f"k_gemm_skinny ({rows}-row tile; q/k/v, o, gate|up + SiLU, down of every layer)", achieved=round(gbps, 1),
+    return dict(bound="hbm", kernel=f"weight-streaming projections ({rows}-row tile; k_gemm_qkv_rope | k_gemm_skinny q/k/v, o, down; k_gemm_pairs_silu gate|up of every layer)", achieved=round(gbps, 1),
                 peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBPS, 4), traffic=traffic, launch_ms=round(ms / launches, 5),
                 launches_per_forward=launches, alg_bytes_per_launch=int(nbytes[0] / launches), forward_gemm_ms=round(ms, 4))
 

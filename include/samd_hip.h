@@ -452,6 +452,13 @@ int samd_gemm_skinny_silu(const void *d_A, const void *d_W, int32_t rows_pad, in
                           void *stream);
 int samd_gemm_splits(int32_t N, int32_t K, int32_t rows_pad);
 int64_t samd_gemm_workspace(int32_t rows_pad, int32_t N, int32_t splits);
+/* LlamaMLP's gate and up projections + act_fn(gate) * up on every CU: the unit of work is a pair of 16 gate columns and the 16 up
+ * columns they multiply, dealt out evenly over one workgroup per CU (samd_gemm_skinny_silu's 128-column tiles leave a third of the
+ * CUs idle for intermediate sizes like 11008).  d_Wg = the [gate; up] matrix with its rows interleaved in groups of 16 (gate rows
+ * 16p.., then up rows 16p..), packed by samd_gemm_pack_groups (N = 2 * inter rows); out [rows_pad][inter].  Same arithmetic and
+ * roundings as samd_gemm_skinny_silu.  Call site replaced: HF LlamaMLP.forward inside SO/samd_model.py:134-138. */
+int samd_gemm_pack_groups(const void *d_W, void *d_packed, int32_t N, int32_t K, void *stream);
+int samd_gemm_pairs_silu(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t inter, int32_t K, void *d_out, int32_t dtype, void *stream);
 /* The q|k|v projection with RoPE and SamdStaticCache.update's row write (SO/cache.py:103-115) as its epilogue -- what samd_gemm_skinny
  * (q|k|v weights) + samd_rope_kv_write_cs do in two launches and a round trip of fp32 partial sums.  d_W64 = the [q|k|v] weight
  * matrix ((n_heads + 2 n_kv_heads) * 128 rows, K columns) packed by samd_gemm_pack_qkv64 (64-column tiles holding 32 rotate_half

@@ -359,6 +359,150 @@ __global__ __launch_bounds__(256) void k_gemm_pack_qkv64(const uint4 *__restrict
     out[u] = W[(row * K + col) / 8];
 }
 
+// ================================================================================================
+// gate|up projection + SiLU*up on ALL CUs (round 3).  k_gemm_skinny<EPI = 1> covers gate|up with 128-column tiles: 172 workgroups for
+// Vicuna-7B's 2 x 11008 columns, and a launch on 172 CUs streams at 172 x ~36 GB/s = 6.0 TB/s -- what a CU's memory pipe ingests,
+// not what HBM delivers (profiles/r03_gemm_variants.md).  Here the unit of work is a PAIR = 16 gate columns + the 16 up columns they
+// multiply (two MFMA column groups, two waves): 688 pairs are dealt out evenly, 2 or 3 to each of 256 workgroups, so every CU pulls.
+// Waves 2i / 2i + 1 of a workgroup own pair i's gate / up group; waves beyond the workgroup's share only help staging A.
+//   PACKED LAYOUT (group-major): column group gi (16 columns), chunk c: 8 KiB contiguous at ((gi * K/256 + c) * 512) uint4 units;
+//   unit (2b + j) * 64 + lane holds Wg[16 gi + n][256 c + 64 b + 16 g + 8 j .. +7] for lane = 16 g + n, where Wg = the gate|up matrix with
+//   its rows interleaved in groups of 16 (group 2p = gate rows 16p.., group 2p + 1 = up rows 16p..) -- samd_gemm_pack_groups.
+// Stream, A staging and waits are k_gemm_skinny's (two chunks in flight, counted vmcnt, bare barriers).
+// ================================================================================================
+template <typename TT, int RT, int DEPTH>
+__global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WAVES / 2) void k_gemm_pairs_silu(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
+                                                                                                     typename TT::elem *__restrict__ out, int K, int inter, int n_chunks, int n_pairs) {
+    typedef typename TT::elem E;
+    typedef typename TT::vec8 V8;
+    constexpr int R = 16 * RT;
+    constexpr int NT = 64 * GEMM_WAVES;
+    constexpr int XV = (R * 32) / NT;
+    constexpr int NB = DEPTH + 1;
+    extern __shared__ __attribute__((aligned(1024))) char gemm_lds[];
+    E (*xs)[R][GEMM_KC] = reinterpret_cast<E (*)[R][GEMM_KC]>(gemm_lds);
+
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, g = l >> 4;
+    // this workgroup's pairs [p0, p1): an even deal of n_pairs over the grid
+    const int p0 = (int)((long long)blockIdx.x * n_pairs / gridDim.x), p1 = (int)((long long)(blockIdx.x + 1) * n_pairs / gridDim.x);
+    const bool active = w < 2 * (p1 - p0);                                       // wave-uniform
+    const int gi = 2 * p0 + w;                                                    // this wave's column group
+    const char *wgrp = reinterpret_cast<const char *>(W) + (size_t)(active ? gi : 0) * n_chunks * 8192;
+    const uint32_t wlane = (uint32_t)l * 16;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)&xs[0][0][0];
+
+    floatx4 acc[RT];
+#pragma unroll
+    for (int mt = 0; mt < RT; mt++) acc[mt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    u32x4 wr[DEPTH][4][2];
+    auto load_w = [&](u32x4 (&dst)[4][2], int c) {
+        const char *p = wgrp + (size_t)c * 8192;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 1024 * (2 * b + j)) : "memory");
+    };
+    auto stage_x = [&](int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < XV; i++) {
+            const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
+            const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
+            E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+    };
+    // a wave without a column group issues no weight loads, so its counted waits leave only its A pieces out
+    auto landed = [&](int younger) {
+        if (DEPTH > 3 && younger >= 3) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (8 + XV)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XV) : "memory"); }
+        else if (DEPTH > 2 && younger >= 2) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (8 + XV)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XV) : "memory"); }
+        else if (younger >= 1) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + XV) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XV) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto phase = [&](u32x4 (&cur)[4][2], int c, int buf) {
+        landed(n_chunks - 1 - c);
+        if (active) {
+            const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t a0 = xbase + (uint32_t)((8 * b + 2 * g) ^ n) * 16, a1 = xbase + (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;
+                u32x4 r[RT][2];
+                if constexpr (RT == 1)
+                    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]) : "v"(a0), "v"(a1));
+                else if constexpr (RT == 2)
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %4 offset:8192\n\tds_read_b128 %3, %5 offset:8192\n\t"
+                                 "s_waitcnt lgkmcnt(0)" : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]) : "v"(a0), "v"(a1));
+                else if constexpr (RT == 3)
+                    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %6 offset:8192\n\tds_read_b128 %3, %7 offset:8192\n\t"
+                                 "ds_read_b128 %4, %6 offset:16384\n\tds_read_b128 %5, %7 offset:16384\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]) : "v"(a0), "v"(a1));
+                else
+                    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %9 offset:8192\n\t"
+                                 "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %9 offset:16384\n\tds_read_b128 %6, %8 offset:24576\n\t"
+                                 "ds_read_b128 %7, %9 offset:24576\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[3][0]), "=&v"(r[3][1])
+                                 : "v"(a0), "v"(a1));
+#pragma unroll
+                for (int mt = 0; mt < RT; mt++) {
+                    acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][0]), __builtin_bit_cast(V8, cur[b][0]), acc[mt]);
+                    acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][1]), __builtin_bit_cast(V8, cur[b][1]), acc[mt]);
+                }
+            }
+        }
+        if (c + DEPTH < n_chunks) { if (active) load_w(cur, c + DEPTH); stage_x(c + DEPTH, buf == 0 ? NB - 1 : buf - 1); }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+        if (d < n_chunks) { if (active) load_w(wr[d], d); stage_x(d, d); }
+    {
+        int buf = 0;
+        for (int c = 0; c < n_chunks; c += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++)
+                if (c + d < n_chunks) { phase(wr[d], c + d, buf); buf = buf == NB - 1 ? 0 : buf + 1; }
+        }
+    }
+    // ---- epilogue: the up waves hand their values over through LDS, the gate waves write silu(gate) * up ---------------------------------
+    float *ex = reinterpret_cast<float *>(gemm_lds);                            // [4 pairs][R][16]; the A tiles are dead
+    __syncthreads();
+    if (active && (w & 1)) {
+#pragma unroll
+        for (int mt = 0; mt < RT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) ex[((w >> 1) * R + 16 * mt + 4 * g + r) * 16 + n] = acc[mt][r];
+    }
+    __syncthreads();
+    if (active && !(w & 1)) {
+        const int col = 16 * (p0 + (w >> 1)) + n;
+#pragma unroll
+        for (int mt = 0; mt < RT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = 16 * mt + 4 * g + r;
+                // the roundings of HF's act_fn(gate_proj(x)) * up_proj(x) in the model dtype (same as k_silu_mul)
+                const float gf = (float)(E)acc[mt][r], uf = (float)(E)ex[((w >> 1) * R + m) * 16 + n];
+                const E sv = (E)(gf / (1.f + __expf(-gf)));
+                out[(size_t)m * inter + col] = (E)((float)sv * uf);
+            }
+    }
+}
+
+// row-major [N][K] -> group-major packed layout of k_gemm_pairs_silu (rows already in group order); one thread moves one 16-byte unit
+__global__ __launch_bounds__(256) void k_gemm_pack_groups(const uint4 *__restrict__ W, uint4 *__restrict__ out, int N, int K) {
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)N * K / 8;
+    if (u >= total) return;
+    const int n_chunks = K / GEMM_KC;
+    const long long blk = u >> 9;                                    // 512 units per 8 KiB block
+    const int in = (int)(u & 511), jj = in >> 6, lane = in & 63, g = lane >> 4, n = lane & 15, b = jj >> 1, j = jj & 1;
+    const long long gi = blk / n_chunks; const int c = (int)(blk % n_chunks);
+    const long long row = 16 * gi + n, col = 256LL * c + 64 * b + 16 * g + 8 * j;
+    out[u] = W[(row * K + col) / 8];
+}
+
 // row-major [N][K] (2-byte elements) -> packed blocks; one thread moves one 16-byte unit
 __global__ __launch_bounds__(256) void k_gemm_pack(const uint4 *__restrict__ W, uint4 *__restrict__ out, int N, int K) {
     const long long u = (long long)blockIdx.x * 256 + threadIdx.x;          // destination unit
@@ -411,6 +555,19 @@ static hipError_t qkv_rope_launch(hipStream_t st, const void *A, const void *W, 
     return hipSuccess;
 }
 
+template <typename TT, int RT, int DEPTH>
+static hipError_t pairs_silu_launch(hipStream_t st, int grid, const void *A, const void *W, void *out, int K, int inter, int n_pairs) {
+    constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 4 * 16 * RT * 16 * 4, lds = lds_a > lds_e ? lds_a : lds_e;
+    if constexpr (lds > 65536) {
+        static unsigned long long done = 0ull;
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_pairs_silu<TT, RT, DEPTH>, lds, &done);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL((k_gemm_pairs_silu<TT, RT, DEPTH>), dim3(grid), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W,
+                       (typename TT::elem *)out, K, inter, K / GEMM_KC, n_pairs);
+    return hipSuccess;
+}
+
 extern "C" {
 
 // choose the split-K factor.  Measured (scripts/gemm_bench.py, profiles/): the stream is fastest when the launch is ONE
@@ -453,6 +610,41 @@ int samd_gemm_pack_weights(const void *d_W, void *d_packed, int32_t N, int32_t K
     }
     const long long units = (long long)N * K / 8;
     hipLaunchKernelGGL(k_gemm_pack, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, N, K);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_gemm_pack_groups(const void *d_W, void *d_packed, int32_t N, int32_t K, void *stream) {
+    if (!d_W || !d_packed || d_W == d_packed || N < 16 || N % 16 != 0 || K < GEMM_KC || K % GEMM_KC != 0) {
+        samd_set_error("samd_gemm_pack_groups: needs N %% 16 == 0, K %% 256 == 0 and distinct buffers"); return SAMD_E_INVALID;
+    }
+    const long long units = (long long)N * K / 8;
+    hipLaunchKernelGGL(k_gemm_pack_groups, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, N, K);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_gemm_pairs_silu(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t inter, int32_t K, void *d_out, int32_t dtype, void *stream) {
+    if (!d_A || !d_Wg || !d_out || (rows_pad != 16 && rows_pad != 32 && rows_pad != 48 && rows_pad != 64) || inter < 16 || inter % 16 != 0 || K < GEMM_KC ||
+        K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_pairs_silu: unsupported shape (rows 16/32/48/64, inter %% 16 == 0, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+    }
+    // one workgroup per CU (256 on MI355X) with an even share of the pairs; more workgroups only when a share would exceed 4 pairs (8 waves)
+    static const int n_cu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount; return n; }();
+    const int n_pairs = inter / 16;
+    int grid = n_pairs < n_cu ? n_pairs : n_cu;
+    while ((n_pairs + grid - 1) / grid > 4) grid += n_cu;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    static const int depth_env = [] { const char *e = getenv("SAMD_PAIRS_DEPTH"); return e ? atoi(e) : 0; }();
+#define ARGS st, grid, d_A, d_Wg, d_out, K, inter, n_pairs
+#define GO(TT) (rows_pad == 16 ? (depth_env == 2 ? pairs_silu_launch<TT, 1, 2>(ARGS) : depth_env == 4 ? pairs_silu_launch<TT, 1, 4>(ARGS) : pairs_silu_launch<TT, 1, 3>(ARGS)) \
+                : rows_pad == 32 ? (depth_env == 2 ? pairs_silu_launch<TT, 2, 2>(ARGS) : pairs_silu_launch<TT, 2, 3>(ARGS)) \
+                : rows_pad == 48 ? pairs_silu_launch<TT, 3, 2>(ARGS) : pairs_silu_launch<TT, 4, 2>(ARGS))
+    e = dtype == SAMD_F16 ? GO(GF16) : GO(GBF16);
+#undef GO
+#undef ARGS
+    if (e != hipSuccess) { samd_set_error("samd_gemm_pairs_silu: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -145,6 +145,8 @@ _PROTOS = {
     "samd_gemm_skinny_silu": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_skinny": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "samd_gemm_pack_qkv64": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
+    "samd_gemm_pack_groups": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
+    "samd_gemm_pairs_silu": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_qkv_rope": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
     "samd_recycle_create": (C.c_int, [_I32, _VP, _VP, _I32, _VP]),
     "samd_recycle_free": (None, [_VP]),

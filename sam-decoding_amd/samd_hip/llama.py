@@ -121,11 +121,15 @@ class LlamaRunner:
             check(lib().samd_gemm_pack_weights(_ptr(t), _ptr(out), t.shape[0], t.shape[1], current_stream()))
             return out
         def pack_gate_up(t):
-            """gate|up rows interleaved in groups of 64 for the GEMM's silu(gate) * up epilogue (samd_gemm_skinny_silu)"""
-            if s.inter % 64 != 0 or not streams(t):
+            """gate|up rows interleaved in groups of 16 (pair p = gate rows 16p.., up rows 16p..) in the group-major layout of
+            samd_gemm_pairs_silu: silu(gate) * up in the projection's epilogue, the pairs dealt out evenly over one workgroup per CU"""
+            if s.inter % 16 != 0 or not streams(t):
                 return None
-            gate, up = t[:s.inter].view(s.inter // 64, 64, -1), t[s.inter:].view(s.inter // 64, 64, -1)
-            return pack(torch.stack([gate, up], dim=1).reshape(2 * s.inter, -1).contiguous())
+            gate, up = t[:s.inter].view(s.inter // 16, 16, -1), t[s.inter:].view(s.inter // 16, 16, -1)
+            w = torch.stack([gate, up], dim=1).reshape(2 * s.inter, -1).contiguous()
+            out = torch.empty_like(w)
+            check(lib().samd_gemm_pack_groups(_ptr(w), _ptr(out), 2 * s.inter, w.shape[1], current_stream()))
+            return out
         def pack_qkv64(t):
             """q|k|v in the 64-column-tile layout of samd_gemm_qkv_rope (RoPE + K/V row write as the projection's epilogue, no split-K):
             taken when the launch then has enough workgroups to stream -- 2 tiles per head, >= 128 of them (Vicuna-7B: 192; a GQA
@@ -377,9 +381,9 @@ class LlamaRunner:
                                                  _ptr(b["ws"]), b["ws_bytes"], hint(w["wo"], wp.get("wo")), st))
             src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"])
             check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride,
-                                      hint(w["wgu"], wp.get("wgu"), fused=True) if self.fused_mlp else None, st))
+                                      None, st))           # (no warm-up hint: gate|up is packed group-major, the hint describes 128-column tiles)
             if self.fused_mlp and RP <= self.native_gemm_max_rows:
-                check(L.samd_gemm_skinny_silu(_ptr(b["h"]), _ptr(wp["wgu"]), RP, 2 * s.inter, s.hidden, _ptr(b["act"]), dt, st))
+                check(L.samd_gemm_pairs_silu(_ptr(b["h"]), _ptr(wp["wgu"]), RP, s.inter, s.hidden, _ptr(b["act"]), dt, st))
             else:
                 src, n_p, stride = gemm(b["h"], w["wgu"], None, b["gu"])           # wgu is only ever packed for the fused form
                 check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))

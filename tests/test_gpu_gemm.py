@@ -169,3 +169,40 @@ def test_qkv_projection_with_rope_epilogue(dtype, tol, rows_pad, H, Hkv, K, n, L
     assert (q[:n].float() - q2[:n].float()).abs().max().item() <= 4 * ulp * scale          # same math, another fp32 summation order
     assert (kc[:, L:L + n].float() - kc2[:, L:L + n].float()).abs().max().item() <= 4 * ulp * scale
     assert (vc[:, L:L + n].float() - vc2[:, L:L + n].float()).abs().max().item() <= 4 * ulp * scale
+
+
+def _pack_pairs(wg, wu, dtype):
+    """[gate; up] rows interleaved in groups of 16 and packed group-major (samd_gemm_pack_groups)"""
+    inter, K = wg.shape
+    w = torch.stack([wg.view(inter // 16, 16, K), wu.view(inter // 16, 16, K)], dim=1).reshape(2 * inter, K).contiguous()
+    out = torch.empty_like(w)
+    samd_hip.check(samd_hip.lib().samd_gemm_pack_groups(samd_hip._ptr(w), samd_hip._ptr(out), 2 * inter, K, samd_hip.current_stream()))
+    return out
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("rows_pad,inter,K", [(16, 11008, 4096), (64, 11008, 4096), (32, 14336, 4096), (48, 1408, 768), (16, 16, 256), (16, 48, 512), (32, 20480, 256)])
+def test_gate_up_pairs_on_all_cus(dtype, tol, rows_pad, inter, K):
+    """samd_gemm_pairs_silu (pairs of 16 gate + 16 up columns dealt out evenly over one workgroup per CU) against fp32 arithmetic with
+    HF's roundings, and bit for bit against samd_gemm_skinny_silu (same products, same summation order per column)."""
+    Lb = samd_hip.lib()
+    g = torch.Generator(device="cuda").manual_seed(inter + K + rows_pad)
+    A = torch.randn((rows_pad, K), generator=g, device="cuda").to(dtype)
+    wg = (torch.randn((inter, K), generator=g, device="cuda") * (K ** -0.5)).to(dtype)
+    wu = (torch.randn((inter, K), generator=g, device="cuda") * (K ** -0.5)).to(dtype)
+    out = torch.full((rows_pad, inter), float("nan"), device="cuda", dtype=dtype)
+    samd_hip.check(Lb.samd_gemm_pairs_silu(samd_hip._ptr(A), samd_hip._ptr(_pack_pairs(wg, wu, dtype)), rows_pad, inter, K, samd_hip._ptr(out),
+                                           samd_hip.torch_dtype_code(dtype), samd_hip.current_stream()))
+    torch.cuda.synchronize()
+    gate, up = (A.float() @ wg.float().t()).to(dtype).float(), (A.float() @ wu.float().t()).to(dtype).float()
+    want = ((gate / (1 + torch.exp(-gate))).to(dtype).float() * up).to(dtype).float()
+    assert torch.isfinite(out).all() and (out.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    if inter % 64 == 0:                                                        # the 128-column-tile kernel on the same matrices
+        w128 = torch.stack([wg.view(inter // 64, 64, K), wu.view(inter // 64, 64, K)], dim=1).reshape(2 * inter, K).contiguous()
+        p128 = torch.empty_like(w128)
+        samd_hip.check(Lb.samd_gemm_pack_weights(samd_hip._ptr(w128), samd_hip._ptr(p128), 2 * inter, K, samd_hip.current_stream()))
+        ref = torch.zeros_like(out)
+        samd_hip.check(Lb.samd_gemm_skinny_silu(samd_hip._ptr(A), samd_hip._ptr(p128), rows_pad, 2 * inter, K, samd_hip._ptr(ref),
+                                                samd_hip.torch_dtype_code(dtype), samd_hip.current_stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
