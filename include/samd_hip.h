@@ -254,6 +254,16 @@ int samd_argmax_rows(const void *d_logits, int32_t dtype, int32_t rows, int64_t 
  * -- SO/utils.py:127-141, SO/samd_model.py:158-170 -- on the session's current draft, from per-node
  * arg-max tokens d_node_argmax int32[n].  Mirrors the reference's -1 padding quirk. */
 int samd_session_accept(samd_session_t *s, const int32_t *d_node_argmax, void *stream);
+/* gen_candidates' gather (SO/utils.py:92-96) for the draft the session holds: d_candidates int64 [n_leaves * max_depth] =
+ * (tokens + [0])[retrieve] (pad token 0 for -1 entries), d_rowmap int32 [n_leaves * max_depth] = the retrieve table; `capacity` =
+ * elements either buffer can take.  Device to device, no host round trip (the shapes are in the previous step's report). */
+int samd_session_candidates(samd_session_t *s, int64_t *d_candidates, int32_t *d_rowmap, int32_t capacity, void *stream);
+/* samd_session_step for a verdict decided elsewhere -- the sampling branch of eval_posterior (SO/utils.py:142-184, samd_posterior_sampled*):
+ * d_best_accept int32[2] = {best candidate row, accept length incl. the root}, d_next_token = the start token drawn for the next step
+ * (torch.multinomial over sample_p, SO/utils.py:84); then update_state's selection (SO/samd_model.py:165-169), DraftModel.update and the
+ * next lookup as in samd_session_step.  All three operands are read on the device: the step needs no host round trip before it. */
+int samd_session_step_given(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, const int32_t *d_best_accept,
+                            const int32_t *d_next_token, void *stream);
 int samd_session_read_verdict(samd_session_t *s, samd_verdict_host_t *out, void *stream);
 /* DraftModel.update(tokens) with the accepted tokens of the last verdict  -- SO/draft.py:62-67 */
 int samd_session_commit(samd_session_t *s, const samd_static_t *sam, void *stream);

@@ -600,3 +600,35 @@ __device__ __forceinline__ void do_accept(const SessionDev &D, StepShared &sh, c
     __syncthreads();
     accept_out = a; next_token_out = next_token;
 }
+
+// update_state's selection (samd_sam_only/samd_model.py:165-169) for a verdict that was decided elsewhere -- the sampling branch of
+// eval_posterior (utils.py:142-184, samd_posterior_sampled*): given[0] = best candidate row, given[1] = accept length (root included),
+// *next_token = the start token drawn for the next step.  Everything else is do_accept's bookkeeping.
+__device__ __forceinline__ void do_accept_given(const SessionDev &D, StepShared &sh, const int *given, const int *next_token_ptr, int type, int n,
+                                                int n_leaves, int max_depth, int &accept_out, int &next_token_out) {
+    const int i = lane_id();
+    int best = given[0], a = given[1];
+    best = best < 0 ? 0 : (best >= n_leaves ? (n_leaves > 0 ? n_leaves - 1 : 0) : best);
+    a = a < 1 ? 1 : (a > max_depth ? max_depth : a);
+    if (i < a) {
+        const int node = sh.path[best][i];
+        const int tk = node == PATH_PAD ? 0 : sh.tokens[node];
+        sh.accepted[i] = tk;
+        D.acc_tokens[i] = tk;
+        D.kv_index[i] = node == PATH_PAD ? -1 : node;
+    }
+    const int nn_raw = sh.path[best][a - 1];
+    const int nn = nn_raw == PATH_PAD ? n - 1 : nn_raw;
+    const int next_token = next_token_ptr[0];
+    if (i == 0) {
+        const int start = D.cache_length[0];
+        D.verdict[V_BEST] = best; D.verdict[V_ACCEPT] = a; D.verdict[V_NEXT_NODE] = nn; D.verdict[V_NEXT_TOKEN] = next_token;
+        D.verdict[V_KV_START] = start; D.verdict[V_IS_TREE] = (type != 0);
+        D.cache_length[0] = start + a;
+        D.start_token[0] = next_token;
+        D.counters[C_STEPS] += 1; D.counters[C_TOKENS] += a;
+        D.counters[type == 0 ? C_SEQ_STEPS : C_TREE_STEPS] += 1;
+    }
+    __syncthreads();
+    accept_out = a; next_token_out = next_token;
+}

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_build_chain(const SamNode *__restrict__
 // ================================================================================================
 enum { OP_RESET = 1, OP_ADD = 2, OP_DYN_WALK = 4, OP_ST_WALK = 8, OP_DRAFT = 16, OP_ACCEPT = 32, OP_COMMIT = 64,
        OP_DRAFT_SEQ = 128, OP_DRAFT_TREE = 256, OP_DRAFT_FIXED = 512, OP_SET_DRAFT = 1024, OP_SET_CURSORS = 2048,
-       OP_BUFFERS_ONLY = 4096 };
+       OP_BUFFERS_ONLY = 4096, OP_ACCEPT_GIVEN = 8192 };
 
 struct StepArgs {
     int ops;
@@ -97,6 +97,8 @@ struct StepArgs {
     int32_t *out2;              // optional (index,length) result of a walk
     const int32_t *start_token; // OP_DRAFT
     const int32_t *node_argmax; // OP_ACCEPT
+    const int32_t *given;       // OP_ACCEPT_GIVEN: {best row, accept length}
+    const int32_t *given_next;  // OP_ACCEPT_GIVEN: the next start token
     int index, match, start, source, type, reverse;
     int c0, c1, c2, c3;         // OP_SET_CURSORS
     int have_static;
@@ -145,6 +147,12 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         int type, n, nl, md, a, nt;
         load_draft(D, sh, type, n, nl, md);
         do_accept(D, sh, A.node_argmax, type, n, nl, md, a, nt);
+        wave_mem_sync();
+    }
+    if (A.ops & OP_ACCEPT_GIVEN) {
+        int type, n, nl, md, a, nt;
+        load_draft(D, sh, type, n, nl, md);
+        do_accept_given(D, sh, A.given, A.given_next, type, n, nl, md, a, nt);
         wave_mem_sync();
     }
     if (A.ops & OP_COMMIT) {
@@ -311,6 +319,17 @@ __global__ __launch_bounds__(64) void k_scripted_logits(SessionDev D, const int3
     h = (h * 2654435761ull) & 0xFFFFFFFFull;
     const int tok = 3 + (int)(h % (unsigned long long)(markov_vocab - 3));
     if (tok != argmax[i]) row[tok] = (T)(64.f - 4.f * (float)c);
+}
+
+// gen_candidates' gather for the draft held in the session (samd_sam_only/utils.py:92-96): candidate_tokens = (tokens + [0])[retrieve]
+// as int64 [leaves][depth], and the retrieve table itself as the cell -> node map of samd_posterior_sampled_nodes
+__global__ __launch_bounds__(256) void k_session_candidates(SessionDev D, long long *__restrict__ cand, int32_t *__restrict__ rowmap, int cap) {
+    const int nl = D.dmeta[D_NLEAVES], md = D.dmeta[D_MAXDEPTH];
+    for (int k = threadIdx.x; k < nl * md && k < cap; k += blockDim.x) {
+        const int v = D.retrieve[k];
+        rowmap[k] = v;
+        cand[k] = v < 0 ? 0 : (long long)D.tokens[v];
+    }
 }
 
 // ================================================================================================
@@ -675,6 +694,21 @@ int samd_session_step(samd_session_t *s, const samd_static_t *sam, const samd_pa
     StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_ACCEPT | OP_COMMIT | OP_DRAFT; A.node_argmax = d_node_argmax;
     A.start_token = s->dev.start_token;
     return launch_session(s, sam, p, A, stream);
+}
+
+int samd_session_step_given(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, const int32_t *d_best_accept, const int32_t *d_next_token,
+                            void *stream) {
+    if (!p || !d_best_accept || !d_next_token || !s) return SAMD_E_INVALID;
+    StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_ACCEPT_GIVEN | OP_COMMIT | OP_DRAFT; A.given = d_best_accept; A.given_next = d_next_token;
+    A.start_token = s->dev.start_token;
+    return launch_session(s, sam, p, A, stream);
+}
+
+int samd_session_candidates(samd_session_t *s, int64_t *d_candidates, int32_t *d_rowmap, int32_t capacity, void *stream) {
+    if (!s || !d_candidates || !d_rowmap || capacity < 1) return SAMD_E_INVALID;
+    hipLaunchKernelGGL(k_session_candidates, dim3(1), dim3(256), 0, (hipStream_t)stream, s->dev, (long long *)d_candidates, d_rowmap, capacity);
+    LAUNCHCHK();
+    return SAMD_OK;
 }
 
 int samd_session_device_views(samd_session_t *s, void *out[16]) {

@@ -109,6 +109,8 @@ _PROTOS = {
     "samd_session_read_verdict": (C.c_int, [_VP, _VP, _VP]),
     "samd_session_commit": (C.c_int, [_VP, _VP, _VP]),
     "samd_session_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "samd_session_step_given": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "samd_session_candidates": (C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     "samd_session_set_cache_length": (C.c_int, [_VP, _I32, _VP]),
     "samd_session_get_cache_length": (C.c_int, [_VP, _VP, _VP]),
     "samd_kv_compact": (C.c_int, [_VP, _VP, _I32, _I32, _I64, _I32, _I32, _VP]),
@@ -455,6 +457,13 @@ class Session:
     def step(self, sam, params, d_node_argmax):
         check(lib().samd_session_step(self._h, sam._h if sam is not None else None, C.byref(params), _ptr(d_node_argmax),
                                       current_stream()))
+
+    def candidates(self, d_candidates, d_rowmap):
+        check(lib().samd_session_candidates(self._h, _ptr(d_candidates), _ptr(d_rowmap), d_rowmap.numel(), current_stream()))
+
+    def step_given(self, sam, params, d_best_accept, d_next_token):
+        check(lib().samd_session_step_given(self._h, sam._h if sam is not None else None, C.byref(params), _ptr(d_best_accept), _ptr(d_next_token),
+                                            current_stream()))
 
     def set_cache_length(self, length):
         check(lib().samd_session_set_cache_length(self._h, int(length), current_stream()))

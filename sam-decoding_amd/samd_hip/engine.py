@@ -251,6 +251,74 @@ class DecodeEngine:
         torch.cuda.current_stream().synchronize()
         return StepReport(self._report_np)
 
+    # ---- sampling (SO/utils.py:66-104 gen_candidates with greedy=False, :142-184 eval_posterior's sampling branch) ------------------
+    # The whole step stays on the device: candidates gathered from the session's draft block, HF's warpers + softmax over the <= 64
+    # node rows, the accept / reject walk in samd_posterior_sampled_nodes, the next start token drawn by torch.multinomial, and
+    # samd_session_step_given (accept the given verdict, update both automata, next lookup) -- ONE host synchronisation per step (the
+    # report + how many uniforms of the host's `random` stream the walk consumed), where the granular decode() makes four.
+    def supports_fused_sampling(self):
+        return self.recycle is None and type(self) is DecodeEngine
+
+    def start_sampled(self, input_ids):
+        s = self.session
+        s.reset()
+        ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int32)
+        last = []
+        self._ingest_beside(ids, lambda: last.append(self.verifier.prefill(s, ids, None)))
+        if last[0] is None:
+            raise SamdError("this verifier does not expose logits; sampling needs them")
+        sample_p = torch.softmax(last[0].reshape(1, -1).float(), dim=-1)         # SamdModel.prefill's return when not greedy
+        self._start = torch.multinomial(sample_p, 1).reshape(-1).to(torch.int32)  # gen_candidates, utils.py:84
+        s.set_start_token(self._start)
+        s.draft(self.static, self.params, self._views["start_token"])
+        s.report_async(self.report_buf)
+        torch.cuda.current_stream().synchronize()
+        return StepReport(self._report_np)
+
+    def step_sampled(self, rep, gen_config):
+        import random
+        s = self.session
+        n, C_, D = rep.n, max(rep.n_leaves, 1), max(rep.max_depth, 1)
+        R = self.verifier.bucket(n)
+        self.bucket_steps[R] = self.bucket_steps.get(R, 0) + 1
+        b = self.verifier.verify(s, R)
+        node_logits = b["logits"][:n]
+        V = node_logits.shape[-1]
+        if getattr(self, "_samp", None) is None or self._samp["work"].dtype != node_logits.dtype or self._samp["work"].numel() != V:
+            self._samp = dict(cand=torch.zeros(MAX_DRAFT * MAX_DRAFT, dtype=torch.int64, device=self.device),
+                              rowmap=torch.zeros(MAX_DRAFT * MAX_DRAFT, dtype=torch.int32, device=self.device),
+                              work=torch.empty(V, dtype=node_logits.dtype, device=self.device),
+                              out=torch.zeros(5, dtype=torch.int32, device=self.device),
+                              out_host=torch.zeros(5, dtype=torch.int32).pin_memory())
+        t = self._samp
+        s.candidates(t["cand"], t["rowmap"])
+        probs = torch.softmax(gen_config.logits_processor(None, node_logits), dim=-1).contiguous()
+        n_u = C_ * D + 8
+        state = random.getstate()                                                 # the RNG contract of samd_posterior_sampled
+        u = torch.from_numpy(np.asarray([random.random() for _ in range(n_u)], dtype=np.float64)).to(self.device)
+        from . import _ptr, check, current_stream, lib
+        check(lib().samd_posterior_sampled_nodes(_ptr(probs), torch_dtype_code(probs.dtype), _ptr(t["rowmap"]), n, _ptr(t["cand"]), C_, D, V,
+                                                 _ptr(u), n_u, _ptr(t["work"]), _ptr(t["out"]), current_stream()))
+        out = t["out"]
+        cell = out[0].long() * D + out[1].long() - 1
+        node = t["rowmap"][cell].long()
+        node = torch.where((node < 0) | (node >= n), torch.full_like(node, n - 1), node)
+        p_raw = torch.softmax(node_logits[node], dim=0)                           # utils.py:178: the RAW logits of the accepted node
+        sample_p = torch.where(out[3] != 0, t["work"], p_raw)                     # utils.py:176-177: the residual after a final rejection
+        self._start = torch.multinomial(sample_p.view(1, -1), 1).reshape(-1).to(torch.int32)
+        s.step_given(self.static, self.params, out, self._start)
+        self.verifier.compact(s)
+        s.report_async(self.report_buf)
+        t["out_host"].copy_(out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        used, status = int(t["out_host"][2]), int(t["out_host"][4])
+        random.setstate(state)
+        for _ in range(used):
+            random.random()
+        if status:
+            raise SamdError("samd_posterior_sampled ran out of uniforms")
+        return StepReport(self._report_np)
+
     def _capture(self, R):
         """capture the step for row bucket R.  Capture records the launches without executing them, so the request's
         state is untouched; the verifier first runs the bucket once with n = 0 rows (no K/V write, every query row

@@ -216,18 +216,26 @@ class SamdModel(nn.Module):
             generation_config = SamdGenerationConfig()
         self.gen_config = generation_config
         assert input_ids.shape[0] == 1, "Only support batch_size == 1"  # [1, N]
-        if not generation_config.greedy:
-            yield from self._run_granular(input_ids, generation_config, max_steps)
-            return
+        sampled = not generation_config.greedy
+        if sampled:
+            self.set_cache(generation_config)
+            # the fused sampling step (engine.step_sampled: one host synchronisation per step) needs the verify forward's logits on
+            # the device and the plain SAM-only engine; anything else decodes through the granular prefill() / decode() loop
+            has_logits = isinstance(self.verifier, LlamaRunner) or hasattr(self.verifier, "runner") or bool(getattr(self.verifier, "with_logits", False))
+            fused = (os.environ.get("SAMD_FUSED_SAMPLING", "1") != "0" and has_logits
+                     and getattr(self.engine, "supports_fused_sampling", lambda: False)())
+            if not fused:
+                yield from self._run_granular(input_ids, generation_config, max_steps)
+                return
         self.set_cache(generation_config)
-        rep = self.engine.start(input_ids)
+        rep = self.engine.start_sampled(input_ids) if sampled else self.engine.start(input_ids)
         input_length = input_ids.shape[-1]
         decode_tokens = 0
         for _ in range(max_steps):
             if input_length + decode_tokens + self.samd_config.max_predicts >= generation_config.max_cache_len:
                 break
             kind = "sequence" if rep.type == 0 else "tree"
-            rep = self.engine.step(rep.n)
+            rep = self.engine.step_sampled(rep, generation_config) if sampled else self.engine.step(rep.n)
             if rep.error:
                 raise RuntimeError(f"dynamic suffix automaton capacity exceeded (status {rep.error})")
             new_ids, stop = self._truncate(rep.tokens)

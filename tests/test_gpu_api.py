@@ -291,6 +291,42 @@ def test_sampling_generate_runs_and_is_seeded():
     assert seq[:len(prompt)] == prompt and len(seq) > len(prompt) and all(0 <= t < 512 for t in seq)
 
 
+@pytest.mark.parametrize("with_static", [False, True])
+@pytest.mark.parametrize("temperature,top_p,top_k", [(0.8, 0.9, 0), (1.0, 0.0, 20), (0.3, 0.0, 0)])
+def test_fused_sampling_step_equals_the_granular_loop(monkeypatch, with_static, temperature, top_p, top_k):
+    """generate(greedy=False) in its fused form (engine.step_sampled: candidates, warpers, the accept / reject walk, the next start
+    token's draw and samd_session_step_given all on the device, ONE host synchronisation per step) must reproduce the granular
+    prefill() / decode() loop -- the reference's own shape (samd_model.py:96-174, utils.py:66-184), itself pinned to the recorded
+    reference at the posterior level -- token for token, step for step, and leave BOTH random streams (host `random`, torch) where that
+    loop leaves them.  Sequence drafts only (no static automaton) and tree drafts (a static automaton the prompt was drawn from)."""
+    import random
+    import samd_sam_only as SO
+    from samd_hip.llama import LlamaRunner
+    from util import markov_stream
+    mcfg = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                vocab_size=512, max_position_embeddings=256, rms_norm_eps=1e-5)
+    rng = np.random.default_rng(3)
+    docs = [markov_stream(rng, 200, vocab=512) for _ in range(6)] + [[i] for i in range(512)]
+    prompt = (docs[1][20:44] + docs[3][5:17])[:32]
+    ids = torch.tensor([prompt], device="cuda")
+    g = SO.SamdGenerationConfig(max_new_tokens=28, max_cache_len=256, greedy=False, temperature=temperature, top_p=top_p, top_k=top_k)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SAMD_FUSED_SAMPLING", mode)
+        runner = LlamaRunner.random_init(mcfg, 256, torch.float16, seed=4, std=0.05)
+        cfg = SO.SamdConfig(max_predicts=16, len_bias=0)
+        sam = SO.build_sam(docs, 2) if with_static else None
+        model = SO.SamdModel(cfg, runner, SO.DraftModel(cfg, sam_static=sam, device="cuda"), 2, torch.float16, "cuda")
+        random.seed(11); torch.manual_seed(11)
+        out = model.generate(ids, generation_config=g)
+        res[mode] = (out.output_ids, out.decode_steps, out.accepet_length_per_step, random.random(), torch.rand(1, device="cuda").item(),
+                     dict((k, list(v)) for k, v in model.lookup_stats.items()))
+    assert res["1"] == res["0"]
+    assert res["1"][1] >= 1 and len(res["1"][0][0]) > len(prompt)
+    if with_static:
+        assert res["1"][5]["tree"][0] > 0                   # tree drafts took part
+
+
 def test_runner_shorter_than_generation_config_is_an_error():
     """a ready-made runner holds K/V rows for ITS max_cache_len only: asking for a longer generation must raise instead of
     silently dropping rows past the end (reference: the cache is always sized from generation_config, samd_model.py:176-191);
