@@ -1,6 +1,7 @@
-"""gemm_probe.py -- only the weight-streaming projections of ONE decoder layer + lm_head (k_gemm_skinny at 16 rows, Vicuna-7B
-shapes, packed weights), rotating over three weight sets so that nothing is served from the Infinity Cache; for rocprofv3
---stats / --pmc passes (scripts/pmc_gemm.sh).  usage: python3 scripts/gemm_probe.py [layers_worth_of_launches] [rows]"""
+"""gemm_probe.py -- only the weight-streaming projections of ONE decoder layer as the runner launches them at <= 16 rows (Vicuna-7B
+shapes): k_gemm_qkv_rope (q|k|v + RoPE + K/V write), k_gemm_skinny (o, down; split-K 8), k_gemm_pairs_silu (gate|up + SiLU), rotating
+over three weight sets so that nothing is served from the Infinity Cache; for rocprofv3 --stats / --pmc passes (scripts/pmc_gemm.sh).
+usage: python3 scripts/gemm_probe.py [layers_worth_of_launches] [rows]"""
 import os
 import sys
 
@@ -8,35 +9,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "sam-decoding_amd")]
 import torch
 import samd_hip
+from samd_hip import _ptr, check
 
 L = samd_hip.lib()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-shapes = [("qkv", 12288, 4096, False), ("o", 4096, 4096, False), ("gate_up", 22016, 4096, True), ("down", 4096, 11008, False)]
+H, D, hid, inter, max_len = 32, 128, 4096, 11008, 2048
+st = samd_hip.current_stream()
 sets = []
 for _ in range(3):
     ws = {}
-    for name, N, K, silu in shapes:
-        w = (torch.randn((N, K), device="cuda") * 0.02).half()
-        p = torch.empty_like(w)
-        samd_hip.check(L.samd_gemm_pack_weights(samd_hip._ptr(w), samd_hip._ptr(p), N, K, samd_hip.current_stream()))
-        ws[name] = p
-        del w
+    w = (torch.randn((3 * hid, hid), device="cuda") * 0.02).half(); p = torch.empty_like(w)
+    check(L.samd_gemm_pack_qkv64(_ptr(w), _ptr(p), 3 * H, hid, st)); ws["qkv"] = p
+    for name, N, K in (("o", hid, hid), ("down", hid, inter)):
+        w = (torch.randn((N, K), device="cuda") * 0.02).half(); p = torch.empty_like(w)
+        check(L.samd_gemm_pack_weights(_ptr(w), _ptr(p), N, K, st)); ws[name] = p
+    w = (torch.randn((2 * inter, hid), device="cuda") * 0.02).half(); p = torch.empty_like(w)
+    check(L.samd_gemm_pack_groups(_ptr(w), _ptr(p), 2 * inter, hid, st)); ws["gate_up"] = p
+    del w
     sets.append(ws)
-A = {K: torch.randn((R, K), device="cuda").half() for K in (4096, 11008)}
-part = torch.zeros(8 * R * 22016, device="cuda", dtype=torch.float32)
-out = torch.zeros((R, 22016), device="cuda", dtype=torch.float16)
+A = {K: torch.randn((R, K), device="cuda").half() for K in (hid, inter)}
+part = torch.zeros(8 * R * hid, device="cuda", dtype=torch.float32)
+act = torch.zeros((R, inter), device="cuda", dtype=torch.float16)
+q = torch.zeros((R, H, D), device="cuda", dtype=torch.float16)
+kv = torch.zeros((2, H, max_len, D), device="cuda", dtype=torch.float16)
+cs = torch.rand((64, D), device="cuda")
+d_L = torch.tensor([800], dtype=torch.int32, device="cuda"); d_n = torch.tensor([max(1, R - 3)], dtype=torch.int32, device="cuda")
 torch.cuda.synchronize()
-st = samd_hip.current_stream()
 nbytes = 0
 for i in range(reps):
-    for name, N, K, silu in shapes:
-        sp = 1 if silu else L.samd_gemm_splits(N, K, R)
-        w = sets[i % 3][name]
-        if silu:
-            samd_hip.check(L.samd_gemm_skinny_silu(samd_hip._ptr(A[K]), samd_hip._ptr(w), R, N, K, samd_hip._ptr(out), samd_hip.F16, st))
-        else:
-            samd_hip.check(L.samd_gemm_skinny(samd_hip._ptr(A[K]), samd_hip._ptr(w), R, N, K, sp, samd_hip._ptr(part), samd_hip._ptr(out), samd_hip.F16, st))
-        nbytes += N * K * 2
+    w = sets[i % 3]
+    check(L.samd_gemm_qkv_rope(_ptr(A[hid]), _ptr(w["qkv"]), R, hid, _ptr(cs), _ptr(d_L), _ptr(d_n), _ptr(q), _ptr(kv[0]), _ptr(kv[1]), H, H, D, max_len, samd_hip.F16, st))
+    check(L.samd_gemm_skinny(_ptr(A[hid]), _ptr(w["o"]), R, hid, hid, L.samd_gemm_splits(hid, hid, R), _ptr(part), None, samd_hip.F16, st))
+    check(L.samd_gemm_pairs_silu(_ptr(A[hid]), _ptr(w["gate_up"]), R, inter, hid, _ptr(act), samd_hip.F16, st))
+    check(L.samd_gemm_skinny(_ptr(A[inter]), _ptr(w["down"]), R, hid, inter, L.samd_gemm_splits(hid, inter, R), _ptr(part), None, samd_hip.F16, st))
+    nbytes += (3 * hid * hid + hid * hid + 2 * inter * hid + hid * inter) * 2
 torch.cuda.synchronize()
-print({"launches": reps * len(shapes), "weight_bytes_per_layer": nbytes // reps})
+print({"launches": reps * 4, "weight_bytes_per_layer": nbytes // reps})

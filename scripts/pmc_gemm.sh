@@ -15,14 +15,14 @@ out = {"counters_per_layer": {}}
 for f in glob.glob("gpurun_out/pmc_gemm/*/*counter_collection.csv") + glob.glob("gpurun_out/pmc_gemm/*/*/*counter_collection.csv"):
     agg = collections.defaultdict(float); launches = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
-        if "k_gemm_skinny" in r["Kernel_Name"]:
+        if "k_gemm_" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); launches[r["Counter_Name"]] += 1
     for c, v in agg.items():
         out["counters_per_layer"][c] = v / (launches[c] / 4)          # 4 projections per layer
 for f in glob.glob("gpurun_out/pmc_gemm/trace/*kernel_stats.csv") + glob.glob("gpurun_out/pmc_gemm/trace/*/*kernel_stats.csv"):
     tot = 0.0; calls = 0
     for r in csv.DictReader(open(f)):
-        if "k_gemm_skinny" in r["Name"]:
+        if "k_gemm_" in r["Name"] and "pack" not in r["Name"]:
             tot += float(r["TotalDurationNs"]); calls += int(r["Calls"])
             out.setdefault("kernels", []).append({k: r[k] for k in ("Name", "Calls", "AverageNs", "MinNs", "MaxNs")})
     out["ns_per_layer"] = tot / (calls / 4)
