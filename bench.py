@@ -629,6 +629,11 @@ def main():
             # the method.  What the path would deliver at the accepted-token counts the reference publishes (README.md:55-57) follows
             # from this run's measured step time: speed-up = MAT x T_AR / T_step.
             "cost_only": args.variant in ("eagle2", "eagle"),
+            # samd[token_recycle]: the synthetic source is order-2 Markov over 32 000 tokens, so a table keyed by ONE token (top-8
+            # successors per token, token_recycle.py:40-48) cannot predict it even with ranked verify rows -- tree steps accept ~1; the
+            # run prices the 61-node tree path (table update + tree fill inside the step graph), the projection below uses the MAT
+            # the reference publishes on natural text.
+            "tree_steps_priced_not_predictive": args.variant == "token_recycle",
             "projected_speedup_of_this_variant": variant_projection(args.variant, ar_tps, dt_max / args.steps * 1e3),
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
             "step_breakdown_by_rows": breakdown, "step_breakdown_named": named,

@@ -494,8 +494,9 @@ int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_t
 /* the same hook for callers that learn from the logits (bench.py --variant token_recycle): on top of the model's own row of draft node
  * i it writes the scripted arg-max as the best entry and, below it, the four successors of the node's two-token context in the bench's
  * sparse order-2 Markov source (bench._succ) in rank order -- a model that continues the text also ranks its plausible continuations.
- * d_argmax int32[64] (samd_scripted_argmax's output), d_logits [64][row_stride] of dtype.  Tests and bench only. */
-int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int64_t row_stride,
+ * d_argmax int32[64] (samd_scripted_argmax's output), d_logits [rows][row_stride] of dtype (rows of the draft beyond `rows` are
+ * left alone).  Tests and bench only. */
+int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride,
                          int32_t markov_vocab, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -306,9 +306,9 @@ __global__ __launch_bounds__(256) void k_transpose_i32(const int32_t *__restrict
 // (a, b) in rank order (bench._succ, the same hash) -- the distribution the synthetic corpus and requests are drawn from.
 template <typename T>
 __global__ __launch_bounds__(64) void k_scripted_logits(SessionDev D, const int32_t *__restrict__ argmax, T *__restrict__ logits, long long stride,
-                                                        int markov_vocab) {
+                                                        int markov_vocab, int rows) {
     const int i = blockIdx.x, n = D.dmeta[D_N];
-    if (i >= n || threadIdx.x > 4) return;
+    if (i >= n || i >= rows || threadIdx.x > 4) return;
     const int b = D.tokens[i], par = D.parent[i];
     const int nc = D.meta[M_NTEXT] - 1;
     const int a = par >= 0 ? D.tokens[par] : (nc > 0 ? D.text[nc] : 0);           // text[0] is the sentinel: text[nc] = last committed token
@@ -798,12 +798,12 @@ int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_t
     return SAMD_OK;
 }
 
-int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int64_t row_stride, int32_t markov_vocab, void *stream) {
+int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride, int32_t markov_vocab, void *stream) {
     if (!s || !d_argmax || !d_logits || markov_vocab < 4 || row_stride < markov_vocab) return SAMD_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_scripted_logits<_Float16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (_Float16 *)d_logits, (long long)row_stride, markov_vocab);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_scripted_logits<__bf16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (__bf16 *)d_logits, (long long)row_stride, markov_vocab);
-    else if (dtype == SAMD_F32) hipLaunchKernelGGL(k_scripted_logits<float>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (float *)d_logits, (long long)row_stride, markov_vocab);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_scripted_logits<_Float16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (_Float16 *)d_logits, (long long)row_stride, markov_vocab, rows);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_scripted_logits<__bf16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (__bf16 *)d_logits, (long long)row_stride, markov_vocab, rows);
+    else if (dtype == SAMD_F32) hipLaunchKernelGGL(k_scripted_logits<float>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (float *)d_logits, (long long)row_stride, markov_vocab, rows);
     else return SAMD_E_INVALID;
     LAUNCHCHK();
     return SAMD_OK;

@@ -101,7 +101,7 @@ _PROTOS = {
     "samd_session_report_async": (C.c_int, [_VP, _VP, _VP]),
     "samd_session_set_start_token": (C.c_int, [_VP, _VP, _VP]),
     "samd_scripted_argmax": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP]),
-    "samd_scripted_logits": (C.c_int, [_VP, _VP, _VP, _I32, _I64, _I32, _VP]),
+    "samd_scripted_logits": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),
     "samd_session_device_views": (C.c_int, [_VP, _VP]),
     "samd_tree_buffers": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_argmax_rows": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),
@@ -433,7 +433,7 @@ class Session:
         check(lib().samd_session_report_async(self._h, _ptr(h_pinned), current_stream()))
 
     def scripted_logits(self, d_argmax, logits, markov_vocab):
-        check(lib().samd_scripted_logits(self._h, _ptr(d_argmax), _ptr(logits), torch_dtype_code(logits.dtype), logits.stride(0), markov_vocab, current_stream()))
+        check(lib().samd_scripted_logits(self._h, _ptr(d_argmax), _ptr(logits), torch_dtype_code(logits.dtype), logits.shape[0], logits.stride(0), markov_vocab, current_stream()))
 
     def scripted_argmax(self, d_target, n_target, vocab, d_out):
         check(lib().samd_scripted_argmax(self._h, _ptr(d_target), n_target, vocab, _ptr(d_out), current_stream()))

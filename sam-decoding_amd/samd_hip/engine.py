@@ -268,12 +268,26 @@ class DecodeEngine:
         if last[0] is None:
             raise SamdError("this verifier does not expose logits; sampling needs them")
         sample_p = torch.softmax(last[0].reshape(1, -1).float(), dim=-1)         # SamdModel.prefill's return when not greedy
-        self._start = torch.multinomial(sample_p, 1).reshape(-1).to(torch.int32)  # gen_candidates, utils.py:84
+        self._start = self._draw(sample_p)                                        # gen_candidates, utils.py:84
         s.set_start_token(self._start)
         s.draft(self.static, self.params, self._views["start_token"])
         s.report_async(self.report_buf)
         torch.cuda.current_stream().synchronize()
         return StepReport(self._report_np)
+
+    def _draw(self, sample_p):
+        """the next step's start token.  The reference draws it at the START of a decode step (gen_candidates), the fused step at the
+        END of the previous one (it is samd_session_step_given's lookup key) -- so the draw made by the last step of a request is one
+        the reference never makes: the generator state before each draw is kept (host-side: seed + offset, no device round trip)
+        and undo_pending_draw() puts it back when the request ends."""
+        self._rng_before_draw = torch.cuda.get_rng_state(self.device)
+        return torch.multinomial(sample_p, 1).reshape(-1).to(torch.int32)
+
+    def undo_pending_draw(self):
+        state = getattr(self, "_rng_before_draw", None)
+        if state is not None:
+            torch.cuda.set_rng_state(state, self.device)
+            self._rng_before_draw = None
 
     def step_sampled(self, rep, gen_config):
         import random
@@ -305,7 +319,7 @@ class DecodeEngine:
         node = torch.where((node < 0) | (node >= n), torch.full_like(node, n - 1), node)
         p_raw = torch.softmax(node_logits[node], dim=0)                           # utils.py:178: the RAW logits of the accepted node
         sample_p = torch.where(out[3] != 0, t["work"], p_raw)                     # utils.py:176-177: the residual after a final rejection
-        self._start = torch.multinomial(sample_p.view(1, -1), 1).reshape(-1).to(torch.int32)
+        self._start = self._draw(sample_p.view(1, -1))
         s.step_given(self.static, self.params, out, self._start)
         self.verifier.compact(s)
         s.report_async(self.report_buf)

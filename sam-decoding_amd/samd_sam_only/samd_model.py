@@ -231,22 +231,26 @@ class SamdModel(nn.Module):
         rep = self.engine.start_sampled(input_ids) if sampled else self.engine.start(input_ids)
         input_length = input_ids.shape[-1]
         decode_tokens = 0
-        for _ in range(max_steps):
-            if input_length + decode_tokens + self.samd_config.max_predicts >= generation_config.max_cache_len:
-                break
-            kind = "sequence" if rep.type == 0 else "tree"
-            rep = self.engine.step_sampled(rep, generation_config) if sampled else self.engine.step(rep.n)
-            if rep.error:
-                raise RuntimeError(f"dynamic suffix automaton capacity exceeded (status {rep.error})")
-            new_ids, stop = self._truncate(rep.tokens)
-            decode_tokens += len(new_ids)
-            self.lookup_stats[kind][0] += 1
-            self.lookup_stats[kind][1] += len(new_ids)
-            if self.cache is not None:
-                self.cache.cache_length = self.cache.last_length = input_length + decode_tokens
-            yield new_ids, rep
-            if stop or decode_tokens >= generation_config.max_new_tokens:
-                break
+        try:
+            for _ in range(max_steps):
+                if input_length + decode_tokens + self.samd_config.max_predicts >= generation_config.max_cache_len:
+                    break
+                kind = "sequence" if rep.type == 0 else "tree"
+                rep = self.engine.step_sampled(rep, generation_config) if sampled else self.engine.step(rep.n)
+                if rep.error:
+                    raise RuntimeError(f"dynamic suffix automaton capacity exceeded (status {rep.error})")
+                new_ids, stop = self._truncate(rep.tokens)
+                decode_tokens += len(new_ids)
+                self.lookup_stats[kind][0] += 1
+                self.lookup_stats[kind][1] += len(new_ids)
+                if self.cache is not None:
+                    self.cache.cache_length = self.cache.last_length = input_length + decode_tokens
+                yield new_ids, rep
+                if stop or decode_tokens >= generation_config.max_new_tokens:
+                    break
+        finally:
+            if sampled:                       # the start token drawn for a step that will not happen (engine._draw)
+                self.engine.undo_pending_draw()
 
     def _run_granular(self, input_ids, generation_config, max_steps):
         """the reference's own loop over prefill()/decode() (sampling needs the logits on the host side of the API)."""

@@ -545,6 +545,21 @@ def test_tree_buffers_malformed_parents_terminate():
     assert ret.tolist() == want["tree_retrieve_indices"].tolist()
 
 
+def test_scripted_logits_stay_inside_the_buffer():
+    """samd_scripted_logits (bench / tests only) writes one ranked row per draft node; a draft with more nodes than the logits buffer
+    has rows (a 61-node tree replayed through the 48-row bucket's graph, as bench.py's per-bucket breakdown does) must leave the
+    memory behind the buffer alone."""
+    n, rows, vocab = 61, 48, 512
+    sess = samd_hip.Session(256)
+    sess.set_draft(dev(list(range(10, 10 + n))), dev(random_parents(np.random.default_rng(5), n, "bushy")), n, type_=1)
+    arg = dev([(7 * i + 3) % vocab for i in range(64)])
+    guard = torch.zeros((64, vocab), dtype=torch.float16, device="cuda")
+    sess.scripted_logits(arg, guard[:rows], vocab)
+    torch.cuda.synchronize()
+    assert guard[:rows].argmax(dim=1).tolist() == arg[:rows].tolist()
+    assert float(guard[rows:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("vocab,rows", [(512, 7), (32000, 61), (4097, 3), (128256, 9)])
 def test_recycle_update_split_topk_matches_torch(dtype, vocab, rows):
