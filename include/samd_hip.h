@@ -471,8 +471,8 @@ int samd_gemm_pack_groups(const void *d_W, void *d_packed, int32_t N, int32_t K,
 int samd_gemm_pairs_silu(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t inter, int32_t K, void *d_out, int32_t dtype, void *stream);
 /* The q|k|v projection with RoPE and SamdStaticCache.update's row write (SO/cache.py:103-115) as its epilogue -- what samd_gemm_skinny
  * (q|k|v weights) + samd_rope_kv_write_cs do in two launches and a round trip of fp32 partial sums.  d_W64 = the [q|k|v] weight
- * matrix ((n_heads + 2 n_kv_heads) * 128 rows, K columns) packed by samd_gemm_pack_qkv64 (64-column tiles holding 32 rotate_half
- * pairs of one head each); d_cs = samd_rope_rows' per-row cos | sin; q_out [rows][n_heads][128]; K / V rows go to
+ * matrix ((n_heads + 2 n_kv_heads) * 128 rows, K columns) packed by samd_gemm_pack_qkv64 (tiles of 24 or 32 complete rotate_half
+ * pairs = 48 or 64 columns; the library picks the width from the matrix and the CU count, the same way in both calls); d_cs = samd_rope_rows' per-row cos | sin; q_out [rows][n_heads][128]; K / V rows go to
  * [n_kv_heads][max_len][128] caches at [L, L + n).  One workgroup per tile, no split-K: worth it when there are >= ~150 tiles
  * (a 32-head MHA model has 192; the runner keeps the two-launch path otherwise).  Call sites replaced: SO/samd_model.py:134-138
  * (the q/k/v projections, rotary embedding and cache update inside HF's LlamaAttention.forward). */

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
 // The stream itself is k_gemm_skinny's: LDS-DMA'd A chunks shared by all waves, hand-issued nt weight loads with DEPTH chunks in flight
 // (32 KiB chunks: DEPTH 4 = the same 128 KiB per workgroup), counted waits, bare barriers.
 // ================================================================================================
-template <typename TT, int RT, int DEPTH>
+template <typename TT, int RT, int DEPTH, int CG>
 __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void k_gemm_qkv_rope(
         const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W, int K, int n_chunks,
         const float *__restrict__ cs, const int *__restrict__ d_L, const int *__restrict__ d_n,
@@ -232,13 +232,18 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
     constexpr int NT = 64 * GEMM_WAVES;
     constexpr int XV = (R * 32) / NT;              // 16-byte units per thread to stage one A chunk
     constexpr int NB = DEPTH + 1;
-    constexpr int WL = 4;                          // weight loads per lane and chunk
+    constexpr int WL = 4;                          // weight loads per lane and chunk (streaming waves)
+    constexpr int TW = 16 * CG, PP = 8 * CG;       // tile width in columns, rotate_half pairs per tile
+    constexpr int CH = CG * 8192;                  // bytes of one (tile, chunk) block
     extern __shared__ __attribute__((aligned(1024))) char gemm_lds[];
     E (*xs)[R][GEMM_KC] = reinterpret_cast<E (*)[R][GEMM_KC]>(gemm_lds);
 
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4, cg = w & 3, kh = w >> 2;
-    const char *wtile = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * 32768;
-    const uint32_t wlane = (uint32_t)tid * 16;
+    // waves 0 .. 2 CG - 1 stream and multiply (column group cg, k half kh); with 48-column tiles waves 6, 7 only help staging A
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
+    const bool streams = CG == 4 || w < 2 * CG;
+    const int cg = CG == 4 ? (w & 3) : (streams ? w % CG : 0), kh = CG == 4 ? (w >> 2) : (streams ? w / CG : 0);
+    const char *wtile = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * CH;
+    const uint32_t wlane = (uint32_t)(64 * (CG * kh + cg) + l) * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)&xs[0][0][0];
     // the scalars and this thread's cos | sin are requested now and used after the stream
     const int n_rows = d_n[0], L = d_L[0];
@@ -249,10 +254,10 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
 
     u32x4 wr[DEPTH][2][2];
     auto load_wb = [&](u32x4 (&dst)[2][2], int c, int bl) {
-        const char *p = wtile + (size_t)c * 32768;
+        const char *p = wtile + (size_t)c * CH;
 #pragma unroll
         for (int j = 0; j < 2; j++)
-            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[bl][j]) : "v"(wlane), "s"(p + 8192 * (2 * bl + j)) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[bl][j]) : "v"(wlane), "s"(p + (CH / 4) * (2 * bl + j)) : "memory");
     };
     auto stage_xi = [&](int c, int buf, int i) {
         const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
@@ -262,15 +267,22 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
         asm volatile("" ::: "memory");
     };
     auto issue = [&](u32x4 (&dst)[2][2], int c, int buf) {
-        load_wb(dst, c, 0); load_wb(dst, c, 1);
+        if (streams) { load_wb(dst, c, 0); load_wb(dst, c, 1); }
 #pragma unroll
         for (int i = 0; i < XV; i++) stage_xi(c, buf, i);
     };
     auto landed = [&](int younger) {               // memory ops retire in issue order: chunk c has landed when only the younger ones may still fly
-        if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (WL + XV)) : "memory");
-        else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (WL + XV)) : "memory");
-        else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + XV) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        if (streams) {
+            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (WL + XV)) : "memory");
+            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (WL + XV)) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + XV) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        } else {                                   // a staging-only wave has XV operations per chunk in flight
+            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XV) : "memory");
+            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XV) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XV) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
@@ -279,6 +291,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
         const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
         for (int bl = 0; bl < 2; bl++) {
+            if (!streams) break;
             const int b = 2 * kh + bl;
             const uint32_t a0 = xbase + (uint32_t)((8 * b + 2 * g) ^ n) * 16, a1 = xbase + (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;
             u32x4 r[RT][2];
@@ -316,22 +329,23 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
                 if (c + d < n_chunks) { phase(wr[d], c + d, buf); buf = buf == NB - 1 ? 0 : buf + 1; }
         }
     }
-    // ---- epilogue: the two k halves meet in LDS ([2][R][64] fp32; the A tiles are dead), then RoPE + rounding + row writes -------------
+    // ---- epilogue: the two k halves meet in LDS ([2][R][TW] fp32; the A tiles are dead), then RoPE + rounding + row writes -------------
     float *ex = reinterpret_cast<float *>(gemm_lds);
     __syncthreads();
+    if (streams) {
 #pragma unroll
-    for (int mt = 0; mt < RT; mt++)
+        for (int mt = 0; mt < RT; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) ex[(kh * R + 16 * mt + 4 * g + r) * 64 + 16 * cg + n] = acc[mt][r];     // C layout: lane holds rows 4g + r of column n
+            for (int r = 0; r < 4; r++) ex[(kh * R + 16 * mt + 4 * g + r) * TW + 16 * cg + n] = acc[mt][r];     // C layout: lane holds rows 4g + r of column n
+    }
     __syncthreads();
-    const int tile = blockIdx.x, head = tile >> 1, half = tile & 1;
-    for (int i = tid; i < R * 32; i += NT) {
-        const int row = i >> 5, p = i & 31;
+    for (int i = tid; i < R * PP; i += NT) {
+        const int row = i / PP, p = i % PP;
         if (row >= n_rows || L + row >= max_len) continue;                     // rows past the draft / past the cache are not written (k_rope_kv)
         // sums rounded to the model dtype first, as the projection's own output would have been (k_rope_kv does the same on partials)
-        const float x1 = (float)(E)(ex[row * 64 + p] + ex[(R + row) * 64 + p]);
-        const float x2 = (float)(E)(ex[row * 64 + 32 + p] + ex[(R + row) * 64 + 32 + p]);
-        const int j = 32 * half + p;                                              // position inside the head: j and j + 64
+        const float x1 = (float)(E)(ex[row * TW + p] + ex[(R + row) * TW + p]);
+        const float x2 = (float)(E)(ex[row * TW + PP + p] + ex[(R + row) * TW + PP + p]);
+        const int pair = PP * (int)blockIdx.x + p, head = pair >> 6, j = pair & 63;   // global pair index -> head, position inside it (j and j + 64)
         if (head >= H + Hkv) {                                                    // V: plain rows
             E *dst = v_cache + ((size_t)(head - H - Hkv) * max_len + L + row) * 128;
             dst[j] = (E)x1; dst[j + 64] = (E)x2;
@@ -344,19 +358,37 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
     }
 }
 
-// row-major [N][K] -> the 64-column-tile packed layout of k_gemm_qkv_rope, with the head-pair row permutation: packed row 64 t + q
-// = source row 128 (t / 2) + 32 (t % 2) + (q < 32 ? q : 32 + q)   (q in [32, 64) -> head column 64 + 32 half + (q - 32))
-__global__ __launch_bounds__(256) void k_gemm_pack_qkv64(const uint4 *__restrict__ W, uint4 *__restrict__ out, int N, int K) {
+// row-major [N][K] -> the packed tile layout of k_gemm_qkv_rope<CG> (16 CG columns per tile), with the rotate_half row permutation:
+// pairs are numbered head by head (pair P = 64 head + j stands for head columns j and 64 + j); tile t holds pairs [8 CG t, 8 CG (t + 1)) --
+// packed row 16 CG t + q = the FIRST column of pair 8 CG t + q for q < 8 CG, the SECOND column of pair 8 CG t + q - 8 CG otherwise.
+//   block (tile t, chunk c) = CG x 8 KiB contiguous at ((t * K/256 + c) * 512 CG) uint4 units; unit (2 bl + j) * 128 CG + x holds
+//   Wperm[16 CG t + 16 cg + n][256 c + 64 (2 kh + bl) + 16 g + 8 j .. +7] for x = 64 (CG kh + cg) + 16 g + n.
+template <int CG>
+__global__ __launch_bounds__(256) void k_gemm_pack_qkv(const uint4 *__restrict__ W, uint4 *__restrict__ out, int N, int K) {
     const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)N * K / 8;
     if (u >= total) return;
+    constexpr int PP = 8 * CG;
     const int n_chunks = K / GEMM_KC;
-    const long long blk = u >> 11;                                   // 2048 units per 32 KiB block
-    const int in = (int)(u & 2047), jj = in >> 9, tid = in & 511, w = tid >> 6, g = (tid >> 4) & 3, n = tid & 15, cg = w & 3, kh = w >> 2;
+    const long long blk = u / (512 * CG);
+    const int in = (int)(u % (512 * CG)), jj = in / (128 * CG), x = in % (128 * CG), w = x >> 6, g = (x >> 4) & 3, n = x & 15, cg = w % CG, kh = w / CG;
     const int t = (int)(blk / n_chunks), c = (int)(blk % n_chunks), bl = jj >> 1, j = jj & 1;
-    const int q = 16 * cg + n;
-    const long long row = 128LL * (t >> 1) + 32 * (t & 1) + (q < 32 ? q : 32 + q), col = 256LL * c + 64 * (2 * kh + bl) + 16 * g + 8 * j;
+    const int q = 16 * cg + n, pair = PP * t + (q < PP ? q : q - PP);
+    const long long row = 128LL * (pair >> 6) + (pair & 63) + (q < PP ? 0 : 64), col = 256LL * c + 64 * (2 * kh + bl) + 16 * g + 8 * j;
     out[u] = W[(row * K + col) / 8];
+}
+
+// 48-column tiles (3 column groups) when they divide the matrix and need no more rounds of workgroups over the CUs than 64-column tiles:
+// Vicuna-7B's 12288 q|k|v columns = 256 tiles of 48 = one workgroup on every CU (64-column tiles: 192 workgroups, a quarter of the CUs idle
+// in a launch bound by what a CU's memory pipe ingests); Vicuna-13B's 15360 = 320 x 48 (two rounds) or 240 x 64 (one): 64.
+static int qkv_tile_groups(int n_heads_total) {
+    static const int env = [] { const char *e = getenv("SAMD_QKV_TILE"); return e ? atoi(e) : 0; }();
+    static const int n_cu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount; return n; }();
+    const int N = n_heads_total * 128;
+    if (N % 48 != 0 || env == 64) return 4;
+    if (env == 48) return 3;
+    const int t48 = N / 48, t64 = N / 64;
+    return ((t48 + n_cu - 1) / n_cu) * 48 < ((t64 + n_cu - 1) / n_cu) * 64 ? 3 : 4;
 }
 
 // ================================================================================================
@@ -541,16 +573,16 @@ static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t 
 #undef GO
 }
 
-template <typename TT, int RT, int DEPTH>
+template <typename TT, int RT, int DEPTH, int CG>
 static hipError_t qkv_rope_launch(hipStream_t st, const void *A, const void *W, int K, int tiles, const float *cs, const int *d_L, const int *d_n, void *q, void *k, void *v,
                                   int H, int Hkv, long long max_len) {
-    constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 2 * 16 * RT * 64 * 4, lds = lds_a > lds_e ? lds_a : lds_e;
+    constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 2 * 16 * RT * 16 * CG * 4, lds = lds_a > lds_e ? lds_a : lds_e;
     if constexpr (lds > 65536) {
         static unsigned long long done = 0ull;
-        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_qkv_rope<TT, RT, DEPTH>, lds, &done);
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_qkv_rope<TT, RT, DEPTH, CG>, lds, &done);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
+    hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH, CG>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
                        cs, d_L, d_n, (typename TT::elem *)q, (typename TT::elem *)k, (typename TT::elem *)v, H, Hkv, max_len);
     return hipSuccess;
 }
@@ -654,7 +686,10 @@ int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total,
         samd_set_error("samd_gemm_pack_qkv64: needs K %% 256 == 0, whole 128-column heads and distinct buffers"); return SAMD_E_INVALID;
     }
     const long long units = (long long)n_heads_total * 128 * K / 8;
-    hipLaunchKernelGGL(k_gemm_pack_qkv64, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, n_heads_total * 128, K);
+    if (qkv_tile_groups(n_heads_total) == 3)
+        hipLaunchKernelGGL(k_gemm_pack_qkv<3>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, n_heads_total * 128, K);
+    else
+        hipLaunchKernelGGL(k_gemm_pack_qkv<4>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, n_heads_total * 128, K);
     LAUNCHCHK();
     return SAMD_OK;
 }
@@ -667,14 +702,16 @@ int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int
         samd_set_error("samd_gemm_qkv_rope: unsupported shape (rows 16/32/48/64, head_dim 128, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
     }
     static const int depth_env = [] { const char *e = getenv("SAMD_QKV_DEPTH"); return e ? atoi(e) : 0; }();
-    const int tiles = 2 * (n_heads + 2 * n_kv_heads);
+    const int groups = qkv_tile_groups(n_heads + 2 * n_kv_heads);
+    const int tiles = (n_heads + 2 * n_kv_heads) * 128 / (16 * groups);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-#define GO(TT, RT, D) e = qkv_rope_launch<TT, RT, D>(st, d_A, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len)
-#define ROWS(TT) do { if (rows_pad == 16) { if (depth_env == 2) GO(TT, 1, 2); else if (depth_env == 3) GO(TT, 1, 3); else GO(TT, 1, 4); } \
-                      else if (rows_pad == 32) { if (depth_env == 2) GO(TT, 2, 2); else GO(TT, 2, 4); } \
-                      else if (rows_pad == 48) GO(TT, 3, 3); else GO(TT, 4, 3); } while (0)
-    if (dtype == SAMD_F16) ROWS(GF16); else ROWS(GBF16);
+#define GO(TT, RT, D, CG) e = qkv_rope_launch<TT, RT, D, CG>(st, d_A, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len)
+#define ROWS(TT, CG) do { if (rows_pad == 16) { if (depth_env == 2) GO(TT, 1, 2, CG); else if (depth_env == 3) GO(TT, 1, 3, CG); else GO(TT, 1, 4, CG); } \
+                          else if (rows_pad == 32) { if (depth_env == 2) GO(TT, 2, 2, CG); else GO(TT, 2, 4, CG); } \
+                          else if (rows_pad == 48) GO(TT, 3, 3, CG); else GO(TT, 4, 3, CG); } while (0)
+    if (groups == 3) { if (dtype == SAMD_F16) ROWS(GF16, 3); else ROWS(GBF16, 3); }
+    else { if (dtype == SAMD_F16) ROWS(GF16, 4); else ROWS(GBF16, 4); }
 #undef ROWS
 #undef GO
     if (e != hipSuccess) { samd_set_error("samd_gemm_qkv_rope: %s", hipGetErrorString(e)); return SAMD_E_HIP; }

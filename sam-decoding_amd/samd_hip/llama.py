@@ -131,9 +131,10 @@ class LlamaRunner:
             check(lib().samd_gemm_pack_groups(_ptr(w), _ptr(out), 2 * s.inter, w.shape[1], current_stream()))
             return out
         def pack_qkv64(t):
-            """q|k|v in the 64-column-tile layout of samd_gemm_qkv_rope (RoPE + K/V row write as the projection's epilogue, no split-K):
-            taken when the launch then has enough workgroups to stream -- 2 tiles per head, >= 128 of them (Vicuna-7B: 192; a GQA
-            model like Llama-3-8B has 96 and keeps the split-K projection + samd_rope_kv_write_cs)"""
+            """q|k|v in the tile layout of samd_gemm_qkv_rope (RoPE + K/V row write as the projection's epilogue, no split-K; 48- or
+            64-column tiles, the library's choice): taken when the launch then has enough workgroups to stream -- >= 128 tiles of 64
+            columns' worth (Vicuna-7B: 192 x 64 = 256 x 48 columns; a GQA model like Llama-3-8B has 96 and keeps the split-K
+            projection + samd_rope_kv_write_cs)"""
             heads_total = s.heads + 2 * s.kv_heads
             if (not streams(t) or self.attention != "split" or 2 * heads_total < 128 or s.head_dim != 128
                     or os.environ.get("SAMD_QKV_FUSED", "1") == "0"):

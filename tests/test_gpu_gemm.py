@@ -113,9 +113,11 @@ def test_gemm_rejects_bad_shapes():
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("rows_pad,H,Hkv,K,n,L", [(16, 32, 32, 4096, 11, 700), (64, 32, 32, 4096, 60, 1900), (32, 2, 2, 512, 32, 0), (48, 4, 1, 768, 37, 129),
-                                                  (16, 3, 3, 256, 1, 5)])
+                                                  (16, 3, 3, 256, 1, 5), (16, 8, 1, 512, 9, 40), (32, 40, 40, 256, 20, 3), (64, 5, 5, 512, 64, 77)])
 def test_qkv_projection_with_rope_epilogue(dtype, tol, rows_pad, H, Hkv, K, n, L):
-    """samd_gemm_qkv_rope (q|k|v projection + RoPE + K/V row write in one launch, 64-column tiles holding rotate_half pairs, no split-K)
+    """samd_gemm_qkv_rope (q|k|v projection + RoPE + K/V row write in one launch, no split-K; tiles of 24 or 32 rotate_half pairs that may
+    straddle heads and the q / k / v regions: 48-column tiles for the 7B shape and the small ones, 64-column tiles where 48 does not divide
+    the matrix -- 8 + 2 x 1 heads -- or would need a second round of workgroups -- 3 x 40 heads)
     against fp32 arithmetic, and against the two-launch path it replaces (samd_gemm_skinny + samd_rope_kv_write_cs): q rows < n, K / V
     rows [L, L + n) of the caches; nothing else may be written."""
     Lb = samd_hip.lib()
