@@ -161,6 +161,17 @@ class ScriptedAcceptance:
         return self.runner.hidden_rows(R)
 
 
+class _GraphPair:
+    """a decode step captured as two hipGraphs replayed back to back on one stream (DecodeEngine._capture)"""
+
+    def __init__(self):
+        self.head, self.rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+
+    def replay(self):
+        self.head.replay()
+        self.rest.replay()
+
+
 class DecodeEngine:
     def __init__(self, verifier, session: Session, static: StaticAutomaton, params: Params, recycle: TokenRecycleTable = None,
                  recycle_parent=None, use_graphs=True):
@@ -337,11 +348,37 @@ class DecodeEngine:
         """capture the step for row bucket R.  Capture records the launches without executing them, so the request's
         state is untouched; the verifier first runs the bucket once with n = 0 rows (no K/V write, every query row
         masked) so that library handles / workspaces exist before capture."""
-        g = torch.cuda.CUDAGraph()
         self._warm(R)
         torch.cuda.current_stream().synchronize()
-        with torch.cuda.graph(g):
-            self._enqueue_step(R)
+        runner = getattr(self.verifier, "runner", self.verifier)
+        split = int(os.environ.get("SAMD_GRAPH_SPLIT_LAYER", "3"))
+        n_layers = len(getattr(runner, "w", {}).get("layers", ())) if hasattr(runner, "layer_hook") else 0
+        if split <= 0 or n_layers <= split:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue_step(R)
+        else:
+            # TWO graphs per step: hipGraphLaunch builds every packet of a graph before the GPU sees the first (~100 us for the step's
+            # ~265 nodes, during which the GPU idles); a short head graph (embedding + the first layers) starts the GPU after ~10 us and
+            # the rest is enqueued while it runs (scripts/host_turnaround.py)
+            g = _GraphPair()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                g.head.capture_begin()
+
+                def hook(li):
+                    if li == split:
+                        g.head.capture_end()
+                        g.rest.capture_begin()
+                runner.layer_hook = hook
+                try:
+                    self._enqueue_step(R)
+                finally:
+                    runner.layer_hook = None
+                g.rest.capture_end()
+            cur.wait_stream(side)
         self._graphs[R] = g
         return g
 

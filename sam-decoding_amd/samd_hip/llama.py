@@ -94,6 +94,7 @@ class LlamaRunner:
         # L2 warm-up (csrc/warm_device.h): the glue launch in front of a projection also reads the first KiB of every workgroup's
         # weight stream into the consuming XCD's L2 while HBM idles.  KiB per projection workgroup; 0 = off, the default: measured
         # zero-sum (profiles/r03_l2_warm.md -- the projections get faster by what the glue launches get slower).
+        self.layer_hook = None                                   # callable(layer index), called before a layer's launches (engine: graph split)
         self.warm_kb = int(os.environ.get("SAMD_L2_WARM_KB", 0))
         self.warm_delay = int(os.environ.get("SAMD_L2_WARM_DELAY", 0))        # x 64 cycles before the warm workgroups' first load
         self.warm_where = int(os.environ.get("SAMD_L2_WARM_WHERE", 0))        # output projection: 0 = from the attention splits, 1 = from their merge
@@ -347,6 +348,8 @@ class LlamaRunner:
         delta, dn, dstride = None, 0, 0
         packed = self.wp["layers"] if self.wp else [{}] * len(self.w["layers"])
         for li, w in enumerate(self.w["layers"]):
+            if self.layer_hook is not None:
+                self.layer_hook(li)
             wp = packed[li]
             raw_in = head and li == 0                             # eagle2_model.py:516-519: no input layer-norm in the head's layer
             if not raw_in:
