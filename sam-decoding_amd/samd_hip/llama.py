@@ -137,8 +137,8 @@ class LlamaRunner:
             columns' worth (Vicuna-7B: 192 x 64 = 256 x 48 columns; a GQA model like Llama-3-8B has 96 and keeps the split-K
             projection + samd_rope_kv_write_cs)"""
             heads_total = s.heads + 2 * s.kv_heads
-            if (not streams(t) or self.attention != "split" or 2 * heads_total < 128 or s.head_dim != 128
-                    or os.environ.get("SAMD_QKV_FUSED", "1") == "0"):
+            mode = os.environ.get("SAMD_QKV_FUSED", "1")
+            if (not streams(t) or self.attention != "split" or (2 * heads_total < 128 and mode != "force") or s.head_dim != 128 or mode == "0"):
                 return None
             out = torch.empty_like(t)
             check(lib().samd_gemm_pack_qkv64(_ptr(t), _ptr(out), heads_total, t.shape[1], current_stream()))

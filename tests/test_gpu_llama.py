@@ -301,7 +301,9 @@ def test_draft_head_on_device_matches_the_pytorch_head():
     anc = torch.zeros((16, 16), device="cuda"); anc[:8, :8] = eye; anc[8:] = m1
     x1 = torch.cat((x0, dh._x(ids1, d_out0[par].clone())), dim=0)
     d_out1, d_log1 = dh.tree(x1, torch.tensor([0] * 8 + [1] * 8, dtype=torch.int32, device="cuda"), anc)
-    assert close(d_out1[8:], out1, 3e-2) and close(d_log1[8:], torch.nn.functional.linear(out1, lm_head), 3e-2)
+    err_rows = (d_out1[8:].float() - out1.float()).abs().amax(dim=1) / max(1.0, out1.float().abs().max().item())
+    assert close(d_out1[8:], out1, 3e-2), f"level-1 states: per-row error / tolerance scale = {err_rows.tolist()} (usual: 1e-3 .. 4e-3, scripts/probes/head_margin.py)"
+    assert close(d_log1[8:], torch.nn.functional.linear(out1, lm_head), 3e-2)
     assert dh.length == 73 and int(dh.L.item()) == 73             # tree levels leave the head's cache length alone
 
     # end to end through both plugins, base model and head on the same kernels
