@@ -168,6 +168,52 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
                 frac_of_request_ceiling=round(gbps / (HBM_REQUESTS_PER_S * 16 / 1e9), 4)), toks
 
 
+def live_walk_traffic(corpus_tokens, B, T, timeout_s=180):
+    """HBM bytes of ONE k_static_walk launch measured in this bench run: scripts/walk_probe.py (the same corpus, streams and kernel)
+    as a CHILD process under `rocprofv3 --kernel-trace --pmc <counter>`, FETCH_SIZE and WRITE_SIZE in separate passes as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE is exact for this scattered 16-byte pattern: profiles/r01_hbm_probe.md).  Returns
+    (bytes or None, how / why not).  Never raises: the committed profiles/walk_pmc.json stays the fallback."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled"
+    per_launch = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="samd_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "w", "--",
+               sys.executable, os.path.join(ROOT, "scripts", "walk_probe.py"), str(corpus_tokens), str(B), str(T), "3"]
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)           # the process group this call created, nothing else
+                p.wait()
+                return None, f"the {counter} pass did not finish in {timeout_s} s"
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_static_walk" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows for k_static_walk (rocprofv3 exit code {p.returncode})"
+            per_launch[counter] = vals[-1] * 1024.0          # KiB per dispatch; the last launch runs on warm caches like the timed ones
+        except OSError as e:
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return int(per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]), \
+        "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate child runs of scripts/walk_probe.py on this GPU, this bench run)"
+
+
 def lm_roofline(runner, iters=10, rows=16):
     """the kernel that takes most of the step: k_gemm_skinny, the weight stream of the verify forward.  All projections of
     all layers at the `rows`-row tile (layer l's matrices are 400 MB apart from layer l+1's: nothing is re-read from a cache),
@@ -427,6 +473,7 @@ def main():
     ap.add_argument("--walk-streams", type=int, default=1 << 20)
     ap.add_argument("--walk-tokens", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from profiles/walk_pmc.json instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--no-long-run", action="store_true", help="skip the untimed continuation of the request stream (context for short --steps)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--launch-selftest", action="store_true", help="CPU check of the N-rank plumbing (gloo): spawn, rendezvous, reduce, relay; no GPU work")
@@ -620,6 +667,12 @@ def main():
                 lm.set_target(req_log[0][1])
             named = named_breakdown(model, lm, req_log[0][0])
         roof, toks_walk = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20, args.corpus_tokens)
+        if world == 1 and not args.no_live_pmc:
+            # `traffic` measured now rather than read from the committed counter file (which stays the fallback and the cross-check)
+            live, how = live_walk_traffic(args.corpus_tokens, args.walk_streams, args.walk_tokens)
+            roof["traffic_from"] = dict(roof["traffic_from"] or {}, committed_file_bytes=roof["traffic"], live=how)
+            if live is not None:
+                roof["traffic"] = live
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(flat, off, docs, cfg, toks_walk)    # rank 0 at N = 1 only
 
         n_steps = sum(v[0] for v in stats.values())
