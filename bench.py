@@ -606,6 +606,13 @@ def main():
     dt = time.perf_counter() - t0
     stats = {k: list(v) for k, v in model.lookup_stats.items()}
     bucket_hist = {str(k): v for k, v in sorted(model.engine.bucket_steps.items())}     # timed steps per row bucket
+    # the fused step kernel's own phase clock (counters C_T_*, 10 ns ticks since the current request began)
+    cnt = [int(x) for x in model.engine._report_np[samd_hip.REP_COUNTERS:samd_hip.REP_COUNTERS + 8]]
+    session_phases = None
+    if cnt[0] > 0:
+        session_phases = {"steps_of_the_current_request": cnt[0]}
+        session_phases.update({k: round(cnt[4 + i] * 0.01 / cnt[0], 2) for i, k in enumerate(
+            ("eval_posterior_us", "dyn_update_us", "static_transfer_us", "lookup_draft_buffers_us"))})
 
     tokens_total, dt_max, per_rank = parallel.reduce_throughput(tokens, dt)      # SUM of tokens, MAX of time over ranks
 
@@ -707,7 +714,7 @@ def main():
             # the reference publishes on natural text.
             "tree_steps_priced_not_predictive": args.variant == "token_recycle",
             "projected_speedup_of_this_variant": variant_projection(args.variant, ar_tps, dt_max / args.steps * 1e3),
-            "long_run": long_run, "timed_tokens": int(tokens_total),
+            "long_run": long_run, "timed_tokens": int(tokens_total), "session_kernel_phases": session_phases,
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
             "step_breakdown_by_rows": breakdown, "step_breakdown_named": named,
             # SURVEY.md 8(d) end-to-end proxy: speed-up = accepted tokens x T_AR / T_step with THIS run's measured step times

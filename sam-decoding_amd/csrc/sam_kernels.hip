@@ -142,12 +142,20 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         wave_mem_sync();
     }
     int n_in = A.d_n ? A.d_n[0] : A.n;
+    // phase clock of the fused step (counters C_T_*): one scalar read of the 100 MHz real-time counter per phase boundary
+    unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+    auto phase_done = [&](int slot) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) D.counters[slot] += (int)(t - t_prev);
+        t_prev = t;
+    };
 
     if (A.ops & OP_ACCEPT) {
         int type, n, nl, md, a, nt;
         load_draft(D, sh, type, n, nl, md);
         do_accept(D, sh, A.node_argmax, type, n, nl, md, a, nt);
         wave_mem_sync();
+        phase_done(C_T_ACCEPT);
     }
     if (A.ops & OP_ACCEPT_GIVEN) {
         int type, n, nl, md, a, nt;
@@ -161,12 +169,15 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         if (lane < a) sh.accepted[lane] = D.acc_tokens[lane];
         __syncthreads();
         dyn_add_tokens(D, sh.accepted, a);
+        wave_mem_sync();
+        phase_done(C_T_DYN);
         if (A.have_static) {
             int is = D.meta[M_ST_IDX], ms = D.meta[M_ST_LEN];
             st_transfer_tokens(S, is, ms, sh.accepted, a);
             if (lane == 0) { D.meta[M_ST_IDX] = is; D.meta[M_ST_LEN] = ms; }
         }
         wave_mem_sync();
+        phase_done(C_T_STATIC);
     }
     if (A.ops & OP_ADD) dyn_add_tokens(D, A.tokens, n_in);
     if (A.ops & OP_DYN_WALK) {
@@ -186,6 +197,8 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
     }
     if (A.ops & OP_DRAFT) {
         do_draft(D, S, A.have_static != 0, P, sh, A.start_token[0]);
+        wave_mem_sync();
+        phase_done(C_T_DRAFT);
     }
     if (A.ops & OP_DRAFT_SEQ) {
         const int n = seq_draft_var(sh, D.text, D.meta[M_NTEXT], D.minend[A.index], draft_size(A.match, P.alpha, P.max_predicts), A.start);

@@ -94,7 +94,9 @@ enum { D_TYPE = 0, D_N, D_NLEAVES, D_MAXDEPTH, D_IDX_DYN, D_MATCH_DYN, D_IDX_ST,
 // verdict[] slots
 enum { V_BEST = 0, V_ACCEPT, V_NEXT_NODE, V_NEXT_TOKEN, V_KV_START, V_IS_TREE, V_COUNT = 8 };
 // counters[] slots
-enum { C_STEPS = 0, C_TOKENS, C_SEQ_STEPS, C_TREE_STEPS, C_COUNT = 8 };
+// C_T_*: time the fused step kernel spent in its phases since the request began, in s_memrealtime ticks (100 MHz = 10 ns): accept
+// (eval_posterior), the dynamic automaton's extension, the static cursor's transfer, lookup + draft + buffers
+enum { C_STEPS = 0, C_TOKENS, C_SEQ_STEPS, C_TREE_STEPS, C_T_ACCEPT, C_T_DYN, C_T_STATIC, C_T_DRAFT, C_COUNT = 8 };
 
 #define SAMD_HEMPTY 0xFFFFFFFFFFFFFFFFull
 
