@@ -161,15 +161,15 @@ class ScriptedAcceptance:
         return self.runner.hidden_rows(R)
 
 
-class _GraphPair:
-    """a decode step captured as two hipGraphs replayed back to back on one stream (DecodeEngine._capture)"""
+class _GraphChain:
+    """a decode step captured as several hipGraphs replayed back to back on one stream (DecodeEngine._capture)"""
 
-    def __init__(self):
-        self.head, self.rest = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    def __init__(self, n):
+        self.parts = [torch.cuda.CUDAGraph() for _ in range(n)]
 
     def replay(self):
-        self.head.replay()
-        self.rest.replay()
+        for g in self.parts:
+            g.replay()
 
 
 class DecodeEngine:
@@ -351,33 +351,36 @@ class DecodeEngine:
         self._warm(R)
         torch.cuda.current_stream().synchronize()
         runner = getattr(self.verifier, "runner", self.verifier)
-        split = int(os.environ.get("SAMD_GRAPH_SPLIT_LAYER", "3"))
+        cuts = [int(x) for x in os.environ.get("SAMD_GRAPH_SPLIT_LAYER", "3").split(",") if x.strip()]
         n_layers = len(getattr(runner, "w", {}).get("layers", ())) if hasattr(runner, "layer_hook") else 0
-        if split <= 0 or n_layers <= split:
+        cuts = sorted({c for c in cuts if 0 < c < n_layers})
+        if not cuts:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._enqueue_step(R)
         else:
-            # TWO graphs per step: hipGraphLaunch builds every packet of a graph before the GPU sees the first (~100 us for the step's
+            # SEVERAL graphs per step: hipGraphLaunch builds every packet of a graph before the GPU sees the first (~100 us for the step's
             # ~265 nodes, during which the GPU idles); a short head graph (embedding + the first layers) starts the GPU after ~10 us and
-            # the rest is enqueued while it runs (scripts/host_turnaround.py)
-            g = _GraphPair()
+            # the rest is enqueued while it runs (scripts/host_turnaround.py).  SAMD_GRAPH_SPLIT_LAYER = the layers to cut before.
+            g = _GraphChain(len(cuts) + 1)
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                g.head.capture_begin()
+                part = [0]
+                g.parts[0].capture_begin()
 
                 def hook(li):
-                    if li == split:
-                        g.head.capture_end()
-                        g.rest.capture_begin()
+                    if li in cuts:
+                        g.parts[part[0]].capture_end()
+                        part[0] += 1
+                        g.parts[part[0]].capture_begin()
                 runner.layer_hook = hook
                 try:
                     self._enqueue_step(R)
                 finally:
                     runner.layer_hook = None
-                g.rest.capture_end()
+                g.parts[part[0]].capture_end()
             cur.wait_stream(side)
         self._graphs[R] = g
         return g
