@@ -231,10 +231,20 @@ def lm_roofline(runner, iters=10, rows=16):
     d_L = torch.tensor([512], dtype=torch.int32, device="cuda")
     d_n = torch.tensor([max(1, rows - 3)], dtype=torch.int32, device="cuda")
 
+    fold = rows == 16 and getattr(runner, "norm_fold", False)       # the launches the runner makes at <= 16 rows (LlamaRunner._forward_rows_fold)
+
     def projections():
         st = current_stream()
         nbytes[0] = 0
         for li, (w, p) in enumerate(zip(runner.w["layers"], runner.wp["layers"])):
+            if fold:
+                check(L.samd_gemm_qkv_rope_norm(_ptr(b["x"]), _ptr(b["ssq"]), _ptr(w["ln1"]), s.eps, _ptr(p["wqkv64"]), 16, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
+                                                _ptr(b["q"]), _ptr(runner.kv[li, 0]), _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
+                check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(p["wo_g"]), 16, s.hidden, attn2d.shape[1], _ptr(b["x"]), _ptr(b["ssq"]), dt, st))
+                check(L.samd_gemm_pairs_silu_norm(_ptr(b["x"]), _ptr(b["ssq"]), _ptr(w["ln2"]), s.eps, _ptr(p["wgu"]), 16, s.inter, s.hidden, _ptr(b["act"]), dt, st))
+                check(L.samd_gemm_cs_residual(_ptr(b["act"]), _ptr(p["wdown_g"]), 16, s.hidden, s.inter, _ptr(b["x"]), _ptr(b["ssq"]), dt, st))
+                nbytes[0] += sum(w[key].numel() * w[key].element_size() for key in ("wqkv", "wo", "wgu", "wdown"))
+                continue
             for a, key, out in ((b["h"], "wqkv", b["qkv"]), (attn2d, "wo", b["o"]), (b["act"], "wdown", b["d"])):
                 n, k = w[key].shape
                 if key == "wqkv" and p.get("wqkv64") is not None:          # the launch the runner makes: RoPE + K/V write in the epilogue
@@ -262,7 +272,9 @@ def lm_roofline(runner, iters=10, rows=16):
             traffic = int((pmc["fetch_bytes_per_layer"] * pmc["fetch_size_correction"] + pmc["write_bytes_per_layer"]) / 4)
     except (OSError, KeyError, ValueError):
         pass
-    return dict(bound="hbm", kernel=f"weight-streaming projections ({rows}-row tile; k_gemm_qkv_rope | k_gemm_skinny q/k/v, o, down; k_gemm_pairs_silu gate|up of every layer)", achieved=round(gbps, 1),
+    names = ("k_gemm_qkv_rope<NORM> q|k|v, k_gemm_cs_residual o / down, k_gemm_pairs_silu<NORM> gate|up: the norm-fold launches, RMSNorm and residual adds included"
+             if fold else "k_gemm_qkv_rope | k_gemm_skinny q/k/v, o, down; k_gemm_pairs_silu gate|up")
+    return dict(bound="hbm", kernel=f"weight-streaming projections ({rows}-row tile; {names} of every layer)", achieved=round(gbps, 1),
                 peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(gbps / HBM_PEAK_GBPS, 4), traffic=traffic, launch_ms=round(ms / launches, 5),
                 launches_per_forward=launches, alg_bytes_per_launch=int(nbytes[0] / launches), forward_gemm_ms=round(ms, 4))
 

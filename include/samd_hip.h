@@ -477,6 +477,27 @@ int samd_gemm_pairs_silu(const void *d_A, const void *d_Wg, int32_t rows_pad, in
  * (a 32-head MHA model has 192; the runner keeps the two-launch path otherwise).  Call sites replaced: SO/samd_model.py:134-138
  * (the q/k/v projections, rotary embedding and cache update inside HF's LlamaAttention.forward). */
 int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total, int32_t K, void *stream);
+/* The "norm-fold" forward at 16 rows (round 3): LlamaRMSNorm is applied by the projection that CONSUMES it, and the residual add by the
+ * projection that PRODUCES the delta, so that a decoder layer is six launches instead of eight and no fp32 split-K partial is written:
+ *   samd_embed_rows_ssq      rows of the embedding table -> x, plus d_ssq [hidden / 16][16] fp32: every row's sum of squares per 16-column
+ *                            tile (tile-major);
+ *   samd_gemm_qkv_rope_norm  samd_gemm_qkv_rope reading the RESIDUAL STREAM d_x [16][K]: 1 / rms per row from d_ssq (added up in a fixed
+ *                            order by every workgroup), h = (x / rms).to(dtype), a = norm_weight * h on the way into LDS;
+ *   samd_gemm_pairs_silu_norm  samd_gemm_pairs_silu in the same way (post_attention_layernorm + gate | up + SiLU * up);
+ *   samd_gemm_cs_residual    x[m][n] <- (x[m][n] + dtype((A W^T)[m][n])).to(dtype) for o_proj / down_proj with COMPLETE sums (one workgroup per 16
+ *                            output columns and all of K; d_Wg = the [N][K] matrix packed by samd_gemm_pack_groups), and the new
+ *                            d_ssq [N / 16][16] of the updated rows.
+ * Roundings are LlamaDecoderLayer's / LlamaRMSNorm's; 1 / rms may differ from samd_rmsnorm's in the last bit (another summation order).
+ * Call sites replaced: SO/samd_model.py:134-138 (input_layernorm, post_attention_layernorm and the two residual adds of every
+ * LlamaDecoderLayer inside the verify forward). */
+int samd_embed_rows_ssq(const int32_t *d_tokens, const void *d_table, void *d_out, float *d_ssq, int32_t rows, int32_t hidden, int32_t vocab,
+                        int32_t dtype, void *stream);
+int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,
+                            const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache,
+                            int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream);
+int samd_gemm_pairs_silu_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_Wg, int32_t rows_pad, int32_t inter,
+                              int32_t K, void *d_out, int32_t dtype, void *stream);
+int samd_gemm_cs_residual(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t N, int32_t K, void *d_x, float *d_ssq, int32_t dtype, void *stream);
 int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length,
                        const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t n_heads, int32_t n_kv_heads,
                        int32_t head_dim, int64_t max_len, int32_t dtype, void *stream);

@@ -207,6 +207,57 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     }
 }
 
+// RMSNorm applied by the CONSUMING projection (NORM variants of k_gemm_qkv_rope / k_gemm_pairs_silu): the rows' sums of squares arrive as
+// per-16-column partials (k_gemm_cs_residual, k_embed_rows_ssq), every workgroup adds them up in the same fixed order and keeps
+// 1 / rms per row in LDS; the A chunks then pass through registers instead of the LDS DMA and are scaled there with the reference's
+// roundings: h = (x * rsqrt(mean(x^2) + eps)).to(dtype), a = weight * h (LlamaRMSNorm.forward).
+struct NormArgs { const float *ssq; const void *g; int tiles; float inv_hidden; float eps; };
+
+// the partial sums are REQUESTED before the first weight chunks (hand-issued loads, so that the counted waits of the stream stay exact) and
+// added up once those chunks are in flight: NORM_NS loads per thread whatever the tile count (clamped + zeroed past the end)
+#define NORM_NS 16
+template <int NT>
+__device__ __forceinline__ void norm_issue(const NormArgs &na, float (&sv)[NORM_NS]) {
+    const int tid = threadIdx.x, row = tid & 15, p = tid >> 4;
+#pragma unroll
+    for (int k = 0; k < NORM_NS; k++) {
+        int t = p + (NT / 16) * k;
+        t = t < na.tiles ? t : na.tiles - 1;
+        const float *src = na.ssq + (size_t)t * 16 + row;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(sv[k]) : "v"(src) : "memory");
+    }
+}
+template <int NT>
+__device__ __forceinline__ void norm_finish(const NormArgs &na, const float (&sv)[NORM_NS], float *part /* [NT / 16][16] */, float *rs /* [16] */) {
+    const int tid = threadIdx.x, row = tid & 15, p = tid >> 4;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NORM_NS; k++) s += (p + (NT / 16) * k < na.tiles) ? sv[k] : 0.f;
+    part[p * 16 + row] = s;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tid < 16) {
+        float tot = 0.f;
+        for (int k = 0; k < NT / 16; k++) tot += part[k * 16 + tid];
+        rs[tid] = rsqrtf(tot * na.inv_hidden + na.eps);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename E>
+__device__ __forceinline__ u32x4 norm_scale8(u32x4 xraw, u32x4 graw, float rs) {
+    const E *xe = reinterpret_cast<const E *>(&xraw);
+    const E *ge = reinterpret_cast<const E *>(&graw);
+    u32x4 out;
+    E *oe = reinterpret_cast<E *>(&out);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const E h = (E)((float)xe[j] * rs); oe[j] = (E)((float)ge[j] * (float)h); }
+    return out;
+}
+
 // ================================================================================================
 // q|k|v projection with RoPE and the K/V row write as its epilogue (round 3): the k_rope_kv launch and the fp32 split-K partials of the
 // q|k|v projection disappear (Vicuna-7B: 5 us and 1.5 MB written + read back per layer).  An epilogue needs COMPLETE sums, so no split-K
@@ -220,12 +271,12 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
 // The stream itself is k_gemm_skinny's: LDS-DMA'd A chunks shared by all waves, hand-issued nt weight loads with DEPTH chunks in flight
 // (32 KiB chunks: DEPTH 4 = the same 128 KiB per workgroup), counted waits, bare barriers.
 // ================================================================================================
-template <typename TT, int RT, int DEPTH, int CG>
-__global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void k_gemm_qkv_rope(
+template <typename TT, int RT, int DEPTH, int CG, bool NORM>
+__global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES / 2) void k_gemm_qkv_rope(
         const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W, int K, int n_chunks,
         const float *__restrict__ cs, const int *__restrict__ d_L, const int *__restrict__ d_n,
         typename TT::elem *__restrict__ q_out, typename TT::elem *__restrict__ k_cache, typename TT::elem *__restrict__ v_cache,
-        int H, int Hkv, long long max_len) {
+        int H, int Hkv, long long max_len, NormArgs na) {
     typedef typename TT::elem E;
     typedef typename TT::vec8 V8;
     constexpr int R = 16 * RT;
@@ -259,35 +310,57 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
         for (int j = 0; j < 2; j++)
             asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[bl][j]) : "v"(wlane), "s"(p + (CH / 4) * (2 * bl + j)) : "memory");
     };
-    auto stage_xi = [&](int c, int buf, int i) {
+    // NORM: the A chunk and the norm weights of its k range come through registers (two loads per unit) and are scaled on their way to LDS
+    static_assert(!NORM || RT == 1, "the norm-fold path is built for the 16-row tile");
+    constexpr int XL = NORM ? 2 * XV : XV;         // memory operations per thread to stage one A chunk
+    u32x4 xr[NORM ? DEPTH : 1][NORM ? XV : 1], gr[NORM ? DEPTH : 1][NORM ? XV : 1];
+    __shared__ float norm_part[NORM ? (NT / 16) * 16 : 1], norm_rs[NORM ? 16 : 1];
+    auto stage_xi = [&](int c, int buf, int i, int d) {
         const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
         const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
-        E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        asm volatile("" ::: "memory");
+        if constexpr (NORM) {
+            const E *gsrc = reinterpret_cast<const E *>(na.g) + (size_t)c * GEMM_KC + 8 * unit;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[d][i]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gr[d][i]) : "v"(gsrc) : "memory");
+        } else {
+            E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            asm volatile("" ::: "memory");
+        }
     };
-    auto issue = [&](u32x4 (&dst)[2][2], int c, int buf) {
+    auto issue = [&](u32x4 (&dst)[2][2], int c, int buf, int d) {
         if (streams) { load_wb(dst, c, 0); load_wb(dst, c, 1); }
 #pragma unroll
-        for (int i = 0; i < XV; i++) stage_xi(c, buf, i);
+        for (int i = 0; i < XV; i++) stage_xi(c, buf, i, d);
     };
-    auto landed = [&](int younger) {               // memory ops retire in issue order: chunk c has landed when only the younger ones may still fly
+    auto scale_to_lds = [&](int buf, int d) {      // NORM: this thread's units of the landed chunk -> LDS, scaled (same positions as the DMA's)
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < XV; i++) {
+                const int slot = tid + NT * i, row = slot >> 5;
+                const u32x4 v = norm_scale8<E>(xr[d][i], gr[d][i], norm_rs[row]);
+                *reinterpret_cast<u32x4 *>(&xs[buf][0][0] + (size_t)slot * 8) = v;
+            }
+        }
+    };
+    auto landed = [&](int younger, int buf, int d) {   // memory ops retire in issue order: chunk c has landed when only the younger ones may still fly
         if (streams) {
-            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (WL + XV)) : "memory");
-            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (WL + XV)) : "memory");
-            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + XV) : "memory");
+            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (WL + XL)) : "memory");
+            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (WL + XL)) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + XL) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        } else {                                   // a staging-only wave has XV operations per chunk in flight
-            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XV) : "memory");
-            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XV) : "memory");
-            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XV) : "memory");
+        } else {                                   // a staging-only wave has XL operations per chunk in flight
+            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XL) : "memory");
+            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XL) : "memory");
+            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XL) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         }
+        if constexpr (NORM) { scale_to_lds(buf, d); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    auto phase = [&](u32x4 (&cur)[2][2], int c, int buf) {
-        landed(n_chunks - 1 - c);
+    auto phase = [&](u32x4 (&cur)[2][2], int c, int buf, int d) {
+        landed(n_chunks - 1 - c, buf, d);
         const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
         for (int bl = 0; bl < 2; bl++) {
@@ -316,17 +389,26 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 ? 2 : GEMM_WAVES / 2) void
                 acc[mt] = TT::mfma(__builtin_bit_cast(V8, r[mt][1]), __builtin_bit_cast(V8, cur[bl][1]), acc[mt]);
             }
         }
-        if (c + DEPTH < n_chunks) issue(cur, c + DEPTH, buf == 0 ? NB - 1 : buf - 1);
+        if (c + DEPTH < n_chunks) issue(cur, c + DEPTH, buf == 0 ? NB - 1 : buf - 1, d);
     };
+    float norm_sv[NORM ? NORM_NS : 1];
+    if constexpr (NORM) norm_issue<NT>(na, norm_sv);
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
-        if (d < n_chunks) issue(wr[d], d, d);
+        if (d < n_chunks) issue(wr[d], d, d, d);
+    if constexpr (NORM) {                           // the partial sums were requested before the chunks: they have landed when only the chunks' operations fly
+        if (n_chunks >= DEPTH) {
+            if (streams) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * (WL + XL)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * XL) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        norm_finish<NT>(na, norm_sv, norm_part, norm_rs);
+    }
     {
         int buf = 0;
         for (int c = 0; c < n_chunks; c += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; d++)
-                if (c + d < n_chunks) { phase(wr[d], c + d, buf); buf = buf == NB - 1 ? 0 : buf + 1; }
+                if (c + d < n_chunks) { phase(wr[d], c + d, buf, d); buf = buf == NB - 1 ? 0 : buf + 1; }
         }
     }
     // ---- epilogue: the two k halves meet in LDS ([2][R][TW] fp32; the A tiles are dead), then RoPE + rounding + row writes -------------
@@ -402,9 +484,9 @@ static int qkv_tile_groups(int n_heads_total) {
 //   its rows interleaved in groups of 16 (group 2p = gate rows 16p.., group 2p + 1 = up rows 16p..) -- samd_gemm_pack_groups.
 // Stream, A staging and waits are k_gemm_skinny's (two chunks in flight, counted vmcnt, bare barriers).
 // ================================================================================================
-template <typename TT, int RT, int DEPTH>
+template <typename TT, int RT, int DEPTH, bool NORM>
 __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WAVES / 2) void k_gemm_pairs_silu(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
-                                                                                                     typename TT::elem *__restrict__ out, int K, int inter, int n_chunks, int n_pairs) {
+                                                                                                     typename TT::elem *__restrict__ out, int K, int inter, int n_chunks, int n_pairs, NormArgs na) {
     typedef typename TT::elem E;
     typedef typename TT::vec8 V8;
     constexpr int R = 16 * RT;
@@ -435,27 +517,47 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
             for (int j = 0; j < 2; j++)
                 asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 1024 * (2 * b + j)) : "memory");
     };
-    auto stage_x = [&](int c, int buf) {
+    // NORM: the A chunk and the norm weights of its k range come through registers and are scaled on their way to LDS (see NormArgs)
+    static_assert(!NORM || RT == 1, "the norm-fold path is built for the 16-row tile");
+    constexpr int XL = NORM ? 2 * XV : XV;         // memory operations per thread to stage one A chunk
+    u32x4 xr[NORM ? DEPTH : 1][NORM ? XV : 1], gr[NORM ? DEPTH : 1][NORM ? XV : 1];
+    __shared__ float norm_part[NORM ? (NT / 16) * 16 : 1], norm_rs[NORM ? 16 : 1];
+    auto stage_x = [&](int c, int buf, int d) {
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
             const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
-            E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-            asm volatile("" ::: "memory");
+            if constexpr (NORM) {
+                const E *gsrc = reinterpret_cast<const E *>(na.g) + (size_t)c * GEMM_KC + 8 * unit;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[d][i]) : "v"(src) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gr[d][i]) : "v"(gsrc) : "memory");
+            } else {
+                E *dst = &xs[buf][0][0] + (size_t)(NT * i + 64 * w) * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+                asm volatile("" ::: "memory");
+            }
         }
     };
     // a wave without a column group issues no weight loads, so its counted waits leave only its A pieces out
-    auto landed = [&](int younger) {
-        if (DEPTH > 3 && younger >= 3) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (8 + XV)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XV) : "memory"); }
-        else if (DEPTH > 2 && younger >= 2) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (8 + XV)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XV) : "memory"); }
-        else if (younger >= 1) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + XV) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XV) : "memory"); }
+    auto landed = [&](int younger, int buf, int d) {
+        if (DEPTH > 3 && younger >= 3) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (8 + XL)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XL) : "memory"); }
+        else if (DEPTH > 2 && younger >= 2) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (8 + XL)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XL) : "memory"); }
+        else if (younger >= 1) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + XL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XL) : "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < XV; i++) {
+                const int slot = tid + NT * i, row = slot >> 5;
+                const u32x4 v = norm_scale8<E>(xr[d][i], gr[d][i], norm_rs[row]);
+                *reinterpret_cast<u32x4 *>(&xs[buf][0][0] + (size_t)slot * 8) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    auto phase = [&](u32x4 (&cur)[4][2], int c, int buf) {
-        landed(n_chunks - 1 - c);
+    auto phase = [&](u32x4 (&cur)[4][2], int c, int buf, int d) {
+        landed(n_chunks - 1 - c, buf, d);
         if (active) {
             const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
@@ -484,17 +586,26 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
                 }
             }
         }
-        if (c + DEPTH < n_chunks) { if (active) load_w(cur, c + DEPTH); stage_x(c + DEPTH, buf == 0 ? NB - 1 : buf - 1); }
+        if (c + DEPTH < n_chunks) { if (active) load_w(cur, c + DEPTH); stage_x(c + DEPTH, buf == 0 ? NB - 1 : buf - 1, d); }
     };
+    float norm_sv[NORM ? NORM_NS : 1];
+    if constexpr (NORM) norm_issue<NT>(na, norm_sv);
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
-        if (d < n_chunks) { if (active) load_w(wr[d], d); stage_x(d, d); }
+        if (d < n_chunks) { if (active) load_w(wr[d], d); stage_x(d, d, d); }
+    if constexpr (NORM) {                           // the partial sums were requested before the chunks (see k_gemm_qkv_rope)
+        if (n_chunks >= DEPTH) {
+            if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * (8 + XL)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * XL) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        norm_finish<NT>(na, norm_sv, norm_part, norm_rs);
+    }
     {
         int buf = 0;
         for (int c = 0; c < n_chunks; c += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; d++)
-                if (c + d < n_chunks) { phase(wr[d], c + d, buf); buf = buf == NB - 1 ? 0 : buf + 1; }
+                if (c + d < n_chunks) { phase(wr[d], c + d, buf, d); buf = buf == NB - 1 ? 0 : buf + 1; }
         }
     }
     // ---- epilogue: the up waves hand their values over through LDS, the gate waves write silu(gate) * up ---------------------------------
@@ -519,6 +630,92 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
                 const E sv = (E)(gf / (1.f + __expf(-gf)));
                 out[(size_t)m * inter + col] = (E)((float)sv * uf);
             }
+    }
+}
+
+// ================================================================================================
+// Complete-sum projection with the residual add as its epilogue (round 3, the "norm-fold" forward): x[m][n] <- x[m][n] + (A W^T)[m][n] for
+// o_proj / down_proj at 16 rows, plus the row's sum of squares over the workgroup's 16 columns -- what the CONSUMING projection needs to
+// apply the RMSNorm itself (k_gemm_qkv_rope / k_gemm_pairs_silu with NORM), so that the two k_rmsnorm launches of a decoder layer and the
+// fp32 split-K partials they read disappear.  One workgroup per 16 output columns and ALL of K: wave w takes the 256-k chunks w, w + 8, ...
+// with its own LDS-DMA'd A chunks (no barrier in the stream), the eight partial accumulators meet in LDS in a fixed order.
+//   W: group-major packed (samd_gemm_pack_groups of the plain [N][K] matrix); ssq: [N / 16][16] fp32 (tile-major, row m at [t][m]).
+// Roundings are the reference's: the projection's output in the model dtype, then the residual sum in the model dtype
+// (LlamaDecoderLayer: hidden_states = residual + hidden_states), squares of the stored values (LlamaRMSNorm: x.float().pow(2)).
+// ================================================================================================
+template <typename TT>
+__global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
+                                                                           typename TT::elem *__restrict__ x, float *__restrict__ ssq, int K, int N, int n_chunks) {
+    typedef typename TT::elem E;
+    typedef typename TT::vec8 V8;
+    constexpr int CSD = 2;                                     // chunks in flight per wave
+    extern __shared__ __attribute__((aligned(1024))) char gemm_lds[];
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, g = l >> 4;
+    E *xs = reinterpret_cast<E *>(gemm_lds) + (size_t)w * CSD * 16 * GEMM_KC;          // this wave's CSD buffers of [16][256]
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)xs;
+    const char *wgrp = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * 8192;
+    const uint32_t wlane = (uint32_t)l * 16;
+
+    floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+    u32x4 wr[CSD][4][2];
+    auto issue = [&](u32x4 (&dst)[4][2], int c, int buf) {
+        const char *p = wgrp + (size_t)c * 8192;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 1024 * (2 * b + j)) : "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                          // the wave's own A chunk: 512 units of 16 B, unit u of row r at position u ^ (r & 15)
+            const int slot = l + 64 * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
+            const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
+            E *dst_l = xs + (size_t)buf * 16 * GEMM_KC + (size_t)(64 * i) * 8;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_l, 16, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+    };
+    auto phase = [&](u32x4 (&cur)[4][2], int c, int buf, bool more) {
+        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t xbase = lds_base + (uint32_t)buf * (16 * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint32_t a0 = xbase + (uint32_t)((8 * b + 2 * g) ^ n) * 16, a1 = xbase + (uint32_t)((8 * b + 2 * g + 1) ^ n) * 16;
+            u32x4 r0, r1;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1));
+            acc = TT::mfma(__builtin_bit_cast(V8, r0), __builtin_bit_cast(V8, cur[b][0]), acc);
+            acc = TT::mfma(__builtin_bit_cast(V8, r1), __builtin_bit_cast(V8, cur[b][1]), acc);
+        }
+    };
+    // chunks of this wave: w, w + 8, ...; two in flight, the LDS buffer of a chunk is refilled only after its reads (lgkmcnt(0) above)
+    const int mine = (n_chunks - w + GEMM_WAVES - 1) / GEMM_WAVES;
+    if (mine > 0) issue(wr[0], w, 0);
+    if (mine > 1) issue(wr[1], w + GEMM_WAVES, 1);
+    for (int i = 0; i < mine; i += 2) {
+        phase(wr[0], w + GEMM_WAVES * i, 0, i + 1 < mine);
+        if (i + 2 < mine) issue(wr[0], w + GEMM_WAVES * (i + 2), 0);
+        if (i + 1 < mine) {
+            phase(wr[1], w + GEMM_WAVES * (i + 1), 1, i + 2 < mine);
+            if (i + 3 < mine) issue(wr[1], w + GEMM_WAVES * (i + 3), 1);
+        }
+    }
+    // ---- the eight k shares meet in LDS (the A buffers are dead), summed in wave order; residual, rounding, row sums of squares -----------
+    __syncthreads();
+    float *ex = reinterpret_cast<float *>(gemm_lds);                               // [8][16][16]
+#pragma unroll
+    for (int r = 0; r < 4; r++) ex[(w * 16 + 4 * g + r) * 16 + n] = acc[r];        // C layout: lane holds rows 4g + r of column n
+    __syncthreads();
+    if (tid < 256) {
+        const int row = tid >> 4, col = tid & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < GEMM_WAVES; k++) sum += ex[(k * 16 + row) * 16 + col];
+        E *xp = x + (size_t)row * N + 16 * blockIdx.x + col;
+        const E o = (E)sum;
+        const E y = (E)((float)*xp + (float)o);
+        *xp = y;
+        float q = (float)y * (float)y;
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+        if (col == 0) ssq[(size_t)blockIdx.x * 16 + row] = q;
     }
 }
 
@@ -573,30 +770,31 @@ static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t 
 #undef GO
 }
 
-template <typename TT, int RT, int DEPTH, int CG>
+template <typename TT, int RT, int DEPTH, int CG, bool NORM = false>
 static hipError_t qkv_rope_launch(hipStream_t st, const void *A, const void *W, int K, int tiles, const float *cs, const int *d_L, const int *d_n, void *q, void *k, void *v,
-                                  int H, int Hkv, long long max_len) {
+                                  int H, int Hkv, long long max_len, NormArgs na = NormArgs{nullptr, nullptr, 0, 0.f, 0.f}) {
     constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 2 * 16 * RT * 16 * CG * 4, lds = lds_a > lds_e ? lds_a : lds_e;
-    if constexpr (lds > 65536) {
+    if constexpr (lds > 60000) {
         static unsigned long long done = 0ull;
-        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_qkv_rope<TT, RT, DEPTH, CG>, lds, &done);
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_qkv_rope<TT, RT, DEPTH, CG, NORM>, lds + 4096, &done);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH, CG>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
-                       cs, d_L, d_n, (typename TT::elem *)q, (typename TT::elem *)k, (typename TT::elem *)v, H, Hkv, max_len);
+    hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH, CG, NORM>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
+                       cs, d_L, d_n, (typename TT::elem *)q, (typename TT::elem *)k, (typename TT::elem *)v, H, Hkv, max_len, na);
     return hipSuccess;
 }
 
-template <typename TT, int RT, int DEPTH>
-static hipError_t pairs_silu_launch(hipStream_t st, int grid, const void *A, const void *W, void *out, int K, int inter, int n_pairs) {
+template <typename TT, int RT, int DEPTH, bool NORM = false>
+static hipError_t pairs_silu_launch(hipStream_t st, int grid, const void *A, const void *W, void *out, int K, int inter, int n_pairs,
+                                    NormArgs na = NormArgs{nullptr, nullptr, 0, 0.f, 0.f}) {
     constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 4 * 16 * RT * 16 * 4, lds = lds_a > lds_e ? lds_a : lds_e;
-    if constexpr (lds > 65536) {
+    if constexpr (lds > 60000) {
         static unsigned long long done = 0ull;
-        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_pairs_silu<TT, RT, DEPTH>, lds, &done);
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_pairs_silu<TT, RT, DEPTH, NORM>, lds + 4096, &done);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((k_gemm_pairs_silu<TT, RT, DEPTH>), dim3(grid), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W,
-                       (typename TT::elem *)out, K, inter, K / GEMM_KC, n_pairs);
+    hipLaunchKernelGGL((k_gemm_pairs_silu<TT, RT, DEPTH, NORM>), dim3(grid), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W,
+                       (typename TT::elem *)out, K, inter, K / GEMM_KC, n_pairs, na);
     return hipSuccess;
 }
 
@@ -652,6 +850,46 @@ int samd_gemm_pack_groups(const void *d_W, void *d_packed, int32_t N, int32_t K,
     }
     const long long units = (long long)N * K / 8;
     hipLaunchKernelGGL(k_gemm_pack_groups, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint4 *)d_W, (uint4 *)d_packed, N, K);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_gemm_pairs_silu_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_Wg, int32_t rows_pad, int32_t inter, int32_t K,
+                              void *d_out, int32_t dtype, void *stream) {
+    if (!d_x || !d_ssq || !d_norm_weight || !d_Wg || !d_out || rows_pad != 16 || inter < 16 || inter % 16 != 0 || K < GEMM_KC || K % GEMM_KC != 0 ||
+        K / 16 > 32 * NORM_NS || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_pairs_silu_norm: unsupported shape (16 rows, inter %% 16 == 0, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+    }
+    static const int n_cu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount; return n; }();
+    const int n_pairs = inter / 16;
+    int grid = n_pairs < n_cu ? n_pairs : n_cu;
+    while ((n_pairs + grid - 1) / grid > 4) grid += n_cu;
+    const NormArgs na{d_ssq, d_norm_weight, K / 16, 1.f / (float)K, eps};
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t e = dtype == SAMD_F16 ? pairs_silu_launch<GF16, 1, 3, true>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na)
+                                           : pairs_silu_launch<GBF16, 1, 3, true>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na);
+    if (e != hipSuccess) { samd_set_error("samd_gemm_pairs_silu_norm: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_gemm_cs_residual(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t N, int32_t K, void *d_x, float *d_ssq, int32_t dtype, void *stream) {
+    if (!d_A || !d_Wg || !d_x || !d_ssq || rows_pad != 16 || N < 16 || N % 16 != 0 || K < GEMM_KC || K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_cs_residual: unsupported shape (16 rows, N %% 16 == 0, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+    }
+    constexpr int lds = GEMM_WAVES * 2 * 16 * GEMM_KC * 2;                       // 128 KiB: two A chunks per wave
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (dtype == SAMD_F16) {
+        static unsigned long long done = 0ull;
+        e = samd_reserve_lds((const void *)k_gemm_cs_residual<GF16>, lds, &done);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_gemm_cs_residual<GF16>, dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const _Float16 *)d_A, (const _Float16 *)d_Wg, (_Float16 *)d_x, d_ssq, K, N, K / GEMM_KC);
+    } else {
+        static unsigned long long done = 0ull;
+        e = samd_reserve_lds((const void *)k_gemm_cs_residual<GBF16>, lds, &done);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_gemm_cs_residual<GBF16>, dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const __bf16 *)d_A, (const __bf16 *)d_Wg, (__bf16 *)d_x, d_ssq, K, N, K / GEMM_KC);
+    }
+    if (e != hipSuccess) { samd_set_error("samd_gemm_cs_residual: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }
@@ -715,6 +953,27 @@ int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int
 #undef ROWS
 #undef GO
     if (e != hipSuccess) { samd_set_error("samd_gemm_qkv_rope: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,
+                            const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache,
+                            int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream) {
+    if (!d_x || !d_ssq || !d_norm_weight || !d_W64 || !d_cs || !d_cache_length || !d_n || !d_q_out || !d_k_cache || !d_v_cache || head_dim != 128 || n_heads < 1 ||
+        n_kv_heads < 1 || rows_pad != 16 || K < GEMM_KC || K % GEMM_KC != 0 || K / 16 > 32 * NORM_NS || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_qkv_rope_norm: unsupported shape (16 rows, head_dim 128, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+    }
+    const int groups = qkv_tile_groups(n_heads + 2 * n_kv_heads);
+    const int tiles = (n_heads + 2 * n_kv_heads) * 128 / (16 * groups);
+    const NormArgs na{d_ssq, d_norm_weight, K / 16, 1.f / (float)K, eps};
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+#define GO(TT, CG) e = qkv_rope_launch<TT, 1, 4, CG, true>(st, d_x, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len, na)
+    if (groups == 3) { if (dtype == SAMD_F16) GO(GF16, 3); else GO(GBF16, 3); }
+    else { if (dtype == SAMD_F16) GO(GF16, 4); else GO(GBF16, 4); }
+#undef GO
+    if (e != hipSuccess) { samd_set_error("samd_gemm_qkv_rope_norm: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -73,6 +73,25 @@ __global__ __launch_bounds__(256) void k_embed_rows(const int *__restrict__ toke
     for (int c = threadIdx.x * 8; c < hidden; c += blockDim.x * 8) st8(dst + c, ld8(src + c));
 }
 
+// the norm-fold forward's embedding: the rows, plus each row's sum of squares per 16-column tile ([hidden / 16][16] fp32, tile-major) --
+// the form in which the projections that apply the RMSNorm themselves expect it (gemm_kernels.hip: NormArgs)
+template <typename T>
+__global__ __launch_bounds__(256) void k_embed_rows_ssq(const int *__restrict__ tokens, const T *__restrict__ table, T *__restrict__ out,
+                                                        float *__restrict__ ssq, int hidden, int vocab) {
+    const int r = blockIdx.x;
+    int t = tokens[r]; t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+    const T *src = table + (size_t)t * hidden;
+    T *dst = out + (size_t)r * hidden;
+    for (int tile = threadIdx.x; tile < hidden / 16; tile += blockDim.x) {
+        const Vec8<T> a = ld8(src + 16 * tile), b = ld8(src + 16 * tile + 8);
+        st8(dst + 16 * tile, a); st8(dst + 16 * tile + 8, b);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float fa = (float)a.v[j], fb = (float)b.v[j]; q += fa * fa; q += fb * fb; }
+        ssq[(size_t)tile * 16 + r] = q;
+    }
+}
+
 // HF LlamaRMSNorm: out = w * (x * rsqrt(mean(x^2) + eps)).to(dtype); optional fused residual add:
 // x <- x + delta first (stored back), as LlamaDecoderLayer does between its two halves.
 template <typename T, bool ADD>
@@ -209,6 +228,17 @@ int samd_embed_rows(const int32_t *d_tokens, const void *d_table, void *d_out, i
     if (dtype == SAMD_F16) hipLaunchKernelGGL(k_embed_rows<_Float16>, dim3(rows), dim3(256), 0, st, d_tokens, (const _Float16 *)d_table, (_Float16 *)d_out, hidden, vocab);
     else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_embed_rows<__bf16>, dim3(rows), dim3(256), 0, st, d_tokens, (const __bf16 *)d_table, (__bf16 *)d_out, hidden, vocab);
     else { samd_set_error("samd_embed_rows: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_embed_rows_ssq(const int32_t *d_tokens, const void *d_table, void *d_out, float *d_ssq, int32_t rows, int32_t hidden, int32_t vocab,
+                        int32_t dtype, void *stream) {
+    if (!d_tokens || !d_table || !d_out || !d_ssq || rows < 1 || rows > 16 || hidden % 16 != 0) { samd_set_error("samd_embed_rows_ssq: invalid argument (<= 16 rows, hidden %% 16 == 0)"); return SAMD_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_embed_rows_ssq<_Float16>, dim3(rows), dim3(256), 0, st, d_tokens, (const _Float16 *)d_table, (_Float16 *)d_out, d_ssq, hidden, vocab);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_embed_rows_ssq<__bf16>, dim3(rows), dim3(256), 0, st, d_tokens, (const __bf16 *)d_table, (__bf16 *)d_out, d_ssq, hidden, vocab);
+    else { samd_set_error("samd_embed_rows_ssq: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
 }

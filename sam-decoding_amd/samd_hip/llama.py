@@ -143,14 +143,30 @@ class LlamaRunner:
             out = torch.empty_like(t)
             check(lib().samd_gemm_pack_qkv64(_ptr(t), _ptr(out), heads_total, t.shape[1], current_stream()))
             return out
+        def pack_groups(t, fold):
+            """o_proj / down_proj in the group-major layout of samd_gemm_cs_residual (the norm-fold forward at <= 16 rows)"""
+            if not fold or t.shape[0] % 16 != 0 or t.shape[1] % 256 != 0:
+                return None
+            out = torch.empty_like(t)
+            check(lib().samd_gemm_pack_groups(_ptr(t), _ptr(out), t.shape[0], t.shape[1], current_stream()))
+            return out
         # packed_lm_head: a draft head shares the base model's lm_head, packed copy included
-        self.wp = dict(lm_head=packed_lm_head if packed_lm_head is not None else pack(weights["lm_head"]),
-                       layers=[dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")}, wgu=pack_gate_up(l["wgu"]), wqkv64=pack_qkv64(l["wqkv"]))
-                               for l in weights["layers"]])
+        layers = []
+        for l in weights["layers"]:
+            lp = dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")}, wgu=pack_gate_up(l["wgu"]), wqkv64=pack_qkv64(l["wqkv"]))
+            # the norm-fold forward (include/samd_hip.h: samd_gemm_cs_residual ...) needs the fused q|k|v and gate|up forms
+            fold = (lp["wqkv64"] is not None and lp["wgu"] is not None and s.hidden <= 8192 and os.environ.get("SAMD_NORM_FOLD", "1") != "0")
+            lp["wo_g"], lp["wdown_g"] = pack_groups(l["wo"], fold), pack_groups(l["wdown"], fold)
+            layers.append(lp)
+        self.wp = dict(lm_head=packed_lm_head if packed_lm_head is not None else pack(weights["lm_head"]), layers=layers)
         self.native_gemm = self.wp["lm_head"] is not None or any(v is not None for l in self.wp["layers"] for v in l.values())
         if not self.native_gemm:
             self.wp = None
         self.fused_mlp = self.wp is not None and all(l["wgu"] is not None for l in self.wp["layers"])
+        # norm-fold forward at <= 16 rows: RMSNorm applied by the consuming projection, residual add by the producing one (6 launches per
+        # layer instead of 8, no split-K partials): scripts/norm_fold_bench.py, profiles/r03_norm_fold.md
+        self.norm_fold = (self.wp is not None and self.attention == "split"
+                          and all(l.get("wo_g") is not None and l.get("wdown_g") is not None for l in self.wp["layers"]))
         self.scale = 1.0 / math.sqrt(s.head_dim)
         self._length_state(max_cache_len, kv)
 
@@ -293,7 +309,8 @@ class LlamaRunner:
                                 argmax=torch.zeros(MAX_DRAFT, dtype=torch.int32, device=dev), rows_pad=RP,
                                 part=torch.zeros(max(part_elems, 1), dtype=torch.float32, device=dev),
                                 ws=torch.zeros(ws_bytes, dtype=torch.uint8, device=dev), ws_bytes=ws_bytes,
-                                cs=torch.zeros((MAX_DRAFT, s.head_dim), dtype=torch.float32, device=dev))
+                                cs=torch.zeros((MAX_DRAFT, s.head_dim), dtype=torch.float32, device=dev),
+                                ssq=torch.zeros((max(s.hidden // 16, 1), 16), dtype=torch.float32, device=dev))
         return self._buf[R]
 
     def bucket(self, n):
@@ -309,6 +326,9 @@ class LlamaRunner:
         layer 0 has no input norm and lm_head reads the residual stream itself (b["x"] = the head's output states)."""
         L, s, b, dt, st = lib(), self.shape, self._buffers(R), self.dt, current_stream()
         RP, part = b["rows_pad"], b["part"]
+        if (self.norm_fold and RP == 16 and x_in is None and d_vis is None and not getattr(self, "draft_head", False)
+                and RP <= self.native_gemm_max_rows):
+            return self._forward_rows_fold(R, b, d_tokens, d_relpos, d_mask, d_L, d_n)
 
         def hint(w, wp, fused=False, is_head=False):
             """samd_warm_t of the projection (w row-major, wp packed) that follows a glue launch, or None"""
@@ -398,6 +418,35 @@ class LlamaRunner:
         gemm(b["x"] if head else b["h"], self.w["lm_head"], self.wp["lm_head"] if self.wp else None, b["logits"])
         if not head:                                              # a draft head's callers rank the logits themselves
             check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
+        return b
+
+    def _forward_rows_fold(self, R, b, d_tokens, d_relpos, d_mask, d_L, d_n):
+        """forward_rows at <= 16 rows in the norm-fold form: the residual stream b["x"] is complete after every projection that adds to it
+        (samd_gemm_cs_residual: complete sums + residual + the rows' sums of squares), and input_layernorm / post_attention_layernorm are
+        applied by the q|k|v and gate|up projections on their way into LDS.  Six launches per decoder layer instead of eight."""
+        L, s, dt, st = lib(), self.shape, self.dt, current_stream()
+        x, ssq = b["x"], b["ssq"]
+        check(L.samd_embed_rows_ssq(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(x), _ptr(ssq), 16, s.hidden, s.vocab, dt, st))
+        check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R, s.head_dim, self.rope_rows, st))
+        attn2d = b["attn"].view(b["attn"].shape[0], -1)
+        for li, (w, wp) in enumerate(zip(self.w["layers"], self.wp["layers"])):
+            if self.layer_hook is not None:
+                self.layer_hook(li)
+            check(L.samd_gemm_qkv_rope_norm(_ptr(x), _ptr(ssq), _ptr(w["ln1"]), s.eps, _ptr(wp["wqkv64"]), 16, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
+                                            _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, self.max_len, dt, st))
+            check(L.samd_tree_attention_warm(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
+                                             s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                                             _ptr(b["ws"]), b["ws_bytes"], None, st))
+            check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(wp["wo_g"]), 16, s.hidden, attn2d.shape[1], _ptr(x), _ptr(ssq), dt, st))
+            check(L.samd_gemm_pairs_silu_norm(_ptr(x), _ptr(ssq), _ptr(w["ln2"]), s.eps, _ptr(wp["wgu"]), 16, s.inter, s.hidden, _ptr(b["act"]), dt, st))
+            check(L.samd_gemm_cs_residual(_ptr(b["act"]), _ptr(wp["wdown_g"]), 16, s.hidden, s.inter, _ptr(x), _ptr(ssq), dt, st))
+        check(L.samd_rmsnorm(_ptr(x), None, _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, 0, 0, st))
+        wl = self.wp["lm_head"]
+        if wl is not None:
+            check(L.samd_gemm_skinny(_ptr(b["h"]), _ptr(wl), 16, s.vocab, s.hidden, 1, _ptr(b["part"]), _ptr(b["logits"]), dt, st))
+        else:
+            torch.mm(b["h"][:R], self.w["lm_head"].t(), out=b["logits"][:R])
+        check(L.samd_argmax_rows(_ptr(b["logits"]), dt, R, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))
         return b
 
     # ------------------------------------------------------------------------------------------------

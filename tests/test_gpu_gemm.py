@@ -208,3 +208,76 @@ def test_gate_up_pairs_on_all_cus(dtype, tol, rows_pad, inter, K):
                                                 samd_hip.torch_dtype_code(dtype), samd_hip.current_stream()))
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,K,inter", [(32, 4096, 11008), (2, 512, 256), (3, 256, 48), (6, 1280, 1024)])
+def test_norm_fold_kernels(dtype, H, K, inter):
+    """the norm-fold forward's launches against the launches they replace: samd_embed_rows_ssq (rows + per-tile sums of squares),
+    samd_gemm_cs_residual (complete-sum projection + residual + sums of squares) vs fp32 arithmetic with the reference's roundings,
+    samd_gemm_qkv_rope_norm / samd_gemm_pairs_silu_norm vs samd_rmsnorm followed by samd_gemm_qkv_rope / samd_gemm_pairs_silu."""
+    Lb, st, dc = samd_hip.lib(), samd_hip.current_stream(), samd_hip.torch_dtype_code(dtype)
+    P = samd_hip._ptr
+    g = torch.Generator(device="cuda").manual_seed(H + K)
+    hidden, D, max_len, n, L, eps = K, 128, 512, 13, 100, 1e-6
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    rnd = lambda *s, sc=1.0: (torch.randn(s, generator=g, device="cuda") * sc).to(dtype)
+    # ---- embedding + sums of squares
+    vocab = 97
+    table, toks = rnd(vocab, hidden), torch.randint(0, vocab, (16,), generator=g, device="cuda", dtype=torch.int32)
+    x = torch.zeros((16, hidden), device="cuda", dtype=dtype)
+    ssq = torch.full((hidden // 16, 16), -1.0, device="cuda", dtype=torch.float32)
+    samd_hip.check(Lb.samd_embed_rows_ssq(P(toks), P(table), P(x), P(ssq), 16, hidden, vocab, dc, st))
+    assert torch.equal(x, table[toks.long()])
+    want = x.float().view(16, hidden // 16, 16).pow(2).sum(-1).t()
+    assert torch.allclose(ssq, want, rtol=1e-5, atol=1e-6)
+    # ---- q|k|v with the input norm folded in, against rmsnorm -> q|k|v
+    gamma = (1.0 + 0.1 * torch.randn(hidden, generator=g, device="cuda")).to(dtype)
+    N = 3 * H * D
+    W = rnd(N, K, sc=K ** -0.5); W64 = torch.empty_like(W)
+    samd_hip.check(Lb.samd_gemm_pack_qkv64(P(W), P(W64), 3 * H, K, st))
+    cs = torch.rand((64, D), generator=g, device="cuda")
+    d_L = torch.tensor([L], dtype=torch.int32, device="cuda"); d_n = torch.tensor([n], dtype=torch.int32, device="cuda")
+    outs = []
+    for fold in (False, True):
+        q = torch.zeros((16, H, D), device="cuda", dtype=dtype); kc = torch.zeros((H, max_len, D), device="cuda", dtype=dtype); vc = torch.zeros_like(kc)
+        if fold:
+            samd_hip.check(Lb.samd_gemm_qkv_rope_norm(P(x), P(ssq), P(gamma), eps, P(W64), 16, K, P(cs), P(d_L), P(d_n), P(q), P(kc), P(vc), H, H, D, max_len, dc, st))
+        else:
+            h = torch.zeros_like(x); xc = x.clone()
+            samd_hip.check(Lb.samd_rmsnorm(P(xc), None, P(gamma), P(h), 16, hidden, eps, dc, 0, 0, st))
+            samd_hip.check(Lb.samd_gemm_qkv_rope(P(h), P(W64), 16, K, P(cs), P(d_L), P(d_n), P(q), P(kc), P(vc), H, H, D, max_len, dc, st))
+        outs.append((q, kc, vc))
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        scale = max(1.0, b.float().abs().max().item())
+        assert (a.float() - b.float()).abs().max().item() <= 4 * ulp * scale
+    # ---- gate|up + SiLU with the post-attention norm folded in
+    Wg, Wu = rnd(inter, K, sc=K ** -0.5), rnd(inter, K, sc=K ** -0.5)
+    Wp = _pack_pairs(Wg, Wu, dtype)
+    act = []
+    for fold in (False, True):
+        o = torch.zeros((16, inter), device="cuda", dtype=dtype)
+        if fold:
+            samd_hip.check(Lb.samd_gemm_pairs_silu_norm(P(x), P(ssq), P(gamma), eps, P(Wp), 16, inter, K, P(o), dc, st))
+        else:
+            h = torch.zeros_like(x); xc = x.clone()
+            samd_hip.check(Lb.samd_rmsnorm(P(xc), None, P(gamma), P(h), 16, hidden, eps, dc, 0, 0, st))
+            samd_hip.check(Lb.samd_gemm_pairs_silu(P(h), P(Wp), 16, inter, K, P(o), dc, st))
+        act.append(o)
+    torch.cuda.synchronize()
+    assert (act[1].float() - act[0].float()).abs().max().item() <= 4 * ulp * max(1.0, act[0].float().abs().max().item())
+    # ---- complete-sum projection + residual + sums of squares (down_proj shape: K2 = inter rounded to the chunk size)
+    K2 = (inter // 256) * 256 or 256
+    A2, W2 = rnd(16, K2), rnd(hidden, K2, sc=K2 ** -0.5)
+    W2p = torch.empty_like(W2)
+    samd_hip.check(Lb.samd_gemm_pack_groups(P(W2), P(W2p), hidden, K2, st))
+    x0 = rnd(16, hidden)
+    x1 = x0.clone(); ssq2 = torch.full((hidden // 16, 16), -1.0, device="cuda", dtype=torch.float32)
+    samd_hip.check(Lb.samd_gemm_cs_residual(P(A2), P(W2p), 16, hidden, K2, P(x1), P(ssq2), dc, st))
+    torch.cuda.synchronize()
+    o_ref = (A2.float() @ W2.float().t()).to(dtype)
+    x_ref = (x0.float() + o_ref.float()).to(dtype)
+    scale = max(1.0, x_ref.float().abs().max().item())
+    assert (x1.float() - x_ref.float()).abs().max().item() <= 3 * ulp * scale
+    assert torch.allclose(ssq2, x1.float().view(16, hidden // 16, 16).pow(2).sum(-1).t(), rtol=1e-5, atol=1e-6)

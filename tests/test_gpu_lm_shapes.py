@@ -237,6 +237,48 @@ def test_vicuna_7b_shape_forward_matches_hf_fp32():
     lm = hf_llama(cfg, seed=0)
     runner = LlamaRunner.from_hf(lm, max_cache_len=2048, dtype=torch.float16)
     verify_against_hf(lm, runner, 1000, 60, 32000, tol=0.15)
+    # a 13-node tree runs the 16-row bucket: the norm-fold forward (RMSNorm applied by the consuming projections, residual adds by the
+    # producing ones; LlamaRunner._forward_rows_fold) against the same fp32 model
+    assert runner.norm_fold
+    verify_against_hf(lm, runner, 700, 13, 32000, tol=0.15, seed=2)
+
+
+def test_norm_fold_forward_equals_the_eight_launch_forward(monkeypatch):
+    """the 16-row forward in its two forms on the same weights (Vicuna-7B width, 4 layers): six launches per layer (norm-fold) against
+    eight (k_rmsnorm + split-K partials).  Same roundings of the same quantities, so the logits differ only by the summation order of
+    the projections and of the rows' sums of squares: a few fp16 ulps of the logit scale; the arg-max agrees wherever the top-2 gap
+    exceeds that."""
+    from samd_hip.llama import LlamaRunner
+    cfg = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=4, num_attention_heads=32, num_key_value_heads=32,
+               vocab_size=32000, max_position_embeddings=2048, rms_norm_eps=1e-6)
+    rng = np.random.default_rng(4)
+    prompt = torch.tensor([rng.integers(3, 32000, 300).tolist()], device="cuda")
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SAMD_NORM_FOLD", mode)
+        runner = LlamaRunner.random_init(cfg, 2048, torch.float16, seed=5)
+        assert runner.norm_fold == (mode == "1")
+        sess = samd_hip.Session(600)
+        runner.prefill(sess, prompt)
+        res = []
+        for n in (1, 7, 16):
+            anc = random_parents(np.random.default_rng(n), n, "bushy")
+            toks = np.random.default_rng(100 + n).integers(3, 32000, n).tolist()
+            dev = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int32)).cuda()
+            sess.set_draft(dev(toks), dev(anc), n, type_=1)
+            b = runner.verify(sess, runner.bucket(n))
+            torch.cuda.synchronize()
+            res.append((b["logits"][:n].float().clone(), b["argmax"][:n].clone(), b["x"][:n].float().clone()))
+        outs[mode] = res
+        del runner
+        torch.cuda.empty_cache()
+    for (la, aa, xa), (lb, ab, xb) in zip(outs["0"], outs["1"]):
+        scale = max(1.0, la.abs().max().item())
+        assert (la - lb).abs().max().item() <= 0.02 * scale
+        assert (xa - xb).abs().max().item() <= 0.02 * max(1.0, xa.abs().max().item())
+        top2 = la.topk(2, dim=-1).values
+        decided = (top2[:, 0] - top2[:, 1]) > 0.04 * scale
+        assert bool((aa == ab)[decided].all())
 
 
 def test_llama3_shape_long_context_matches_hf_fp32():
