@@ -138,7 +138,11 @@ class LlamaRunner:
             projection + samd_rope_kv_write_cs)"""
             heads_total = s.heads + 2 * s.kv_heads
             mode = os.environ.get("SAMD_QKV_FUSED", "1")
-            if (not streams(t) or self.attention != "split" or (2 * heads_total < 128 and mode != "force") or s.head_dim != 128 or mode == "0"):
+            # enough workgroups: 128 tiles of 64 columns, or of 48 where 48 divides the matrix (Llama-3-8B: 6144 = 128 x 48 -- alone the
+            # fused launch only equals split-K + k_rope_kv there, but it is what the norm-fold forward builds on)
+            n_cols = heads_total * 128
+            enough = n_cols // 64 >= 128 or (n_cols % 48 == 0 and n_cols // 48 >= 128)
+            if (not streams(t) or self.attention != "split" or (not enough and mode != "force") or s.head_dim != 128 or mode == "0"):
                 return None
             out = torch.empty_like(t)
             check(lib().samd_gemm_pack_qkv64(_ptr(t), _ptr(out), heads_total, t.shape[1], current_stream()))
