@@ -486,7 +486,8 @@ int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total,
  *   samd_gemm_pairs_silu_norm  samd_gemm_pairs_silu in the same way (post_attention_layernorm + gate | up + SiLU * up);
  *   samd_gemm_cs_residual    x[m][n] <- (x[m][n] + dtype((A W^T)[m][n])).to(dtype) for o_proj / down_proj with COMPLETE sums (one workgroup per 16
  *                            output columns and all of K; d_Wg = the [N][K] matrix packed by samd_gemm_pack_groups), and the new
- *                            d_ssq [N / 16][16] of the updated rows.
+ *                            d_ssq [N / 16][16] of the updated rows.  rows_pad 16, or 8: only rows 0..7 of d_A are read and only rows 0..7 of
+ *                            d_x / d_ssq written (a draft of <= 8 nodes: the launch pulls half the activation bytes).
  * Roundings are LlamaDecoderLayer's / LlamaRMSNorm's; 1 / rms may differ from samd_rmsnorm's in the last bit (another summation order).
  * Call sites replaced: SO/samd_model.py:134-138 (input_layernorm, post_attention_layernorm and the two residual adds of every
  * LlamaDecoderLayer inside the verify forward). */

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
 // Roundings are the reference's: the projection's output in the model dtype, then the residual sum in the model dtype
 // (LlamaDecoderLayer: hidden_states = residual + hidden_states), squares of the stored values (LlamaRMSNorm: x.float().pow(2)).
 // ================================================================================================
-template <typename TT>
+template <typename TT, int ROWS>
 __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                                            typename TT::elem *__restrict__ x, float *__restrict__ ssq, int K, int N, int n_chunks) {
     typedef typename TT::elem E;
@@ -656,6 +656,18 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const t
     const char *wgrp = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * 8192;
     const uint32_t wlane = (uint32_t)l * 16;
 
+    // ROWS = 8: a draft of <= 8 rows -- only rows 0..7 of the activation tile are fetched (half of what this ingest-bound launch pulls
+    // from L2 besides its weights); rows 8..15 of the LDS tiles are zeroed once and their outputs are not written
+    static_assert(ROWS == 8 || ROWS == 16, "");
+    constexpr int AL = ROWS / 2;                               // A loads per lane and chunk
+    if constexpr (ROWS == 8) {
+#pragma unroll
+        for (int buf = 0; buf < CSD; buf++)
+#pragma unroll
+            for (int i = 4; i < 8; i++)
+                *reinterpret_cast<u32x4 *>(xs + (size_t)buf * 16 * GEMM_KC + (size_t)(64 * i + l) * 8) = (u32x4){0u, 0u, 0u, 0u};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
     u32x4 wr[CSD][4][2];
     auto issue = [&](u32x4 (&dst)[4][2], int c, int buf) {
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const t
             for (int j = 0; j < 2; j++)
                 asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 1024 * (2 * b + j)) : "memory");
 #pragma unroll
-        for (int i = 0; i < 8; i++) {                          // the wave's own A chunk: 512 units of 16 B, unit u of row r at position u ^ (r & 15)
+        for (int i = 0; i < AL; i++) {                         // the wave's own A chunk: 32 units of 16 B per row, unit u of row r at position u ^ (r & 15)
             const int slot = l + 64 * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
             const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
             E *dst_l = xs + (size_t)buf * 16 * GEMM_KC + (size_t)(64 * i) * 8;
@@ -675,7 +687,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const t
         }
     };
     auto phase = [&](u32x4 (&cur)[4][2], int c, int buf, bool more) {
-        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + AL) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t xbase = lds_base + (uint32_t)buf * (16 * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -704,7 +716,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const t
 #pragma unroll
     for (int r = 0; r < 4; r++) ex[(w * 16 + 4 * g + r) * 16 + n] = acc[r];        // C layout: lane holds rows 4g + r of column n
     __syncthreads();
-    if (tid < 256) {
+    if (tid < 16 * ROWS) {
         const int row = tid >> 4, col = tid & 15;
         float sum = 0.f;
 #pragma unroll
@@ -874,21 +886,18 @@ int samd_gemm_pairs_silu_norm(const void *d_x, const float *d_ssq, const void *d
 }
 
 int samd_gemm_cs_residual(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t N, int32_t K, void *d_x, float *d_ssq, int32_t dtype, void *stream) {
-    if (!d_A || !d_Wg || !d_x || !d_ssq || rows_pad != 16 || N < 16 || N % 16 != 0 || K < GEMM_KC || K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
-        samd_set_error("samd_gemm_cs_residual: unsupported shape (16 rows, N %% 16 == 0, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+    if (!d_A || !d_Wg || !d_x || !d_ssq || (rows_pad != 16 && rows_pad != 8) || N < 16 || N % 16 != 0 || K < GEMM_KC || K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_cs_residual: unsupported shape (8 or 16 rows, N %% 16 == 0, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
     }
     constexpr int lds = GEMM_WAVES * 2 * 16 * GEMM_KC * 2;                       // 128 KiB: two A chunks per wave
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    if (dtype == SAMD_F16) {
-        static unsigned long long done = 0ull;
-        e = samd_reserve_lds((const void *)k_gemm_cs_residual<GF16>, lds, &done);
-        if (e == hipSuccess) hipLaunchKernelGGL(k_gemm_cs_residual<GF16>, dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const _Float16 *)d_A, (const _Float16 *)d_Wg, (_Float16 *)d_x, d_ssq, K, N, K / GEMM_KC);
-    } else {
-        static unsigned long long done = 0ull;
-        e = samd_reserve_lds((const void *)k_gemm_cs_residual<GBF16>, lds, &done);
-        if (e == hipSuccess) hipLaunchKernelGGL(k_gemm_cs_residual<GBF16>, dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const __bf16 *)d_A, (const __bf16 *)d_Wg, (__bf16 *)d_x, d_ssq, K, N, K / GEMM_KC);
-    }
+#define GO(TT, ROWS, ET) do { static unsigned long long done = 0ull; \
+        e = samd_reserve_lds((const void *)k_gemm_cs_residual<TT, ROWS>, lds, &done); \
+        if (e == hipSuccess) hipLaunchKernelGGL((k_gemm_cs_residual<TT, ROWS>), dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const ET *)d_A, (const ET *)d_Wg, (ET *)d_x, d_ssq, K, N, K / GEMM_KC); } while (0)
+    if (dtype == SAMD_F16) { if (rows_pad == 8) GO(GF16, 8, _Float16); else GO(GF16, 16, _Float16); }
+    else { if (rows_pad == 8) GO(GBF16, 8, __bf16); else GO(GBF16, 16, __bf16); }
+#undef GO
     if (e != hipSuccess) { samd_set_error("samd_gemm_cs_residual: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;

@@ -430,6 +430,7 @@ class LlamaRunner:
         applied by the q|k|v and gate|up projections on their way into LDS.  Six launches per decoder layer instead of eight."""
         L, s, dt, st = lib(), self.shape, self.dt, current_stream()
         x, ssq = b["x"], b["ssq"]
+        rows_cs = 8 if R <= 8 else 16            # the complete-sum projections fetch only the rows a <= 8-node draft has
         check(L.samd_embed_rows_ssq(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(x), _ptr(ssq), 16, s.hidden, s.vocab, dt, st))
         check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R, s.head_dim, self.rope_rows, st))
         attn2d = b["attn"].view(b["attn"].shape[0], -1)
@@ -441,9 +442,9 @@ class LlamaRunner:
             check(L.samd_tree_attention_warm(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
                                              s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
                                              _ptr(b["ws"]), b["ws_bytes"], None, st))
-            check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(wp["wo_g"]), 16, s.hidden, attn2d.shape[1], _ptr(x), _ptr(ssq), dt, st))
+            check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(wp["wo_g"]), rows_cs, s.hidden, attn2d.shape[1], _ptr(x), _ptr(ssq), dt, st))
             check(L.samd_gemm_pairs_silu_norm(_ptr(x), _ptr(ssq), _ptr(w["ln2"]), s.eps, _ptr(wp["wgu"]), 16, s.inter, s.hidden, _ptr(b["act"]), dt, st))
-            check(L.samd_gemm_cs_residual(_ptr(b["act"]), _ptr(wp["wdown_g"]), 16, s.hidden, s.inter, _ptr(x), _ptr(ssq), dt, st))
+            check(L.samd_gemm_cs_residual(_ptr(b["act"]), _ptr(wp["wdown_g"]), rows_cs, s.hidden, s.inter, _ptr(x), _ptr(ssq), dt, st))
         check(L.samd_rmsnorm(_ptr(x), None, _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, 0, 0, st))
         wl = self.wp["lm_head"]
         if wl is not None:

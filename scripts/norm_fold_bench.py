@@ -57,6 +57,8 @@ singles = {
     "qkv_rope_norm": lambda w: check(L.samd_gemm_qkv_rope_norm(P(x), P(ssq), P(g1), eps, P(w["qkv"]), R, hid, P(cs), P(d_L), P(d_n), P(q), P(kv[0]), P(kv[1]), H, H, D, max_len, F, S())),
     "o split-K": lambda w: check(L.samd_gemm_skinny(P(attn), P(w["o"]), R, hid, hid, sp_o, P(part), None, F, S())),
     "o complete + residual": lambda w: check(L.samd_gemm_cs_residual(P(attn), P(w["o_g"]), R, hid, hid, P(x), P(ssq), F, S())),
+    "o complete + residual, 8 rows": lambda w: check(L.samd_gemm_cs_residual(P(attn), P(w["o_g"]), 8, hid, hid, P(x), P(ssq), F, S())),
+    "down complete + residual, 8 rows": lambda w: check(L.samd_gemm_cs_residual(P(act), P(w["down_g"]), 8, hid, inter, P(x), P(ssq), F, S())),
     "pairs_silu": lambda w: check(L.samd_gemm_pairs_silu(P(h), P(w["gate_up"]), R, inter, hid, P(act), F, S())),
     "pairs_silu_norm": lambda w: check(L.samd_gemm_pairs_silu_norm(P(x), P(ssq), P(g1), eps, P(w["gate_up"]), R, inter, hid, P(act), F, S())),
     "down split-K": lambda w: check(L.samd_gemm_skinny(P(act), P(w["down"]), R, hid, inter, sp_d, P(part), None, F, S())),

@@ -281,3 +281,9 @@ def test_norm_fold_kernels(dtype, H, K, inter):
     scale = max(1.0, x_ref.float().abs().max().item())
     assert (x1.float() - x_ref.float()).abs().max().item() <= 3 * ulp * scale
     assert torch.allclose(ssq2, x1.float().view(16, hidden // 16, 16).pow(2).sum(-1).t(), rtol=1e-5, atol=1e-6)
+    # the 8-row form (drafts of <= 8 nodes): rows 0..7 as above -- bit for bit, the arithmetic is the same -- rows 8..15 of x and ssq untouched
+    x8 = x0.clone(); ssq8 = torch.full((hidden // 16, 16), -1.0, device="cuda", dtype=torch.float32)
+    samd_hip.check(Lb.samd_gemm_cs_residual(P(A2), P(W2p), 8, hidden, K2, P(x8), P(ssq8), dc, st))
+    torch.cuda.synchronize()
+    assert torch.equal(x8[:8], x1[:8]) and torch.equal(x8[8:], x0[8:])
+    assert torch.equal(ssq8[:, :8], ssq2[:, :8]) and bool((ssq8[:, 8:] == -1.0).all())
