@@ -230,8 +230,11 @@ class LlamaRunner:
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
-    def from_hf(cls, lm, max_cache_len, dtype=None, device="cuda", **kw):
-        """weights of a transformers LlamaForCausalLM (what the reference passes as `lm`)."""
+    def from_hf(cls, lm, max_cache_len, dtype=None, device="cuda", share_weights=None, **kw):
+        """weights of a transformers LlamaForCausalLM (what the reference passes as `lm`).  share_weights (default: env
+        SAMD_SHARE_HF_WEIGHTS, off): re-point the HF module's q/k/v and gate/up weights at row slices of the runner's concatenated
+        matrices -- saves one row-major copy of the model, but the caller's parameters become views of storage the runner owns
+        (matters for save_pretrained / in-place edits), so it is opt-in and logged once."""
         dtype = dtype or next(lm.parameters()).dtype
         shape = LlamaShape(lm.config)
         dev = torch.device(device)
@@ -243,8 +246,9 @@ class LlamaRunner:
         # The runner reads q|k|v and gate|up as ONE matrix each.  When the HF module already lives on this device in this dtype, its
         # separate projection weights are re-pointed at row slices of the concatenated matrices (same values, the module keeps working),
         # so the model exists once row-major (+ once packed) instead of the HF copy + the concatenated copy + the packed copy.
-        # SAMD_SHARE_HF_WEIGHTS=0 leaves the module untouched.
-        share = os.environ.get("SAMD_SHARE_HF_WEIGHTS", "1") != "0"
+        # Opt-in (share_weights=True / SAMD_SHARE_HF_WEIGHTS=1): by default the caller's module is left untouched.
+        share = (os.environ.get("SAMD_SHARE_HF_WEIGHTS", "0") == "1") if share_weights is None else bool(share_weights)
+        shared = [0]
 
         def fuse(linears):
             ws = [l.weight for l in linears]
@@ -255,6 +259,7 @@ class LlamaRunner:
                     n = l.weight.shape[0]
                     l.weight.data = cat[r:r + n]
                     r += n
+                shared[0] += 1
             return cat
         for lyr in m.layers:
             a, f = lyr.self_attn, lyr.mlp
@@ -268,6 +273,10 @@ class LlamaRunner:
                 wdown=get(f.down_proj.weight),
                 ln1=get(lyr.input_layernorm.weight), ln2=get(lyr.post_attention_layernorm.weight)))
         weights = dict(embed=get(m.embed_tokens.weight), layers=layers, norm=get(m.norm.weight), lm_head=get(lm.lm_head.weight))
+        if shared[0]:
+            import logging
+            logging.getLogger("samd_hip").info("LlamaRunner.from_hf: %d fused projection groups now back the HF module's q/k/v and gate/up "
+                                               "weights (share_weights); its parameters are views of the runner's matrices", shared[0])
         return cls(shape, weights, max_cache_len, dtype, device, **kw)
 
     @classmethod

@@ -189,7 +189,7 @@ def tree_mask_4d(anc, L, n):
     return mask
 
 
-def verify_against_hf(lm, runner, prompt_len, n, vocab, tol, seed=1):
+def verify_against_hf(lm, runner, prompt_len, n, vocab, tol, seed=1, decide_gap=None):
     from transformers import DynamicCache
     rng = np.random.default_rng(seed)
     sess = samd_hip.Session(prompt_len + 128)
@@ -214,7 +214,7 @@ def verify_against_hf(lm, runner, prompt_len, n, vocab, tol, seed=1):
                   attention_mask=tree_mask_4d(anc, L, n), past_key_values=cache, use_cache=True).logits[0]
     err_tree = (got - want).abs().max().item()
     top2 = want.topk(2, dim=-1).values
-    decided = (top2[:, 0] - top2[:, 1]) > 4 * tol                      # rows whose fp32 arg-max is not a near-tie
+    decided = (top2[:, 0] - top2[:, 1]) > (decide_gap or 4 * tol)      # rows whose fp32 arg-max is not a near-tie
     agree = (b["argmax"][:n].long() == want.argmax(-1))
     print(f"prefill-last |dlogit| {err_prefill:.4f}, tree |dlogit| {err_tree:.4f} (|logit| max {want.abs().max().item():.2f}); arg-max agreement "
           f"{agree.float().mean().item():.3f} over {n} nodes, {int(decided.sum())} decided rows")
@@ -298,6 +298,60 @@ def test_llama3_shape_long_context_matches_hf_fp32():
         runner = LlamaRunner.from_hf(lm, max_cache_len=8192, dtype=torch.bfloat16, attention=attention)
         verify_against_hf(lm, runner, 6000, 63, 128256, tol=0.25, seed=3)
         del runner
+
+
+def test_llama3_8b_full_depth_forward_matches_hf_fp32():
+    """configs[3]'s base model at FULL depth: Llama-3-8B's shape -- 32 layers, hidden 4096, inter 14336, 32 query / 8 KV heads,
+    vocab 128256, llama3 rope scaling, bf16 -- against a random-init transformers LlamaForCausalLM of the same shape in fp32
+    (32 GB) on the same GPU: last-position logits after a 2000-token prefill, then a 63-node tree verify (EAGLE-2's draft size) over
+    the cached prompt with the reference's 4-D additive tree mask (samd_sam_only/model_patch/llama.py:82-96), then a 13-node tree on
+    the 16-row bucket (norm-fold forward).  bf16 rounds activations to 8 bits ~250 times on the way through 32 layers, so the yardstick
+    is what the REFERENCE's own arithmetic loses in bf16: the same HF model cast to bfloat16 (what samd/samd_model.py runs) is
+    evaluated beside ours, and our error against fp32 must stay within 1.5x of HF-bf16's error against fp32 (plus 0.02); the absolute
+    bound TOL = 0.8 on logits of range +-6.7 is stated for the record (measured on MI355X: 0.39 after the prefill, 0.67 on the tree
+    rows).  The arg-max must agree with fp32 on every node whose fp32 top-2 gap exceeds 2 x TOL."""
+    import copy
+    from transformers import DynamicCache
+    from samd_hip.llama import LlamaRunner
+    TOL = 0.8
+    rs = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192,
+              rope_theta=500000.0)
+    cfg = dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+               vocab_size=128256, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_parameters=rs)
+    try:
+        lm = hf_llama(cfg, seed=3)
+    except Exception as e:
+        pytest.skip(f"LlamaConfig(rope_parameters=...) unsupported: {e}")
+    runner = LlamaRunner.from_hf(lm, max_cache_len=4096, dtype=torch.bfloat16, share_weights=False)
+    assert runner.norm_fold
+    # the reference's own arithmetic in bf16: HF's LlamaForCausalLM cast to bfloat16, same prompt, same tree
+    lm16 = copy.deepcopy(lm).to(torch.bfloat16)
+    lm16.model.rotary_emb.inv_freq = lm.model.rotary_emb.inv_freq.clone()       # .to(bf16) rounds the rotary frequencies too; from_pretrained(dtype=bf16) keeps them fp32
+    if hasattr(lm16.model.rotary_emb, "original_inv_freq"):
+        lm16.model.rotary_emb.original_inv_freq = lm.model.rotary_emb.inv_freq.clone()
+    for prompt_len, n, seed in ((2000, 63, 5), (1200, 13, 6)):
+        e_pre, e_tree = verify_against_hf(lm, runner, prompt_len, n, 128256, tol=TOL, seed=seed, decide_gap=2 * TOL)
+        rng = np.random.default_rng(seed)
+        prompt = rng.integers(3, 128256, prompt_len).tolist()
+        anc = random_parents(rng, n, "bushy")
+        toks = rng.integers(3, 128256, n).tolist()
+        depth = [0] * n
+        for i in range(1, n):
+            depth[i] = depth[anc[i]] + 1
+        ids = torch.tensor([prompt], device="cuda")
+        outs = []
+        with torch.no_grad():
+            for m in (lm, lm16):
+                cache = DynamicCache()
+                last = m(input_ids=ids, past_key_values=cache, use_cache=True, logits_to_keep=1).logits[0, -1].float()
+                mask = tree_mask_4d(anc, prompt_len, n).to(next(m.parameters()).dtype)
+                tree = m(input_ids=torch.tensor([toks], device="cuda"), position_ids=torch.tensor([[prompt_len + x for x in depth]], device="cuda"),
+                         attention_mask=mask, past_key_values=cache, use_cache=True).logits[0].float()
+                outs.append((last, tree))
+        hf_pre = (outs[0][0] - outs[1][0]).abs().max().item()
+        hf_tree = (outs[0][1] - outs[1][1]).abs().max().item()
+        print(f"llama3-8b full depth, L={prompt_len}, n={n}: ours vs fp32 {e_pre:.4f} / {e_tree:.4f}; HF bf16 vs fp32 {hf_pre:.4f} / {hf_tree:.4f}")
+        assert e_pre <= 1.5 * hf_pre + 0.02 and e_tree <= 1.5 * hf_tree + 0.02
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
