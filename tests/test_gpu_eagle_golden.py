@@ -20,10 +20,13 @@ Two layers:
       (c) a different draft whose FIRST differing top-k decision is a near-tie of the reference: recorded margin
           (value[p] - value[p+1]) <= 2 * TOL_FP16, with all values before it within TOL_FP16.
     Anything else fails, and at least MIN_SAME of a fixture's calls must end in (a) or (b): 80 % for the fp16 head (on the box every
-    call of the V = 512 fixtures is (a)).  For the bf16 head no share is demanded: bf16 carries 8x the rounding noise, the ~300 ordered
-    decisions of an expansion over random weights include margins of 0.005-0.04, and on the box all five calls end in (c) at such a
-    margin -- the test proves exactly that (first difference = a recorded near-tie, everything before it equal), which is also all a
-    bf16 run of the reference itself could promise.
+    call of the V = 512 fixtures is (a)).  For the bf16 head on the RANDOM-weight fixture no share is demanded: bf16 carries 8x the
+    rounding noise, the ~300 ordered decisions of an expansion over random weights include margins of 0.005-0.04, and on the box all
+    five calls end in (c) at such a margin (the differing decision's recorded margin must be <= TIE_CAP_BF16 = 0.1).
+
+ 3. round 4: the bf16 device head on the PLANTED fixture (eagle2_planted_bf16.npz, V = 32000), where reproduction is decidable: every
+    recorded decision has a margin >= 0.25 = 10x the measured bf16 noise, and the drafts must be identical (>= 80 % of the calls; all
+    five on the box) -- test_eagle2_bf16_device_head_reproduces_reference_on_the_planted_fixture.
 
 Fixtures: eagle2_hd128.npz / eagle_hd128.npz (fp16-representable weights, V = 512), eagle2_hd128_v32k.npz (V = 32000: the row
 statistics take their split path) and eagle2_hd128_bf16.npz (weights and inputs representable in bf16 -- configs[3] computes in
@@ -48,6 +51,7 @@ from eagle_fixture_weights import CFG, call_inputs, head_state, lm_head_weight
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL_FP16 = 0.1
 TOL_BF16 = 0.8
+TIE_CAP_BF16 = 0.1                 # random-weight bf16 fixture: a differing decision must be a recorded near-tie below this (observed 0.005-0.04)
 NOISE_BF16_PLANTED = 0.04          # bound on |device value - reference value| of the planted fixture's top-k values (measured on MI355X: 0.0250);
                                    # accepted near-tie margin = 2x = 0.08, the fixture's smallest recorded margin is 0.25 = 10x the measured noise
 MIN_SAME = {"f16": 0.8, "bf16": 0.0, "bf16_planted": 0.8}
@@ -129,11 +133,12 @@ def test_eagle_v1_fp32_on_gpu_matches_recorded_reference(name):
 # ---------------------------------------------------------------------------------------------------------------------
 # 2. the fp16 device head vs the head_dim-128 recordings, decision by decision
 # ---------------------------------------------------------------------------------------------------------------------
-def follow(ref_calls, dev_calls, last_is_a_set=False, tol=TOL_FP16):
+def follow(ref_calls, dev_calls, last_is_a_set=False, tol=TOL_FP16, tie_cap=None):
     """compare two top-k decision sequences -> None when every call agrees (indices equal, values within TOL_FP16), else
     (call j, row, position, recorded margin) of the first difference, which must be a near-tie of the reference.
     last_is_a_set: the final call only selects (EAGLE-2 sorts the kept candidates by index afterwards, eagle2_model.py:893-895)."""
     assert len(ref_calls) == len(dev_calls)
+    tie_cap = 2 * tol if tie_cap is None else tie_cap            # the largest recorded margin a differing decision may have
     for j, ((rv, ri, rnext), (dv, di)) in enumerate(zip(ref_calls, dev_calls)):
         rv2, ri2, dv2, di2 = (np.asarray(a).reshape(-1, np.asarray(a).shape[-1]) for a in (rv, ri, dv, di))
         if last_is_a_set and j == len(ref_calls) - 1 and sorted(ri2.reshape(-1).tolist()) == sorted(di2.reshape(-1).tolist()):
@@ -144,8 +149,8 @@ def follow(ref_calls, dev_calls, last_is_a_set=False, tol=TOL_FP16):
             for p in range(rv2.shape[1]):
                 if ri2[row, p] != di2[row, p]:
                     margin = float(ext[p] - ext[p + 1])
-                    assert margin <= 2 * tol, (f"top-k call {j} row {row} position {p}: device chose {di2[row, p]}, reference {ri2[row, p]} "
-                                               f"with margin {margin:.4f} > 2 x {tol}")
+                    assert margin <= tie_cap, (f"top-k call {j} row {row} position {p}: device chose {di2[row, p]}, reference {ri2[row, p]} "
+                                               f"with margin {margin:.4f} > {tie_cap}")
                     return j, row, p, margin
                 assert abs(float(rv2[row, p]) - float(dv2[row, p])) <= tol, (j, row, p, float(rv2[row, p]), float(dv2[row, p]))
     return None
@@ -209,7 +214,9 @@ def test_eagle2_device_head_follows_recorded_reference(fixture, kind):
             notes.append(f"call {ci}: same tree, other numbering")
             good += 1
         else:
-            where = follow(ref_trace(z, f"c{ci}"), dev_calls, last_is_a_set=True, tol=tol)       # asserts that the first difference is a near-tie
+            # asserts that the first difference is a near-tie; bf16: values may sit 0.8 apart (logits of 64-128 are 0.5 apart in bf16),
+            # but the DECISION that differs must be closer than TIE_CAP_BF16 = 0.1 in the reference (observed: 0.005-0.04)
+            where = follow(ref_trace(z, f"c{ci}"), dev_calls, last_is_a_set=True, tol=tol, tie_cap=TIE_CAP_BF16 if kind == "bf16" else None)
             assert where is not None, f"call {ci}: drafts differ although every recorded decision matches"
             notes.append(f"call {ci}: near-tie at top-k call {where[0]} row {where[1]} pos {where[2]} (recorded margin {where[3]:.4f})")
     summary = f"eagle2 {kind} device head vs recorded reference ({fixture}): " + "; ".join(notes)
