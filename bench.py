@@ -163,16 +163,33 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
                 frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=traffic, traffic_from=traffic_from, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
                 visited_states=n_visited, alg_bytes_per_launch=int(alg_bytes), transitions_per_s=round(B * T / (ms * 1e-3), 1),
                 line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2),
-                # the walk is request-bound: one 64-byte request per visited state carries 16 algorithmic bytes
-                request_ceiling_gbps=round(HBM_REQUESTS_PER_S * 16 / 1e9, 1),
-                frac_of_request_ceiling=round(gbps / (HBM_REQUESTS_PER_S * 16 / 1e9), 4)), toks
+                # the walk is bound by the rate of scattered 64-byte requests (scripts/hbm_probe.hip: ~48.6 G/s whatever their size);
+                # request_rate() fills in the measured rate once `traffic` is final
+                request_ceiling_per_s=HBM_REQUESTS_PER_S), toks
 
 
-def live_walk_traffic(corpus_tokens, B, T, timeout_s=180):
+def request_rate(roof):
+    """requests_per_s = HBM traffic of a launch / 64 B / launch time, against the probed ceiling of scattered requests; a launch may
+    serve several visited states per request (chain words, hashed blocks), so this -- not bytes per visited state -- is the quantity
+    the ceiling bounds.  Null without counters."""
+    t = roof.get("traffic")
+    if t:
+        req = t / 64.0
+        roof["requests_per_launch"] = int(req)
+        roof["requests_per_visited_state"] = round(req / max(roof["visited_states"], 1), 4)
+        roof["requests_per_s"] = round(req / (roof["launch_ms"] * 1e-3), 1)
+        roof["frac_of_request_ceiling"] = round(req / (roof["launch_ms"] * 1e-3) / roof["request_ceiling_per_s"], 4)
+    else:
+        roof["requests_per_s"] = roof["frac_of_request_ceiling"] = None
+    return roof
+
+
+def live_walk_traffic(corpus_tokens, B, T, timeout_s=90):
     """HBM bytes of ONE k_static_walk launch measured in this bench run: scripts/walk_probe.py (the same corpus, streams and kernel)
     as a CHILD process under `rocprofv3 --kernel-trace --pmc <counter>`, FETCH_SIZE and WRITE_SIZE in separate passes as
     MI355X_MICROARCH.md prescribes (FETCH_SIZE is exact for this scattered 16-byte pattern: profiles/r01_hbm_probe.md).  Returns
-    (bytes or None, how / why not).  Never raises: the committed profiles/walk_pmc.json stays the fallback."""
+    (bytes or None, how / why not).  Never raises: the committed profiles/walk_pmc.json stays the fallback.  timeout_s bounds BOTH
+    passes together (each takes ~10 s), so a default bench run cannot be held up for minutes by a stuck profiler."""
     import csv
     import glob
     import shutil
@@ -185,6 +202,7 @@ def live_walk_traffic(corpus_tokens, B, T, timeout_s=180):
     if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this process is itself being profiled"
     per_launch = {}
+    deadline = time.monotonic() + timeout_s
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="samd_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "w", "--",
@@ -193,11 +211,11 @@ def live_walk_traffic(corpus_tokens, B, T, timeout_s=180):
             p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                  start_new_session=True)
             try:
-                p.wait(timeout=timeout_s)
+                p.wait(timeout=max(deadline - time.monotonic(), 1.0))
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)           # the process group this call created, nothing else
                 p.wait()
-                return None, f"the {counter} pass did not finish in {timeout_s} s"
+                return None, f"the {counter} pass did not finish inside the {timeout_s} s both passes share"
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -460,7 +478,7 @@ def launch_selftest(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-    total, dt_max, per_rank = parallel.reduce_throughput(100 * (rank + 1), 1.0 + rank)
+    total, dt_max, per_rank = parallel.reduce_throughput(100 * (rank + 1), 1.0 + rank, extra={"static_sam_distribution_ms": 5.0 + rank})
     if rank == 0:
         print(json.dumps({"selftest": True, "n_gpus": world, "gpus_flag": args.gpus, "value": total / dt_max, "per_rank": per_rank}), flush=True)
     if world > 1:
@@ -609,9 +627,13 @@ def main():
     # does not start on a GPU whose clocks are still ramping after seconds of host-side setup (one of five such runs on fresh boxes lost
     # 8 ms of its 69 ms window that way)
     if model.engine.use_graphs and args.spin_up_ms > 0:
+        from samd_hip.engine import StepReport
+        spin_R = lm.bucket(max(StepReport(model.engine._report_np).n, 1))      # the bucket of the draft the session holds right now
+        lm.warm(spin_R)                                                         # buffers / LDS reservation exist before the capture
+        torch.cuda.synchronize()
         spin = torch.cuda.CUDAGraph()
         with torch.cuda.graph(spin):
-            lm.verify(model.engine.session, runner.BUCKETS[1])
+            lm.verify(model.engine.session, spin_R)
         t_spin = time.perf_counter()
         while (time.perf_counter() - t_spin) * 1e3 < args.spin_up_ms:
             for _ in range(8):
@@ -649,7 +671,8 @@ def main():
         session_phases.update({k: round(cnt[4 + i] * 0.01 / cnt[0], 2) for i, k in enumerate(
             ("eval_posterior_us", "dyn_update_us", "static_transfer_us", "lookup_draft_buffers_us"))})
 
-    tokens_total, dt_max, per_rank = parallel.reduce_throughput(tokens, dt)      # SUM of tokens, MAX of time over ranks
+    # SUM of tokens, MAX of time over ranks; every rank's own wait for the static automaton (broadcast + adopt) travels along
+    tokens_total, dt_max, per_rank = parallel.reduce_throughput(tokens, dt, extra={"static_sam_distribution_ms": broadcast_ms})
 
     # context, outside the timed region: a short timed window (the driver's 20 steps = ~46 tokens inside one request) samples the
     # accepted-token process with +-20 % noise; the same request stream continued for LONG_RUN_STEPS more steps gives the rate the
@@ -715,6 +738,7 @@ def main():
             roof["traffic_from"] = dict(roof["traffic_from"] or {}, committed_file_bytes=roof["traffic"], live=how)
             if live is not None:
                 roof["traffic"] = live
+        request_rate(roof)
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(flat, off, docs, cfg, toks_walk)    # rank 0 at N = 1 only
 
         n_steps = sum(v[0] for v in stats.values())
@@ -737,7 +761,8 @@ def main():
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
             "per_rank": [dict(r, ms_per_step=round(r["seconds"] / args.steps * 1e3, 4)) for r in per_rank], "bucket_histogram": bucket_hist,
             "static_sam_distribution": {"how": "RCCL broadcast from rank 0 + samd_static_adopt_device" if world > 1 else "host image -> HBM upload",
-                                        "ms": round(broadcast_ms, 2), "bytes": int(sam_info["device_bytes"])},
+                                        "ms": round(broadcast_ms, 2), "ms_per_rank": [r["static_sam_distribution_ms"] for r in per_rank],
+                                        "bytes": int(sam_info["device_bytes"])},
             # samd[EAGLE2] / samd[EAGLE] run a RANDOM-INIT draft head (no EAGLE weights exist on the box): its drafts are noise, so
             # `value` and `speedup_vs_ar` of such a run price the plugin PATH (head forwards + 63-node verify), they are not a result of
             # the method.  What the path would deliver at the accepted-token counts the reference publishes (README.md:55-57) follows

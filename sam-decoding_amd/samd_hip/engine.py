@@ -363,21 +363,30 @@ class DecodeEngine:
             # ~265 nodes, during which the GPU idles); a short head graph (embedding + the first layers) starts the GPU after ~10 us and
             # the rest is enqueued while it runs (scripts/host_turnaround.py).  SAMD_GRAPH_SPLIT_LAYER = the layers to cut before.
             g = _GraphChain(len(cuts) + 1)
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream()
+            cur = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 part = [0]
                 g.parts[0].capture_begin()
 
                 def hook(li):
-                    if li in cuts:
+                    if li in cuts and part[0] < len(g.parts) - 1:            # a second pass over the layers must not index past the parts
                         g.parts[part[0]].capture_end()
                         part[0] += 1
                         g.parts[part[0]].capture_begin()
                 runner.layer_hook = hook
                 try:
                     self._enqueue_step(R)
+                except BaseException:
+                    # never leave the stream in capture mode: end the open part (its graph is discarded with `g`) before re-raising
+                    runner.layer_hook = None
+                    try:
+                        g.parts[part[0]].capture_end()
+                    except Exception:
+                        pass
+                    cur.wait_stream(side)
+                    raise
                 finally:
                     runner.layer_hook = None
                 g.parts[part[0]].capture_end()

@@ -14,12 +14,13 @@ from . import StaticAutomaton
 
 
 def shard_bounds(n_items, world, rank):
-    """contiguous chunks as eval_vicuna.py:50-65: chunk = n // world per worker, the remainder goes to the last one
-    (the reference spawns one extra tail task; a fixed world folds it into the last rank)."""
-    chunk = n_items // world
-    lo = rank * chunk
-    hi = n_items if rank == world - 1 else lo + chunk
-    return lo, hi
+    """contiguous chunks as eval_vicuna.py:50-65 (chunk = n // world questions per worker, in question order).  The reference
+    hands the remainder to one extra Ray task that runs after the others; with a fixed world that tail would double the last
+    rank's wall time (480 questions + 7 on 8 GPUs), so the n % world leftover questions are spread one each over the first
+    ranks: rank r gets chunk + 1 when r < n % world.  Still contiguous, still in order, sizes differ by at most one."""
+    chunk, rem = divmod(n_items, world)
+    lo = rank * chunk + min(rank, rem)
+    return lo, lo + chunk + (1 if rank < rem else 0)
 
 
 def broadcast_static(auto, src=0, device=None):
@@ -76,15 +77,20 @@ def gather_results(rows, pad=-1, device=None):
     return res
 
 
-def reduce_throughput(tokens, seconds):
+def reduce_throughput(tokens, seconds, extra=None):
     """bench.py's whole-job figure: tokens summed over ranks, wall time = MAX over ranks, plus what every rank did.
-    -> (tokens_total, seconds_max, [{"rank", "tokens", "seconds"}]).  Works without a process group (world size 1)."""
+    -> (tokens_total, seconds_max, [{"rank", "tokens", "seconds", **extra}]).  `extra`: name -> float of this rank (e.g. how long
+    the static automaton took to arrive), reported per rank as is.  Works without a process group (world size 1)."""
+    extra = dict(extra or {})
+    names = sorted(extra)
     if not (dist.is_available() and dist.is_initialized()):
-        return float(tokens), float(seconds), [{"rank": 0, "tokens": int(tokens), "seconds": round(float(seconds), 4)}]
+        return float(tokens), float(seconds), [dict({"rank": 0, "tokens": int(tokens), "seconds": round(float(seconds), 4)},
+                                                    **{k: round(float(extra[k]), 3) for k in names})]
     use_gpu = dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
-    mine = torch.tensor([float(tokens), float(seconds)], dtype=torch.float64, device=dev)
+    mine = torch.tensor([float(tokens), float(seconds)] + [float(extra[k]) for k in names], dtype=torch.float64, device=dev)
     parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, mine)
-    per_rank = [{"rank": r, "tokens": int(v[0].item()), "seconds": round(float(v[1].item()), 4)} for r, v in enumerate(parts)]
+    per_rank = [dict({"rank": r, "tokens": int(v[0].item()), "seconds": round(float(v[1].item()), 4)},
+                     **{k: round(float(v[2 + i].item()), 3) for i, k in enumerate(names)}) for r, v in enumerate(parts)]
     return float(sum(v[0].item() for v in parts)), float(max(v[1].item() for v in parts)), per_rank

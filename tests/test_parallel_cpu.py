@@ -61,7 +61,7 @@ def test_broadcast_shard_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     want = [list(range(100 * i, 100 * i + (i % 4))) for i in range(11)]
-    assert [r[2] for r in res] == [(0, 5), (5, 11)]          # chunk = 11 // 2, remainder to the last rank
+    assert [r[2] for r in res] == [(0, 6), (6, 11)]          # chunk = 11 // 2, the leftover question goes to the first rank
     for rank, same, _, flat in res:
         assert same, "broadcast automaton differs from the source"
         assert flat == want                                   # every rank sees all results, in request order
@@ -112,16 +112,47 @@ def test_run_eval_shards_and_gathers_world2(tmp_path):
     rows = [json.loads(l) for l in ans.read_text().splitlines()]
     assert [r["question_id"] for r in rows] == [10, 11, 12, 13, 14]
     who = [r["choices"][0]["turns"][0] for r in rows]
-    assert who == ["answer of rank 0"] * 2 + ["answer of rank 1"] * 3          # chunk = 5 // 2, remainder to the last rank
-    assert res[0][1] == 3 * 1 + 2 and res[1][1] == 3 * 1 + 3                  # 3 warm-up passes + own questions
+    assert who == ["answer of rank 0"] * 3 + ["answer of rank 1"] * 2          # chunk = 5 // 2, the leftover question to the first rank
+    assert res[0][1] == 3 * 1 + 3 and res[1][1] == 3 * 1 + 2                  # 3 warm-up passes + own questions
     assert res[0][2] == res[1][2] and len(res[0][2]) == 2 * 5                 # every rank holds all accept lengths, in question order
+    assert sorted(os.listdir(tmp_path / "out")) == ["a.jsonl"]
+
+
+def test_run_eval_world8_with_a_question_count_that_does_not_divide(tmp_path):
+    """configs[4]'s shape on CPU: 8 ranks (gloo), 21 questions = 8 x 2 + 5: the first five ranks take 3 questions, the others 2;
+    every question answered exactly once, one answer file in question order, every rank holds all 42 accept lengths."""
+    import json
+    n_q, world = 21, 8
+    qs = [{"question_id": 100 + i, "category": "qa", "turns": [f"question number {i}"]} for i in range(n_q)]
+    qfile = tmp_path / "q.jsonl"
+    qfile.write_text("".join(json.dumps(x) + "\n" for x in qs))
+    ans = tmp_path / "out" / "a.jsonl"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, str(qfile), str(ans), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rows = [json.loads(l) for l in ans.read_text().splitlines()]
+    assert [r["question_id"] for r in rows] == list(range(100, 100 + n_q))
+    who = [r["choices"][0]["turns"][0] for r in rows]
+    want = sum((["answer of rank %d" % r] * (3 if r < 5 else 2) for r in range(world)), [])
+    assert who == want
+    assert [r[1] for r in res] == [3 + (3 if r < 5 else 2) for r in range(world)]      # 3 warm-up passes + own questions
+    assert all(r[2] == res[0][2] for r in res) and len(res[0][2]) == 2 * n_q
     assert sorted(os.listdir(tmp_path / "out")) == ["a.jsonl"]
 
 
 def test_shard_bounds_cover_everything():
     from samd_hip import parallel
-    for n in (0, 1, 7, 80, 481):
+    for n in (0, 1, 7, 80, 481, 487):
         for world in (1, 2, 4, 8):
             spans = [parallel.shard_bounds(n, world, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)     # balanced, the extra ones first
