@@ -41,7 +41,8 @@ def test_two_ranks_are_spawned_reduced_and_relayed():
     assert len(lines) == 1, r.stdout                                          # only rank 0 prints
     d = lines[0]
     assert d["n_gpus"] == 2 and d["gpus_flag"] == 2
-    assert d["per_rank"] == [{"rank": 0, "tokens": 100, "seconds": 1.0}, {"rank": 1, "tokens": 200, "seconds": 2.0}]
+    assert d["per_rank"] == [{"rank": 0, "tokens": 100, "seconds": 1.0, "static_sam_distribution_ms": 5.0},
+                             {"rank": 1, "tokens": 200, "seconds": 2.0, "static_sam_distribution_ms": 6.0}]    # every rank's own figures
     assert abs(d["value"] - 300 / 2.0) < 1e-9                                 # SUM of tokens / MAX of time
 
 
