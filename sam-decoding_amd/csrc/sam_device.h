@@ -77,6 +77,13 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
 // word of the new state is fetched (one 16-byte load that then serves up to W transitions).  W = 8 (u16 tokens) or 4 (u32).  Results are identical to st_transfer's by construction;
 // tests/test_gpu_sam.py and test_gpu_fullsize.py compare both with the oracle.
 // ------------------------------------------------------------------------------------------------
+// Round 4: chain entries carry a FLAG in their top bit (clear = flagged, so that "no word" = all-ones says nothing): entry j of the word
+// loaded at state s, a real token, flagged <=> state s + j has no edge but that token (SAMD_SINGLE) and its suffix link is a child of
+// the root.  A cursor at s + j that holds the word and meets another token then knows the outcome of transfer_state's whole climb
+// without loading anything at s + j: the state fails, its link is root_next[previous token] (the only root child whose strings end
+// in the token that brought the cursor here), whose hashed block decides in one probe (root16 carries its length).  In the bench walk
+// this is what every noise token does: node + link node + its tail + a spill probe (3.5 requests, 5 dependent rounds) become one
+// probe.  W = 8: 15-bit tokens (vocabularies <= 32767); W = 4: 31-bit tokens.
 struct ChainWord { unsigned long long lo, hi; int used; };     // used = tokens of this word already consumed
 __device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = ~0ull; c.used = 0; return c; }
 __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
@@ -87,46 +94,74 @@ __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
     w.used = 0;
     return w;
 }
+// the first half of a state's chain word, as the root-child hash stores it beside the edge that leads there (samd_common.h): it serves
+// W / 2 transitions; when those are used up the full word of the state reached is fetched, exactly as after a full word
+template <int W>
+__device__ __forceinline__ ChainWord chain_half(unsigned lo, unsigned hi) {
+    ChainWord w;
+    w.lo = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    w.hi = ~0ull;
+    w.used = W / 2;
+    return w;
+}
 
 // position of the cursor's state in the ROOT-CHILD HASH (samd_common.h): valid (slots > 0) only while the cursor sits on the state it
 // reached through the root table
 struct RootChild { int base, slots; };
 __device__ __forceinline__ RootChild rootchild_none() { RootChild r; r.base = 0; r.slots = 0; return r; }
 
-template <int W>
-__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, ChainWord &cw, RootChild &rc) {
-    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); rc.slots = 0; return 1; }
-    {   // register path
-        const unsigned next = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
-        const unsigned term = W == 8 ? 0xFFFFu : 0xFFFFFFFFu;
-        if (next != term && next == (unsigned)tok) {
-            idx += 1; len += 1; rc.slots = 0;
-            if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
-            else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
-            // a FULL word used up: the run may go on -- fetch the new state's word now (one load) instead of finding out through
-            // its node and then fetching the word (two); a word that ended early marks the end of the run
-            if (++cw.used == W) cw = chain_load(S, idx);
-            return 1;
-        }
+// one probe sequence of a root child's hashed block: -> the entry {tok, dst, first half of chain[dst]} or tok = -1
+__device__ __forceinline__ uint4 d1_probe(const StaticDev &S, int base, int slots, int tok) {
+    const uint32_t m = (uint32_t)slots;
+    const uint4 *tab = S.d1hash + base;
+    uint32_t h = samd_spill_hash(tok, m);
+    for (uint32_t probes = 0; probes < m; probes++) {
+        const uint4 e = tab[h];
+        if ((int)e.x == tok) return e;
+        if ((int)e.x == -1) break;
+        h = (h + 1) & (m - 1);
     }
+    return make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+}
+
+// ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown
+template <int W>
+__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, int ptok, ChainWord &cw, RootChild &rc) {
+    constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
+    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); rc.slots = 0; return 1; }
+    const unsigned ent = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+    const bool is_tok = (ent & LOW) != LOW;                  // a chain token (the end marker is all-ones)
+    if (is_tok && (ent & LOW) == (unsigned)tok) {            // register path
+        idx += 1; len += 1; rc.slots = 0;
+        if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
+        else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
+        // a FULL word used up: the run may go on -- fetch the new state's word now (one load) instead of finding out through
+        // its node and then fetching the word (two); a word that ended early marks the end of the run
+        if (++cw.used == W) cw = chain_load(S, idx);
+        return 1;
+    }
+    const bool known_climb = is_tok && !(ent & HI) && ptok >= 0 && S.root16 != nullptr;
     cw = chain_none();
     int visited = 0;
     bool hopped = false;
-    if (rc.slots) {
+    if (known_climb) {
+        // flagged entry: idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.  transfer_state visits idx,
+        // hops (length <- states[link].length), and looks for `tok` there: all edges of that state are in its hashed block.
+        const uint4 r = S.root16[ptok];
+        rc.slots = 0;
+        visited = 1; idx = (int)r.x; len = (int)r.w; hopped = true;
+        if (r.z) {
+            const uint4 e = d1_probe(S, (int)r.y, (int)r.z, tok);
+            if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return 2; }
+            visited = 2; idx = 0; len = 0;                   // no edge there either; the link of a root child is the root
+        }
+        // (a root child of degree <= 5 has no block: the loop below visits it through its node)
+    } else if (rc.slots) {
         // on a high-degree child of the root, reached through the root table: ONE probe of its hashed block decides (all its edges are
         // there).  No edge = the reference's visit of this state plus the hop to its suffix link, which is the root.
-        const uint32_t m = (uint32_t)rc.slots;
-        const SamEdge *tab = S.d1hash + rc.base;
-        uint32_t h = samd_spill_hash(tok, m);
-        int nx = -1;
-        for (uint32_t probes = 0; probes < m; probes++) {
-            const SamEdge e = tab[h];
-            if (e.tok == tok) { nx = e.dst; break; }
-            if (e.tok == -1) break;
-            h = (h + 1) & (m - 1);
-        }
+        const uint4 e = d1_probe(S, rc.base, rc.slots, tok);
         rc.slots = 0;
-        if (nx >= 0) { idx = nx; len += 1; cw = chain_load(S, idx); return 1; }
+        if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return 1; }
         visited = 1; idx = 0; len = 0; hopped = true;
     }
     for (;;) {
@@ -175,10 +210,10 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
 __device__ __forceinline__ void st_transfer_tokens(const StaticDev &S, int &idx, int &len, const int *toks, int n) {
     if (S.chain && S.chain_w == 8) {
         ChainWord cw = chain_none(); RootChild rc = rootchild_none();
-        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, idx, len, toks[i], cw, rc);
+        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, idx, len, toks[i], i ? toks[i - 1] : -1, cw, rc);
     } else if (S.chain) {
         ChainWord cw = chain_none(); RootChild rc = rootchild_none();
-        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, idx, len, toks[i], cw, rc);
+        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, idx, len, toks[i], i ? toks[i - 1] : -1, cw, rc);
     } else {
         for (int i = 0; i < n; i++) st_transfer(S, idx, len, toks[i]);
     }

@@ -15,8 +15,8 @@ static inline StaticDev static_view(const samd_static_t *s) {
     if (!s) { memset(&v, 0, sizeof(v)); return v; }
     v.nodes = s->d_nodes; v.root_next = s->d_root; v.spill = s->d_spill; v.text = s->d_text;
     v.n_states = (int32_t)s->n_states; v.vocab = (int32_t)s->vocab; v.n_text = (int32_t)s->n_text; v.kind = s->kind;
-    v.chain = (const uint4 *)s->d_chain; v.chain_w = s->vocab < 65535 ? 8 : 4;
-    v.root16 = (const uint4 *)s->d_root16; v.d1hash = (const SamEdge *)s->d_d1hash;
+    v.chain = (const uint4 *)s->d_chain; v.chain_w = s->vocab <= 32767 ? 8 : 4;
+    v.root16 = (const uint4 *)s->d_root16; v.d1hash = (const uint4 *)s->d_d1hash;
     v.topk_cnt = (const int32_t *)s->d_topk_cnt;
     return v;
 }
@@ -44,12 +44,13 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
         int tok = tokens[b];
         ChainWord cw = chain_none();
         RootChild rc = rootchild_none();
+        int ptok = -1;
         for (int t = 0; t < T; t++) {
             const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;
-            if (CHAIN) visited += st_transfer_chain<W>(S, idx, len, tok, cw, rc);
+            if (CHAIN) visited += st_transfer_chain<W>(S, idx, len, tok, ptok, cw, rc);
             else visited += st_transfer(S, idx, len, tok);
             if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(idx, len);
-            tok = nxt;
+            ptok = tok; tok = nxt;
         }
         if (commit) reinterpret_cast<int2 *>(cursors)[b] = make_int2(idx, len);
     }
@@ -65,13 +66,18 @@ __global__ __launch_bounds__(256) void k_build_chain(const SamNode *__restrict__
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     unsigned tokw[W];
+    constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
     bool alive = true;
 #pragma unroll
     for (int j = 0; j < W; j++) {
         tokw[j] = W == 8 ? 0xFFFFu : 0xFFFFFFFFu;
         if (alive && s + j < n) {
             const int4 w0 = reinterpret_cast<const int4 *>(nodes + s + j)[0];
-            if (w0.z >= 0 && (long long)w0.w == s + j + 1) tokw[j] = (unsigned)w0.z; else alive = false;
+            if (w0.z >= 0 && (unsigned)w0.z < LOW && (long long)w0.w == s + j + 1) {
+                // flag (top bit CLEAR): state s + j has this one edge only and its suffix link is a child of the root
+                const bool flagged = (w0.y & SAMD_SINGLE) && w0.x > 0 && nodes[w0.x].link == 0;
+                tokw[j] = (unsigned)w0.z | (flagged ? 0u : HI);
+            } else alive = false;
         } else alive = false;
     }
     uint4 o;
@@ -401,19 +407,20 @@ __global__ __launch_bounds__(256) void k_d1_sizes(const SamNode *__restrict__ no
 }
 __global__ __launch_bounds__(256) void k_d1_fill(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, const int32_t *__restrict__ root_next,
                                                  int vocab, const long long *__restrict__ offsets, const int32_t *__restrict__ sizes,
-                                                 uint4 *__restrict__ root16, SamEdge *__restrict__ hash) {
+                                                 const uint4 *__restrict__ chain, uint4 *__restrict__ root16, uint4 *__restrict__ hash) {
     const int tok = blockIdx.x * blockDim.x + threadIdx.x;
     if (tok >= vocab) return;
     const int dst = root_next[tok], m = sizes[tok];
     const long long base = offsets[tok];
-    root16[tok] = make_uint4((unsigned)dst, (unsigned)base, (unsigned)m, 0u);
+    root16[tok] = make_uint4((unsigned)dst, (unsigned)base, (unsigned)m, dst > 0 ? (unsigned)(nodes[dst].length & SAMD_LEN_MASK) : 0u);
     if (m == 0) return;
-    SamEdge *tab = hash + base;
+    uint4 *tab = hash + base;
     auto put = [&](int t, int d) {
         if (t < 0) return;
         uint32_t h = samd_spill_hash(t, (uint32_t)m);
-        while (tab[h].tok != -1) { if (tab[h].tok == t) return; h = (h + 1) & (uint32_t)(m - 1); }     // (the spill head repeats ranks 5..7)
-        tab[h].tok = t; tab[h].dst = d;
+        while ((int)tab[h].x != -1) { if ((int)tab[h].x == t) return; h = (h + 1) & (uint32_t)(m - 1); }     // (the spill head repeats ranks 5..7)
+        const uint4 c = d > 0 ? chain[d] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        tab[h] = make_uint4((unsigned)t, (unsigned)d, c.x, c.y);                                          // edge + the first half of its target's chain word
     };
     const int *w = reinterpret_cast<const int *>(nodes + dst);
     for (int k = 0; k < SAMD_INLINE_EDGES; k++) put(w[SAMD_EDGE_WORD(k)], w[SAMD_EDGE_WORD(k) + 1]);
@@ -465,11 +472,11 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st) {
     for (int i = 0; i < vocab && rc == SAMD_OK; i++) { off[i] = total; total += sizes[i]; }
     if (rc == SAMD_OK && total >= (1ll << 31)) { total = 0; rc = -1; }      // base does not fit 32 bits: go without the hash
     if (rc == SAMD_OK && total > 0) {
-        if (hipMalloc(&s->d_root16, (size_t)vocab * 16) != hipSuccess || hipMalloc(&s->d_d1hash, (size_t)total * 8) != hipSuccess) rc = SAMD_E_HIP;
-        if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)total * 8, st) != hipSuccess ||
+        if (hipMalloc(&s->d_root16, (size_t)vocab * 16) != hipSuccess || hipMalloc(&s->d_d1hash, (size_t)total * 16) != hipSuccess) rc = SAMD_E_HIP;
+        if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)total * 16, st) != hipSuccess ||
                               hipMemcpyAsync(d_off, off.data(), (size_t)vocab * 8, hipMemcpyHostToDevice, st) != hipSuccess)) rc = SAMD_E_HIP;
         if (rc == SAMD_OK) {
-            hipLaunchKernelGGL(k_d1_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, d_off, d_sizes, (uint4 *)s->d_root16, (SamEdge *)s->d_d1hash);
+            hipLaunchKernelGGL(k_d1_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, d_off, d_sizes, (const uint4 *)s->d_chain, (uint4 *)s->d_root16, (uint4 *)s->d_d1hash);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
         }
         s->n_d1hash = total;
@@ -488,7 +495,7 @@ int samd_static_derive_chain(samd_static_t *s, void *stream) {
     if (!s || !s->uploaded || !s->d_nodes) return SAMD_E_INVALID;
     if (!s->d_chain && hipMalloc(&s->d_chain, (size_t)s->n_states * 16) != hipSuccess) { s->d_chain = nullptr; samd_set_error("hipMalloc(chain words) failed"); return SAMD_E_HIP; }
     const unsigned blocks = (unsigned)((s->n_states + 255) / 256);
-    if (s->vocab < 65535) hipLaunchKernelGGL(k_build_chain<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
+    if (s->vocab <= 32767) hipLaunchKernelGGL(k_build_chain<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
     else hipLaunchKernelGGL(k_build_chain<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
     LAUNCHCHK();
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { samd_set_error("chain-word derivation failed"); return SAMD_E_HIP; }

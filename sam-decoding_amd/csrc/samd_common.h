@@ -28,7 +28,8 @@
 // CHAIN WORDS (device-only, derived from the node image at upload): chain[s] = the rank-0 tokens of the non-branching run that
 // starts at s -- token j is e0.tok of state s + j as long as e0.dst of every state s .. s + j is the NEXT state in memory
 // (the builder numbers states in creation order, which makes a corpus position's successor state the next index: 93 % of
-// the states of the bench automaton) -- as 8 x u16 (vocab < 65535) or 4 x u32, terminator all-ones.  A cursor that holds
+// the states of the bench automaton) -- as 8 x u16 (vocab <= 32767: 15-bit tokens) or 4 x u32, terminator all-ones; the top bit of an
+// entry is CLEAR when state s + j is SAMD_SINGLE and its suffix link is a child of the root (sam_device.h, "Round 4").  A cursor that holds
 // chain[s] follows up to 8 matching tokens WITHOUT touching memory (st_transfer_chain, sam_device.h): the batched walk runs at
 // the memory system's request rate, and this removes ~0.37 of its requests (scripts/walk_chain_sim.py).
 struct __attribute__((aligned(64))) SamNode {
@@ -70,13 +71,13 @@ struct StaticDev {
     // ROOT-CHILD HASH (device-only, derived at upload; may be null).  The states one token below the root are where a walk lands after
     // every mismatch, and in a real corpus they have the highest degrees of the automaton (every token that ever followed t): resolving
     // a transition there through the node costs its line, its tail and a probe of its spill block -- three dependent round trips, two
-    // HBM lines.  root16[tok] = {dst, base, slots, 0} extends the dense root table (root_next) by the position of a hashed block that
+    // HBM lines.  root16[tok] = {dst, base, slots, length[dst]} extends the dense root table (root_next) by the position of a hashed block that
     // holds ALL edges of dst (ranks 0..4 included; slots = power of two >= 2 x deg, samd_spill_hash, linear probing, empty = (-1,-1);
     // slots = 0 for children of degree <= 5, which resolve inside their node line anyway).  A cursor that just landed through the root
     // table carries (base, slots) and resolves its next token with ONE probe: found -> the edge; not found -> no edge at all, and the
     // suffix link of a root child is the root (its shortest string has length 1), so the node is never loaded.
     const uint4 *root16;
-    const SamEdge *d1hash;
+    const uint4 *d1hash;        // 16-byte entries {tok, dst, first half of chain[dst]} (round 4), empty = all-ones
     // TOP-K COUNTS (device-only, derived at upload; may be null): topk_cnt[8 s + k] = cnt_endpos of state s's rank-k successor, the
     // numerators of the best-first tree's child probabilities (static_sam.py:205-210).  Without it an expansion is two dependent round
     // trips (the parent's node for the edges, then the children's nodes for their counts); with it one.

@@ -11,7 +11,7 @@ import samd_hip
 from samd_hip import Params
 from oracle import sam_oracle as O
 from scripted_lm import ScriptedLM
-from util import markov_stream, split_edges, random_parents
+from util import walk_visited, markov_stream, split_edges, random_parents
 
 
 def dev(a, dtype=torch.int32):
@@ -88,6 +88,8 @@ def test_static_walk_batched_vs_oracle(vocab, B, T):
     cur2 = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
     prod.walk(cur2, dev(toks), commit=True, visited=visited)
     assert torch.equal(cur, cur2) and int(visited.item()) >= B * T
+    if B * T <= 70000:                  # the visited-state count (the bench's algorithmic bytes) is the reference's, state for state
+        assert int(visited.item()) == walk_visited(ora.export(), toks)
     got = trace.cpu().numpy()
     for b in range(0, B, max(1, B // 64)):
         i, l = 0, 0
@@ -134,6 +136,63 @@ def test_static_walk_long_runs_use_chain_words(base):
             i, l = ora.transfer_state(i, l, int(toks[t, b]))
             assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (b, t)
     check_stream_major_walk(prod, toks, got, cur)
+
+
+@pytest.mark.parametrize("vocab", [1000, 32767, 32768, 90000])
+def test_static_walk_known_climbs(vocab):
+    """round 4 (csrc/sam_device.h "Round 4"): a chain entry whose top bit is clear says that its state has ONE edge and that its suffix
+    link is a child of the root; a cursor holding the word resolves a mismatch there through root16[previous token] and one probe of
+    that child's hashed block -- without loading the state or its link.  Exercised here: climbs that end at the root (miss), climbs
+    whose probe HITS (the offending token does follow the previous token elsewhere), links to root children of degree <= 5 (no block:
+    node path), mismatches on the first / a middle / the last entry of a word and right after a half word from the hash, token ids at
+    the top of the vocabulary (32766 in 15-bit entries; vocab 32768 and 90000 take the 31-bit form), and the visited-state count.
+    Every (index, length) against the oracle."""
+    rng = np.random.default_rng(vocab)
+    ids = rng.permutation(np.arange(3, vocab - 2))[:400].tolist()
+    A = [vocab - 1, vocab - 2] + ids[:300]                     # one long run of distinct tokens, the two largest ids first
+    extra = ids[300:]
+    hub, hub2 = A[77], A[150]
+    docs = [A, A[100:180] + A[20:60]]
+    docs += [[hub, z] for z in extra[:12]]                     # state(hub) gets 13 successors: a hashed block
+    docs += [[hub2, z, z + 1 if z + 1 < vocab else 5] for z in extra[12:20]]
+    docs += [[t] for t in extra[20:40]]
+    prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    ora = O.StaticSAM.build(docs, 2)
+    streams = []
+    for off in range(40):
+        q = A[max(0, 30 + off):max(0, 30 + off) + 60]
+        q[17 + off % 9] = extra[20 + off % 20]                  # a token that exists but follows nothing here: climb to the root
+        q[40 + off % 5] = int(rng.integers(vocab, vocab + 3))   # out of vocabulary
+        streams.append(q)
+    for j, z in enumerate(extra[:12]):                          # the climb's probe hits: ... A[77] z
+        streams.append((A[40 + j:78] + [z] + A[79:101 + j])[:60])
+    for j, z in enumerate(extra[12:20]):                        # ... A[150] z z+1 A[153] ...
+        streams.append((A[120 + j:151] + [z, z + 1 if z + 1 < vocab else 5] + A[153:190])[:60])
+    for j in range(8):                                          # mismatch right after a landing through the hash's half word
+        streams.append(([A[76], hub, extra[j]] + A[200 + j:257 + j])[:60])
+        streams.append((A[0:3 + j] + [A[1]] + A[3 + j:70])[:60])   # the largest ids, early mismatch positions
+    toks = np.array([s + [A[5]] * (60 - len(s)) for s in streams], dtype=np.int64).astype(np.int32).T.copy()
+    T, B = toks.shape
+    cur = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    trace = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.walk(cur, dev(toks), commit=True, trace=trace)
+    prod.walk(torch.zeros_like(cur), dev(toks), commit=False, visited=visited)
+    got = trace.cpu().numpy()
+    for b in range(B):
+        i, l = 0, 0
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[t, b]))
+            assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (b, t)
+    assert int(visited.item()) == walk_visited(ora.export(), toks)
+    check_stream_major_walk(prod, toks, got, cur, int(visited.item()))
+    # the single-wavefront form (the session kernel's committed transfer: st_transfer_tokens) walks the same streams
+    sess = samd_hip.Session(256)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for b in range(0, B, 3):
+        sess.reset()
+        sess.static_walk(prod, dev(toks[:, b].copy()), T, commit=True, d_out=out)
+        assert out.cpu().tolist() == [int(got[T - 1, b, 0]), int(got[T - 1, b, 1])], b
 
 
 def test_static_walk_empty_and_ragged():

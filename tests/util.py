@@ -63,3 +63,30 @@ def toy_dialogues(rng, words, n=50):
         pick = lambda k: " ".join(phrases[int(j)] for j in rng.integers(0, len(phrases), k))
         out.append({"prompt": pick(int(rng.integers(1, 4))) + " ", "response": pick(int(rng.integers(1, 5)))})
     return out
+
+
+def walk_visited(export, toks_tb):
+    """states the reference's transfer_state examines (samd_sam_only/sam/static_sam.py:98-107: every state of the climb, the one where
+    it ends included) over all streams of a time-major token matrix, cursors starting at the root; `export` = oracle export().
+    Negative tokens count 1 (no state has such an edge: the kernels do not climb for them)."""
+    link, deg = export["link"].tolist(), export["deg"].tolist()
+    et, ed = export["edge_tok"].tolist(), export["edge_dst"].tolist()
+    nxt, k = [], 0
+    for d in deg:
+        nxt.append(dict(zip(et[k:k + d], ed[k:k + d])))
+        k += d
+    T, B = len(toks_tb), len(toks_tb[0])
+    total = 0
+    for b in range(B):
+        idx = 0
+        for t in range(T):
+            tok = int(toks_tb[t][b])
+            if tok < 0:
+                idx, total = 0, total + 1
+                continue
+            total += 1
+            while idx != 0 and tok not in nxt[idx]:
+                idx = link[idx]
+                total += 1
+            idx = nxt[idx].get(tok, 0)
+    return total
