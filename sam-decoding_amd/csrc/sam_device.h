@@ -144,25 +144,30 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
     cw = chain_none();
     int visited = 0;
     bool hopped = false;
-    if (known_climb) {
-        // flagged entry: idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.  transfer_state visits idx,
-        // hops (length <- states[link].length), and looks for `tok` there: all edges of that state are in its hashed block.
-        const uint4 r = S.root16[ptok];
-        rc.slots = 0;
-        visited = 1; idx = (int)r.x; len = (int)r.w; hopped = true;
-        if (r.z) {
-            const uint4 e = d1_probe(S, (int)r.y, (int)r.z, tok);
-            if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return 2; }
-            visited = 2; idx = 0; len = 0;                   // no edge there either; the link of a root child is the root
+    if (known_climb || rc.slots) {
+        // Both kinds of cursor end in ONE probe of a root child's hashed block (all edges of that state are there), so they share it:
+        // a wave pays one memory round trip for its climbing lanes and its lanes below the root together.
+        //   known_climb (flagged entry): idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.
+        //     transfer_state visits idx, hops (length <- states[link].length) and looks for `tok` there.
+        //   rc.slots: the cursor sits on a root child it reached through the root table.
+        // No edge in the block = that state visited too, then the hop to ITS suffix link, the root -- whose entry for `tok` was
+        // requested up front (an L2 hit, no HBM request), so the miss costs no further round trip.
+        int base = rc.base, slots = rc.slots;
+        uint4 rt = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        if (tok < S.vocab) rt = S.root16[tok];
+        if (known_climb) {
+            const uint4 r = S.root16[ptok];
+            visited = 1; idx = (int)r.x; len = (int)r.w; base = (int)r.y; slots = (int)r.z;
         }
-        // (a root child of degree <= 5 has no block: the loop below visits it through its node)
-    } else if (rc.slots) {
-        // on a high-degree child of the root, reached through the root table: ONE probe of its hashed block decides (all its edges are
-        // there).  No edge = the reference's visit of this state plus the hop to its suffix link, which is the root.
-        const uint4 e = d1_probe(S, rc.base, rc.slots, tok);
-        rc.slots = 0;
-        if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return 1; }
-        visited = 1; idx = 0; len = 0; hopped = true;
+        rc.slots = 0; hopped = true;
+        if (slots) {
+            const uint4 e = d1_probe(S, base, slots, tok);
+            if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return visited + 1; }
+            const int nx = (int)rt.x;
+            if (nx >= 0) { idx = nx; len = 1; rc.base = (int)rt.y; rc.slots = (int)rt.z; } else { idx = 0; len = 0; }
+            return visited + 2;
+        }
+        // (a known climb to a root child of degree <= 5, which has no block: the loop below visits it through its node)
     }
     for (;;) {
         visited++;
