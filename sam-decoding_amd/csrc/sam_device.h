@@ -124,10 +124,15 @@ __device__ __forceinline__ uint4 d1_probe(const StaticDev &S, int base, int slot
     return make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 
-// ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown
+// ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown; ntok = the token
+// after `tok` (-1 when unknown).  pre = root16[ptok] when pre.x != 0xFFFFFFFF: a cursor that follows a chain entry and SEES that its next
+// token will leave the run through a flagged entry requests the root child's entry one token early, so that the climb is one round trip.
 template <int W>
-__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, int ptok, ChainWord &cw, RootChild &rc) {
+__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, int ptok, int ntok, ChainWord &cw, RootChild &rc,
+                                                 uint4 &pre) {
     constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
+    const uint4 pre_in = pre;
+    pre.x = 0xFFFFFFFFu;
     if (tok < 0) { idx = 0; len = 0; cw = chain_none(); rc.slots = 0; return 1; }
     const unsigned ent = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
     const bool is_tok = (ent & LOW) != LOW;                  // a chain token (the end marker is all-ones)
@@ -138,52 +143,72 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
         // a FULL word used up: the run may go on -- fetch the new state's word now (one load) instead of finding out through
         // its node and then fetching the word (two); a word that ended early marks the end of the run
         if (++cw.used == W) cw = chain_load(S, idx);
+        else if (ntok >= 0 && S.root16 != nullptr) {
+            const unsigned e2 = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+            if ((e2 & LOW) != LOW && !(e2 & HI) && (e2 & LOW) != (unsigned)ntok) pre = S.root16[tok];      // the next call climbs from here
+        }
         return 1;
     }
     const bool known_climb = is_tok && !(ent & HI) && ptok >= 0 && S.root16 != nullptr;
     cw = chain_none();
     int visited = 0;
     bool hopped = false;
-    if (known_climb || rc.slots) {
-        // Both kinds of cursor end in ONE probe of a root child's hashed block (all edges of that state are there), so they share it:
-        // a wave pays one memory round trip for its climbing lanes and its lanes below the root together.
-        //   known_climb (flagged entry): idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.
-        //     transfer_state visits idx, hops (length <- states[link].length) and looks for `tok` there.
-        //   rc.slots: the cursor sits on a root child it reached through the root table.
-        // No edge in the block = that state visited too, then the hop to ITS suffix link, the root -- whose entry for `tok` was
-        // requested up front (an L2 hit, no HBM request), so the miss costs no further round trip.
-        int base = rc.base, slots = rc.slots;
-        uint4 rt = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
-        if (tok < S.vocab) rt = S.root16[tok];
-        if (known_climb) {
-            const uint4 r = S.root16[ptok];
-            visited = 1; idx = (int)r.x; len = (int)r.w; base = (int)r.y; slots = (int)r.z;
-        }
-        rc.slots = 0; hopped = true;
-        if (slots) {
-            const uint4 e = d1_probe(S, base, slots, tok);
-            if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return visited + 1; }
-            const int nx = (int)rt.x;
-            if (nx >= 0) { idx = nx; len = 1; rc.base = (int)rt.y; rc.slots = (int)rt.z; } else { idx = 0; len = 0; }
-            return visited + 2;
-        }
-        // (a known climb to a root child of degree <= 5, which has no block: the loop below visits it through its node)
+    int base = rc.base, slots = rc.slots;
+    rc.slots = 0;
+    if (known_climb) {
+        // flagged entry: idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.  transfer_state visits idx,
+        // hops (length <- states[link].length) and looks for `tok` there.
+        uint4 r = pre_in;
+        if (r.x == 0xFFFFFFFFu) r = S.root16[ptok];
+        visited = 1; idx = (int)r.x; len = (int)r.w; base = (int)r.y; slots = (int)r.z; hopped = true;
     }
+    // THE FIRST LOAD OF EVERY LANE IS ONE INSTRUCTION: 16 bytes from a per-lane address -- a slot of a root child's hashed block (the
+    // climbing lanes and the lanes that sit on a root child: all edges of that state are there, one probe decides), the root's entry
+    // for `tok`, or word 0 of the cursor's node.  A wave advances in lock-step, so what it pays per token is the number of dependent
+    // PHASES, not of loads: with the kinds in separate branches a token cost their sum (profiles/r04_walk.md).
+    const bool probing = slots != 0;
+    const bool tok_ok = tok < S.vocab;
+    const bool at_root = !probing && idx == 0 && tok_ok && S.root16 != nullptr;
+    const uint32_t m = (uint32_t)slots;
+    uint32_t h = probing ? samd_spill_hash(tok, m) : 0u;
+    const uint4 *addr = probing ? S.d1hash + base + h : at_root ? S.root16 + tok : reinterpret_cast<const uint4 *>(S.nodes + idx);
+    // where a failed probe ends: the root's entry for `tok`, requested with the probe (an L2 hit, no HBM request)
+    uint4 rt = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    if (probing && tok_ok) rt = S.root16[tok];
+    const uint4 first = *addr;
+    if (probing) {
+        const uint4 *tab = S.d1hash + base;
+        uint4 e = first;
+        for (uint32_t probes = 1; (int)e.x != tok && (int)e.x != -1 && probes < m; probes++) { h = (h + 1) & (m - 1); e = tab[h]; }
+        if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return visited + 1; }
+        // no edge in the block = that state visited too, then the hop to ITS suffix link, the root
+        const int nx = (int)rt.x;
+        if (nx >= 0) { idx = nx; len = 1; rc.base = (int)rt.y; rc.slots = (int)rt.z; } else { idx = 0; len = 0; }
+        return visited + 2;
+    }
+    if (at_root) {
+        const int nx = (int)first.x;
+        // (no word is fetched for a landing through the root table: a depth-1 state is rarely left through its rank-0 edge --
+        // measured 0.401 ms per launch with the fetch against 0.374 without)
+        if (nx >= 0) { idx = nx; len += 1; rc.base = (int)first.y; rc.slots = (int)first.z; } else { idx = 0; len = 0; }
+        return visited + 1;
+    }
+    bool use_first = idx != 0;
     for (;;) {
         visited++;
         if (idx == 0) {
             int nx = -1;
-            if (tok < S.vocab) {
+            if (tok_ok) {
                 if (S.root16) { const uint4 r = S.root16[tok]; nx = (int)r.x; rc.base = (int)r.y; rc.slots = nx >= 0 ? (int)r.z : 0; }
                 else nx = S.root_next[tok];
             }
-            // (no word is fetched for a landing through the root table: a depth-1 state is rarely left through its rank-0 edge --
-            // measured 0.401 ms per launch with the fetch against 0.374 without)
             if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
             return visited;
         }
         const int4 *np = reinterpret_cast<const int4 *>(S.nodes + idx);
-        const int4 w0 = np[0];
+        int4 w0;
+        if (use_first) { w0 = make_int4((int)first.x, (int)first.y, (int)first.z, (int)first.w); use_first = false; }
+        else w0 = np[0];
         if (hopped) len = w0.y & SAMD_LEN_MASK;
         if (w0.z == tok) {                                   // rank-0 edge
             idx = w0.w; len += 1;
@@ -214,11 +239,11 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
 // has them, so that a run of tokens that follows the corpus costs one load per 8 (4) tokens instead of one per token
 __device__ __forceinline__ void st_transfer_tokens(const StaticDev &S, int &idx, int &len, const int *toks, int n) {
     if (S.chain && S.chain_w == 8) {
-        ChainWord cw = chain_none(); RootChild rc = rootchild_none();
-        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, idx, len, toks[i], i ? toks[i - 1] : -1, cw, rc);
+        ChainWord cw = chain_none(); RootChild rc = rootchild_none(); uint4 pre = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, idx, len, toks[i], i ? toks[i - 1] : -1, i + 1 < n ? toks[i + 1] : -1, cw, rc, pre);
     } else if (S.chain) {
-        ChainWord cw = chain_none(); RootChild rc = rootchild_none();
-        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, idx, len, toks[i], i ? toks[i - 1] : -1, cw, rc);
+        ChainWord cw = chain_none(); RootChild rc = rootchild_none(); uint4 pre = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, idx, len, toks[i], i ? toks[i - 1] : -1, i + 1 < n ? toks[i + 1] : -1, cw, rc, pre);
     } else {
         for (int i = 0; i < n; i++) st_transfer(S, idx, len, toks[i]);
     }

@@ -44,10 +44,11 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
         int tok = tokens[b];
         ChainWord cw = chain_none();
         RootChild rc = rootchild_none();
+        uint4 pre = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
         int ptok = -1;
         for (int t = 0; t < T; t++) {
             const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;
-            if (CHAIN) visited += st_transfer_chain<W>(S, idx, len, tok, ptok, cw, rc);
+            if (CHAIN) visited += st_transfer_chain<W>(S, idx, len, tok, ptok, t + 1 < T ? nxt : -1, cw, rc, pre);
             else visited += st_transfer(S, idx, len, tok);
             if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(idx, len);
             ptok = tok; tok = nxt;
