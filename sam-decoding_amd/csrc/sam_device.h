@@ -84,14 +84,18 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
 // in the token that brought the cursor here), whose hashed block decides in one probe (root16 carries its length).  In the bench walk
 // this is what every noise token does: node + link node + its tail + a spill probe (3.5 requests, 5 dependent rounds) become one
 // probe.  W = 8: 15-bit tokens (vocabularies <= 32767); W = 4: 31-bit tokens.
-struct ChainWord { unsigned long long lo, hi; int used; };     // used = tokens of this word already consumed
-__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = ~0ull; c.used = 0; return c; }
+// used = tokens of this word already consumed; (nlo, nhi) = the NEXT word of the run when have_next: requested while the last entry of
+// this one is still unused, so that a cursor deep in a run never waits for a word (a wave otherwise stalls at the top of every token
+// for the lanes -- one in eight -- that used up a word at the previous one)
+struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next; };
+__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = c.nlo = c.nhi = ~0ull; c.used = 0; c.have_next = 0; return c; }
 __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
     const uint4 c = S.chain[state];
     ChainWord w;
     w.lo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
     w.hi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
-    w.used = 0;
+    w.nlo = w.nhi = ~0ull;
+    w.used = 0; w.have_next = 0;
     return w;
 }
 // the first half of a state's chain word, as the root-child hash stores it beside the edge that leads there (samd_common.h): it serves
@@ -100,8 +104,8 @@ template <int W>
 __device__ __forceinline__ ChainWord chain_half(unsigned lo, unsigned hi) {
     ChainWord w;
     w.lo = (unsigned long long)lo | ((unsigned long long)hi << 32);
-    w.hi = ~0ull;
-    w.used = W / 2;
+    w.hi = w.nlo = w.nhi = ~0ull;
+    w.used = W / 2; w.have_next = 0;
     return w;
 }
 
@@ -109,20 +113,6 @@ __device__ __forceinline__ ChainWord chain_half(unsigned lo, unsigned hi) {
 // reached through the root table
 struct RootChild { int base, slots; };
 __device__ __forceinline__ RootChild rootchild_none() { RootChild r; r.base = 0; r.slots = 0; return r; }
-
-// one probe sequence of a root child's hashed block: -> the entry {tok, dst, first half of chain[dst]} or tok = -1
-__device__ __forceinline__ uint4 d1_probe(const StaticDev &S, int base, int slots, int tok) {
-    const uint32_t m = (uint32_t)slots;
-    const uint4 *tab = S.d1hash + base;
-    uint32_t h = samd_spill_hash(tok, m);
-    for (uint32_t probes = 0; probes < m; probes++) {
-        const uint4 e = tab[h];
-        if ((int)e.x == tok) return e;
-        if ((int)e.x == -1) break;
-        h = (h + 1) & (m - 1);
-    }
-    return make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-}
 
 // ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown; ntok = the token
 // after `tok` (-1 when unknown).  pre = root16[ptok] when pre.x != 0xFFFFFFFF: a cursor that follows a chain entry and SEES that its next
@@ -140,12 +130,24 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
         idx += 1; len += 1; rc.slots = 0;
         if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
         else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
-        // a FULL word used up: the run may go on -- fetch the new state's word now (one load) instead of finding out through
-        // its node and then fetching the word (two); a word that ended early marks the end of the run
-        if (++cw.used == W) cw = chain_load(S, idx);
-        else if (ntok >= 0 && S.root16 != nullptr) {
+        // a FULL word used up: the run may go on -- its next word was requested one token ago (below); without it (a word that came
+        // in with one entry left) fetch the new state's word now.  A word that ended early marks the end of the run.
+        bool in_regs = true;
+        if (++cw.used == W) {
+            if (cw.have_next) { cw.lo = cw.nlo; cw.hi = cw.nhi; cw.nlo = cw.nhi = ~0ull; cw.used = 0; cw.have_next = 0; }
+            else { cw = chain_load(S, idx); in_regs = false; }
+        }
+        if (in_regs) {
             const unsigned e2 = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
-            if ((e2 & LOW) != LOW && !(e2 & HI) && (e2 & LOW) != (unsigned)ntok) pre = S.root16[tok];      // the next call climbs from here
+            const bool tok2 = (e2 & LOW) != LOW;
+            if (cw.used == W - 1 && tok2) {                  // one entry left and the run goes on: the word of the state after it
+                const uint4 c = S.chain[idx + 1];
+                cw.nlo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
+                cw.nhi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
+                cw.have_next = 1;
+            }
+            // the next call will climb from here (flagged entry, another token): request the root child's entry now
+            if (ntok >= 0 && S.root16 != nullptr && tok2 && !(e2 & HI) && (e2 & LOW) != (unsigned)ntok) pre = S.root16[tok];
         }
         return 1;
     }

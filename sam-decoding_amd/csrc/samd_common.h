@@ -72,7 +72,7 @@ struct StaticDev {
     // every mismatch, and in a real corpus they have the highest degrees of the automaton (every token that ever followed t): resolving
     // a transition there through the node costs its line, its tail and a probe of its spill block -- three dependent round trips, two
     // HBM lines.  root16[tok] = {dst, base, slots, length[dst]} extends the dense root table (root_next) by the position of a hashed block that
-    // holds ALL edges of dst (ranks 0..4 included; slots = power of two >= 2 x deg, samd_spill_hash, linear probing, empty = (-1,-1);
+    // holds ALL edges of dst (ranks 0..4 included; slots = power of two >= 4 x deg, samd_spill_hash, linear probing, empty = (-1,-1);
     // slots = 0 for children of degree <= 5, which resolve inside their node line anyway).  A cursor that just landed through the root
     // table carries (base, slots) and resolves its next token with ONE probe: found -> the edge; not found -> no edge at all, and the
     // suffix link of a root child is the root (its shortest string has length 1), so the node is never loaded.
