@@ -28,6 +28,19 @@
 
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
 
+// compute units of the CURRENT device, looked up once per device (a process may drive several GPUs)
+static int samd_cu_count() {
+    static int cached[64];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return 256;
+    if (d >= 0 && d < 64 && cached[d] > 0) return cached[d];
+    int n = 256;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+    if (d >= 0 && d < 64) cached[d] = n;
+    return n;
+}
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(256) void k_gemm_pack_qkv(const uint4 *__restrict__
 // in a launch bound by what a CU's memory pipe ingests); Vicuna-13B's 15360 = 320 x 48 (two rounds) or 240 x 64 (one): 64.
 static int qkv_tile_groups(int n_heads_total) {
     static const int env = [] { const char *e = getenv("SAMD_QKV_TILE"); return e ? atoi(e) : 0; }();
-    static const int n_cu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount; return n; }();
+    const int n_cu = samd_cu_count();
     const int N = n_heads_total * 128;
     if (N % 48 != 0 || env == 64) return 4;
     if (env == 48) return 3;
@@ -872,7 +885,7 @@ int samd_gemm_pairs_silu_norm(const void *d_x, const float *d_ssq, const void *d
         K / 16 > 32 * NORM_NS || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
         samd_set_error("samd_gemm_pairs_silu_norm: unsupported shape (16 rows, inter %% 16 == 0, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
     }
-    static const int n_cu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount; return n; }();
+    const int n_cu = samd_cu_count();
     const int n_pairs = inter / 16;
     int grid = n_pairs < n_cu ? n_pairs : n_cu;
     while ((n_pairs + grid - 1) / grid > 4) grid += n_cu;
@@ -909,7 +922,7 @@ int samd_gemm_pairs_silu(const void *d_A, const void *d_Wg, int32_t rows_pad, in
         samd_set_error("samd_gemm_pairs_silu: unsupported shape (rows 16/32/48/64, inter %% 16 == 0, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
     }
     // one workgroup per CU (256 on MI355X) with an even share of the pairs; more workgroups only when a share would exceed 4 pairs (8 waves)
-    static const int n_cu = [] { int d = 0, n = 256; hipDeviceProp_t p; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount; return n; }();
+    const int n_cu = samd_cu_count();
     const int n_pairs = inter / 16;
     int grid = n_pairs < n_cu ? n_pairs : n_cu;
     while ((n_pairs + grid - 1) / grid > 4) grid += n_cu;

@@ -16,8 +16,19 @@
 #include "samd_common.h"
 
 static thread_local char g_err[512] = "";
+static thread_local char g_detail[256] = "";
+// a detail recorded below the place that names the failing entry point (e.g. what the device's LDS offers): the next samd_set_error
+// appends it instead of overwriting it
+void samd_set_error_detail(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_detail, sizeof(g_detail), fmt, ap); va_end(ap);
+}
 void samd_set_error(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    if (g_detail[0]) {
+        const size_t n = strlen(g_err);
+        snprintf(g_err + n, sizeof(g_err) - n, " [%s]", g_detail);
+        g_detail[0] = 0;
+    }
 }
 extern "C" const char *samd_last_error(void) { return g_err; }
 

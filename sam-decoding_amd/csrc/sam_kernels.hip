@@ -169,6 +169,7 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         load_draft(D, sh, type, n, nl, md);
         do_accept_given(D, sh, A.given, A.given_next, type, n, nl, md, a, nt);
         wave_mem_sync();
+        phase_done(C_T_ACCEPT);
     }
     if (A.ops & OP_COMMIT) {
         // DraftModel.update(accepted tokens) (draft.py:62-67)

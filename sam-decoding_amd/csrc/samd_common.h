@@ -158,6 +158,7 @@ extern "C"
 int samd_static_derive_chain(struct samd_static *s, void *stream);
 
 void samd_set_error(const char *fmt, ...);
+void samd_set_error_detail(const char *fmt, ...);      // kept until the next samd_set_error, which appends it
 
 #if defined(__HIPCC__)
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (kernel, device), not once per
@@ -172,7 +173,7 @@ static inline hipError_t samd_reserve_lds(const void *kernel, int bytes, unsigne
     if (e != hipSuccess) {                                   // say what the device offers (a 64 KiB-LDS part cannot run these kernels)
         int optin = 0;
         if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess)
-            samd_set_error("device %d offers %d bytes of LDS per workgroup, the kernel needs %d (written for gfx950: 160 KiB)", dev, optin, bytes);
+            samd_set_error_detail("device %d offers %d bytes of LDS per workgroup, the kernel needs %d (written for gfx950: 160 KiB)", dev, optin, bytes);
     }
     if (e == hipSuccess && dev >= 0 && dev < 64) *done |= 1ull << dev;
     return e;
