@@ -520,6 +520,11 @@ int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_t
  * left alone).  Tests and bench only. */
 int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride,
                          int32_t markov_vocab, void *stream);
+/* the same for a source whose next token depends on the LAST token alone (bench.py --variant token_recycle: bench._succ1, eight
+ * successors per token over the ids [3, hot_vocab)): what a token-keyed successor table can learn, as the reference's does on natural
+ * text (S/tree_model/token_recycle/token_recycle.py:40-48).  Tests and bench only. */
+int samd_scripted_logits_order1(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride,
+                                int32_t hot_vocab, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token Recycle (S/tree_model/token_recycle/token_recycle.py:18-63)

@@ -325,18 +325,23 @@ __global__ __launch_bounds__(256) void k_transpose_i32(const int32_t *__restrict
 // draft node i with context (a, b) = (its parent's token | the last committed token, its own token) the row gets, on top of the model's
 // own logits: the scripted arg-max (samd_scripted_argmax) as the best entry, then the sparse order-2 Markov source's four successors of
 // (a, b) in rank order (bench._succ, the same hash) -- the distribution the synthetic corpus and requests are drawn from.
-template <typename T>
+// ORDER = 2: the four successors of (a, b) in bench._succ's order; ORDER = 1 (bench.py --variant token_recycle, round 4): the eight
+// successors of b alone in bench._succ1's order over a hot vocabulary of `markov_vocab` ids -- a source whose next token depends on the
+// last token, which is what a token-keyed successor table (Token Recycle) can learn.
+template <typename T, int ORDER>
 __global__ __launch_bounds__(64) void k_scripted_logits(SessionDev D, const int32_t *__restrict__ argmax, T *__restrict__ logits, long long stride,
                                                         int markov_vocab, int rows) {
     const int i = blockIdx.x, n = D.dmeta[D_N];
-    if (i >= n || i >= rows || threadIdx.x > 4) return;
+    constexpr int NS = ORDER == 2 ? 4 : 8;
+    if (i >= n || i >= rows || threadIdx.x > NS) return;
     const int b = D.tokens[i], par = D.parent[i];
     const int nc = D.meta[M_NTEXT] - 1;
     const int a = par >= 0 ? D.tokens[par] : (nc > 0 ? D.text[nc] : 0);           // text[0] is the sentinel: text[nc] = last committed token
     T *row = logits + (size_t)i * stride;
     const int c = (int)threadIdx.x - 1;
     if (c < 0) { row[argmax[i]] = (T)96.f; return; }
-    unsigned long long h = ((unsigned long long)(unsigned)a * 1000003ull + (unsigned long long)(unsigned)b * 10007ull + (unsigned long long)c * 7919ull + 12345ull) & 0x7FFFFFFFull;
+    unsigned long long h = ((ORDER == 2 ? (unsigned long long)(unsigned)a * 1000003ull : 0ull) + (unsigned long long)(unsigned)b * 10007ull
+                            + (unsigned long long)c * 7919ull + 12345ull) & 0x7FFFFFFFull;
     h = (h * 2654435761ull) & 0xFFFFFFFFull;
     const int tok = 3 + (int)(h % (unsigned long long)(markov_vocab - 3));
     if (tok != argmax[i]) row[tok] = (T)(64.f - 4.f * (float)c);
@@ -820,15 +825,28 @@ int samd_scripted_argmax(samd_session_t *s, const int32_t *d_target, int32_t n_t
     return SAMD_OK;
 }
 
-int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride, int32_t markov_vocab, void *stream) {
+static int scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride, int32_t markov_vocab,
+                           int order, void *stream) {
     if (!s || !d_argmax || !d_logits || markov_vocab < 4 || row_stride < markov_vocab) return SAMD_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_scripted_logits<_Float16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (_Float16 *)d_logits, (long long)row_stride, markov_vocab, rows);
-    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_scripted_logits<__bf16>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (__bf16 *)d_logits, (long long)row_stride, markov_vocab, rows);
-    else if (dtype == SAMD_F32) hipLaunchKernelGGL(k_scripted_logits<float>, dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (float *)d_logits, (long long)row_stride, markov_vocab, rows);
+#define SCRIPTED(T) do { if (order == 2) hipLaunchKernelGGL((k_scripted_logits<T, 2>), dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (T *)d_logits, (long long)row_stride, markov_vocab, rows); \
+                         else hipLaunchKernelGGL((k_scripted_logits<T, 1>), dim3(SAMD_MAX_DRAFT), dim3(WAVE), 0, st, s->dev, d_argmax, (T *)d_logits, (long long)row_stride, markov_vocab, rows); } while (0)
+    if (dtype == SAMD_F16) SCRIPTED(_Float16);
+    else if (dtype == SAMD_BF16) SCRIPTED(__bf16);
+    else if (dtype == SAMD_F32) SCRIPTED(float);
     else return SAMD_E_INVALID;
+#undef SCRIPTED
     LAUNCHCHK();
     return SAMD_OK;
+}
+
+int samd_scripted_logits(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride, int32_t markov_vocab, void *stream) {
+    return scripted_logits(s, d_argmax, d_logits, dtype, rows, row_stride, markov_vocab, 2, stream);
+}
+
+int samd_scripted_logits_order1(samd_session_t *s, const int32_t *d_argmax, void *d_logits, int32_t dtype, int32_t rows, int64_t row_stride, int32_t hot_vocab,
+                                void *stream) {
+    return scripted_logits(s, d_argmax, d_logits, dtype, rows, row_stride, hot_vocab, 1, stream);
 }
 
 int samd_tree_buffers(const int32_t *d_parent, int32_t n, int32_t reverse_leaves, int32_t *d_position, uint64_t *d_mask,

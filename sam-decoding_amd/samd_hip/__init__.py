@@ -106,6 +106,7 @@ _PROTOS = {
     "samd_gemm_pairs_silu_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_cs_residual": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "samd_scripted_logits": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),
+    "samd_scripted_logits_order1": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),
     "samd_session_device_views": (C.c_int, [_VP, _VP]),
     "samd_tree_buffers": (C.c_int, [_VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_argmax_rows": (C.c_int, [_VP, _I32, _I32, _I64, _I64, _VP, _VP, _VP]),
@@ -436,8 +437,9 @@ class Session:
         """enqueue the D2H copy of the per-step report block into a pinned int32[REPORT_INTS] tensor."""
         check(lib().samd_session_report_async(self._h, _ptr(h_pinned), current_stream()))
 
-    def scripted_logits(self, d_argmax, logits, markov_vocab):
-        check(lib().samd_scripted_logits(self._h, _ptr(d_argmax), _ptr(logits), torch_dtype_code(logits.dtype), logits.shape[0], logits.stride(0), markov_vocab, current_stream()))
+    def scripted_logits(self, d_argmax, logits, markov_vocab, order=2):
+        fn = lib().samd_scripted_logits if order == 2 else lib().samd_scripted_logits_order1
+        check(fn(self._h, _ptr(d_argmax), _ptr(logits), torch_dtype_code(logits.dtype), logits.shape[0], logits.stride(0), markov_vocab, current_stream()))
 
     def scripted_argmax(self, d_target, n_target, vocab, d_out):
         check(lib().samd_scripted_argmax(self._h, _ptr(d_target), n_target, vocab, _ptr(d_out), current_stream()))

@@ -121,11 +121,13 @@ class ScriptedAcceptance:
     LM on its own decodes degenerate loops.  The target buffer has a fixed address and length so the step stays one
     hipGraph across requests."""
 
-    def __init__(self, runner, vocab, target_len, ranked_logits=False):
+    def __init__(self, runner, vocab, target_len, ranked_logits=False, order1_hot_vocab=0):
         self.runner, self.vocab, self.target_len = runner, int(vocab), int(target_len)
         # ranked_logits: the verify rows also carry the source's plausible continuations below the scripted arg-max
-        # (samd_scripted_logits) -- for plugins that learn from the logits (Token Recycle's top-8 table)
+        # (samd_scripted_logits) -- for plugins that learn from the logits (Token Recycle's top-8 table).  order1_hot_vocab > 0: the
+        # source's next token depends on the last token alone (eight successors per token over [3, hot_vocab): bench._succ1)
         self.ranked_logits = bool(ranked_logits)
+        self.order1_hot_vocab = int(order1_hot_vocab)
         self.target = torch.zeros(self.target_len, dtype=torch.int32, device=runner.device)
         self.pf_mask = runner.pf_mask
         self._prompt_len = 0
@@ -145,7 +147,10 @@ class ScriptedAcceptance:
         b = self.runner.verify(session, R)
         session.scripted_argmax(self.target, self.target_len, self.vocab, b["argmax"])
         if self.ranked_logits:
-            session.scripted_logits(b["argmax"], b["logits"], self.vocab)
+            if self.order1_hot_vocab > 0:
+                session.scripted_logits(b["argmax"], b["logits"], self.order1_hot_vocab, order=1)
+            else:
+                session.scripted_logits(b["argmax"], b["logits"], self.vocab)
         return b
 
     def compact(self, session):
