@@ -280,24 +280,34 @@ __device__ __forceinline__ int dyn_find(const SessionDev &D, int state, int tok,
     return -1;
 }
 
-// states[state].next[tok] = dst for a new key, appended to the state's dict order
-__device__ __forceinline__ void dyn_insert(const SessionDev &D, int slot, int state, int tok, int dst) {
+// states[state].next[tok] = dst for a new key, appended to the state's dict order.  tail = D.tail[state] as the caller read it
+// (together with the probe that found `slot` free: one memory round trip instead of two)
+__device__ __forceinline__ void dyn_insert(const SessionDev &D, int slot, int state, int tok, int dst, int tail) {
     if (lane_id() == 0) {
         D.hkey[slot] = dyn_key(state, tok); D.hdst[slot] = dst; D.hnext[slot] = -1;
-        const int t = D.tail[state];
-        if (t < 0) D.head[state] = slot; else D.hnext[t] = slot;
+        if (tail < 0) D.head[state] = slot; else D.hnext[tail] = slot;
         D.tail[state] = slot;
     }
     wave_mem_sync();
 }
+__device__ __forceinline__ void dyn_insert(const SessionDev &D, int slot, int state, int tok, int dst) {
+    dyn_insert(D, slot, state, tok, dst, D.tail[state]);
+}
 
+// transfer_state (dyn_sam.py:78-87).  Everything whose address follows from the current state goes out with the probe of its edges:
+// its suffix link (where a failed probe continues), and -- one hop later, with the NEXT probe -- that state's length.  One memory round
+// trip per visited state where the plain form paid three (probe, link, length); the session's arena is L2-resident, ~0.6 us each.
 __device__ __forceinline__ void dyn_transfer(const SessionDev &D, int &idx, int &len, int tok) {
     int fs, e;
-    while (idx != 0 && (e = dyn_find(D, idx, tok, &fs)) < 0) {
-        idx = D.link[idx];
-        len = D.length[idx];
+    bool hopped = false;
+    for (;;) {
+        const int lk = idx != 0 ? D.link[idx] : -1;              // requested with the probe below
+        const int ln = hopped ? D.length[idx] : 0;
+        e = dyn_find(D, idx, tok, &fs);
+        if (hopped) len = ln;
+        if (e >= 0 || idx == 0) break;
+        idx = lk; hopped = true;
     }
-    e = dyn_find(D, idx, tok, &fs);
     if (e >= 0) { idx = D.hdst[e]; len += 1; } else { idx = 0; len = 0; }
 }
 
@@ -315,23 +325,27 @@ __device__ __forceinline__ void dyn_add_state(const SessionDev &D, DynRegs &R, i
     R.max_length += 1;
     const int cur = dyn_new_state(D, R, -1, R.max_length, R.max_length);
     wave_mem_sync();
-    int p = R.last, e = -1, fs = -1;
+    int p = R.last, e = -1, fs = -1, len_p = 0;
     while (p != -1) {
+        // the suffix link, the dict tail and the length of p are requested with the probe of its edges: one round trip per chain hop,
+        // not three
+        const int lk = D.link[p], tl = D.tail[p];
+        len_p = D.length[p];
         e = dyn_find(D, p, tok, &fs);
         if (e >= 0) break;
         if (fs < 0 || (uint32_t)(R.n_edges + 8) * 2 > D.hmask) { R.error = SAMD_E_CAPACITY; return; }
-        dyn_insert(D, fs, p, tok, cur); R.n_edges++;
-        p = D.link[p];
+        dyn_insert(D, fs, p, tok, cur, tl); R.n_edges++;
+        p = lk;
     }
     if (p == -1) {
         if (lane_id() == 0) D.link[cur] = 0;
     } else {
         const int q = D.hdst[e];
-        if (D.length[p] + 1 == D.length[q]) {
+        if (len_p + 1 == D.length[q]) {
             if (lane_id() == 0) D.link[cur] = q;
         } else {
             // clone = deepcopy(q): same dict (order kept), link, min_endpos; length = len(p)+1
-            const int clone = dyn_new_state(D, R, D.link[q], D.length[p] + 1, D.minend[q]);
+            const int clone = dyn_new_state(D, R, D.link[q], len_p + 1, D.minend[q]);
             wave_mem_sync();
             for (int qe = D.head[q]; qe >= 0; qe = D.hnext[qe]) {
                 const int t = (int)(uint32_t)D.hkey[qe];

@@ -157,7 +157,10 @@ class LlamaRunner:
         # packed_lm_head: a draft head shares the base model's lm_head, packed copy included
         layers = []
         for l in weights["layers"]:
-            lp = dict({k: pack(l[k]) for k in ("wqkv", "wo", "wdown")}, wgu=pack_gate_up(l["wgu"]), wqkv64=pack_qkv64(l["wqkv"]))
+            lp = dict({k: pack(l[k]) for k in ("wo", "wdown")}, wgu=pack_gate_up(l["wgu"]), wqkv64=pack_qkv64(l["wqkv"]))
+            # the 128-column packed q|k|v (split-K projection + samd_rope_kv_write_cs) only where the fused tile form does not exist:
+            # with it, no launch of this runner ever reads the other (3.2 GB of a 7B model)
+            lp["wqkv"] = pack(l["wqkv"]) if lp["wqkv64"] is None else None
             # the norm-fold forward (include/samd_hip.h: samd_gemm_cs_residual ...) needs the fused q|k|v and gate|up forms
             fold = (lp["wqkv64"] is not None and lp["wgu"] is not None and s.hidden <= 8192 and os.environ.get("SAMD_NORM_FOLD", "1") != "0")
             lp["wo_g"], lp["wdown_g"] = pack_groups(l["wo"], fold), pack_groups(l["wdown"], fold)
@@ -172,7 +175,41 @@ class LlamaRunner:
         self.norm_fold = (self.wp is not None and self.attention == "split"
                           and all(l.get("wo_g") is not None and l.get("wdown_g") is not None for l in self.wp["layers"]))
         self.scale = 1.0 / math.sqrt(s.head_dim)
+        self.row_major_released = False
         self._length_state(max_cache_len, kv)
+        if os.environ.get("SAMD_RELEASE_ROW_MAJOR", "0") == "1":
+            self.release_row_major()
+
+    def memory_report(self):
+        """bytes of HBM the weights take, by form (documented in DESIGN.md section 2): row-major originals (the wide prefill's library
+        GEMMs), and the packed forms the streaming kernels read"""
+        def nbytes(t):
+            return 0 if t is None or t.device.type == "meta" else t.numel() * t.element_size()
+        rep = dict(row_major=sum(nbytes(t) for l in self.w["layers"] for t in l.values()) + nbytes(self.w["lm_head"]) + nbytes(self.w["embed"]))
+        if self.wp:
+            for k in ("wqkv", "wqkv64", "wo", "wo_g", "wgu", "wdown", "wdown_g"):
+                rep["packed_" + k] = sum(nbytes(l.get(k)) for l in self.wp["layers"])
+            rep["packed_lm_head"] = nbytes(self.wp["lm_head"])
+        rep["total"] = sum(rep.values())
+        return rep
+
+    def release_row_major(self):
+        """drop the row-major projection matrices (13 GB of a 7B model): they serve only the wide prefill's library GEMMs, so the prompt
+        then goes through the streaming kernels in 64-row chunks (SAMD_PREFILL=chunked: ~5 ms per 64 tokens instead of ~9 ms per
+        512-token prompt).  Only when every projection has its packed forms and the tensors are the runner's own; shapes stay readable
+        (meta tensors).  SAMD_RELEASE_ROW_MAJOR=1 does this at construction."""
+        if self.row_major_released or not self.wp:
+            return self.row_major_released
+        need = ("wo", "wdown", "wgu")
+        if self.wp["lm_head"] is None or any(l.get(k) is None for l in self.wp["layers"] for k in need) or \
+                any(l.get("wqkv") is None and l.get("wqkv64") is None for l in self.wp["layers"]):
+            return False
+        for l in self.w["layers"]:
+            for k in ("wqkv", "wo", "wgu", "wdown"):
+                l[k] = torch.empty(l[k].shape, dtype=l[k].dtype, device="meta")
+        self.row_major_released = True                           # (lm_head stays: draft heads and the granular API read it)
+        torch.cuda.empty_cache()
+        return True
 
     def _length_state(self, max_cache_len, kv=None):
         """everything that depends on max_cache_len: KV storage, rotary tables, row buffers, prefill staging.  The weights
@@ -474,7 +511,7 @@ class LlamaRunner:
         N = ids.numel()
         if N < 1 or N > self.max_len:
             raise SamdError(f"prompt of {N} tokens does not fit max_cache_len {self.max_len}")
-        if N >= 2 * MAX_DRAFT and os.environ.get("SAMD_PREFILL", "wide") != "chunked":
+        if N >= 2 * MAX_DRAFT and os.environ.get("SAMD_PREFILL", "wide") != "chunked" and not self.row_major_released:
             return self._prefill_wide(session, ids, on_chunk)
         v = session.device_views()
         b = None

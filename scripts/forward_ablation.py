@@ -36,7 +36,7 @@ for R in (1, 8, 16, 32, 64):
 
     def gemms_only():
         for w, p in zip(runner.w["layers"], runner.wp["layers"] if runner.wp else runner.w["layers"]):
-            gemm(b["h"], w["wqkv"], b["qkv"], wp=p["wqkv"]); gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], b["o"], wp=p["wo"])
+            gemm(b["h"], w["wqkv"], b["qkv"], wp=p["wqkv"] if p.get("wqkv") is not None else p["wqkv64"]); gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], b["o"], wp=p["wo"])
             check(L.samd_gemm_pairs_silu(_ptr(b["h"]), _ptr(p["wgu"]), RP, s.inter, s.hidden, _ptr(b["act"]), dt, current_stream())); gemm(b["act"], w["wdown"], b["d"], wp=p["wdown"])
         gemm(b["h"], runner.w["lm_head"], b["logits"], True, wp=runner.wp["lm_head"] if runner.wp else None)
 

@@ -483,3 +483,32 @@ def test_attn_patch_dict_forward_is_a_drop_in_for_hf_attention(impl, bool_mask):
                  attention_mask=(mask4d(torch.float16) == 0) if bool_mask else mask4d(torch.float16), past_key_values=cache, use_cache=True,
                  cache_position=torch.arange(L, L + n, device="cuda")).logits[0]
     assert calls and (got.float() - want).abs().max().item() < TOL
+
+
+def test_release_row_major_keeps_the_forward(monkeypatch):
+    """LlamaRunner.release_row_major (SAMD_RELEASE_ROW_MAJOR=1): the row-major projection matrices go away (memory_report), the prompt
+    runs through the streaming kernels in 64-row chunks, and prefill + verify give what the same runner gave with SAMD_PREFILL=chunked
+    before the release -- bit for bit, the launches are the same."""
+    from samd_hip.llama import LlamaRunner
+    cfg = dict(hidden_size=1024, intermediate_size=2816, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=8, vocab_size=4096,
+               max_position_embeddings=1024, rms_norm_eps=1e-6)
+    monkeypatch.setenv("SAMD_PREFILL", "chunked")
+    runner = LlamaRunner.random_init(cfg, 1024, torch.float16, seed=2)
+    before = runner.memory_report()
+    prompt = torch.tensor([np.random.default_rng(8).integers(3, 4096, 300).tolist()], device="cuda")
+
+    def run():
+        sess = samd_hip.Session(1024)
+        last = runner.prefill(sess, prompt).float().clone()
+        n = 11
+        sess.set_draft(torch.arange(5, 5 + n, dtype=torch.int32, device="cuda"), torch.tensor([-1] + list(range(n - 1)), dtype=torch.int32, device="cuda"), n, type_=1)
+        b = runner.verify(sess, runner.bucket(n))
+        torch.cuda.synchronize()
+        return last, b["logits"][:n].float().clone()
+    a_last, a_tree = run()
+    assert runner.release_row_major() and runner.row_major_released
+    after = runner.memory_report()
+    assert after["row_major"] < 0.2 * before["row_major"] and after["total"] < before["total"]
+    monkeypatch.delenv("SAMD_PREFILL")
+    b_last, b_tree = run()
+    assert torch.equal(a_last, b_last) and torch.equal(a_tree, b_tree)
