@@ -166,13 +166,22 @@ class ScriptedAcceptance:
         return self.runner.hidden_rows(R)
 
 
-class _GraphChain:
-    """a decode step captured as several hipGraphs replayed back to back on one stream (DecodeEngine._capture)"""
+class _StopForward(Exception):
+    """raised by the engine's layer hook to end a forward after its first launches (the eager head of a step)"""
 
-    def __init__(self, n):
+
+class _GraphChain:
+    """a decode step captured as several hipGraphs replayed back to back on one stream (DecodeEngine._capture), optionally behind an
+    EAGER HEAD (SAMD_EAGER_HEAD_LAYERS, off by default: measured slower): the step's first launches (embedding, RoPE rows, the first
+    decoder layers) issued directly instead of through hipGraphLaunch, which hands the GPU its first packet only after ~25-30 us."""
+
+    def __init__(self, n, head=None):
         self.parts = [torch.cuda.CUDAGraph() for _ in range(n)]
+        self.head = head
 
     def replay(self):
+        if self.head is not None:
+            self.head()
         for g in self.parts:
             g.replay()
 
@@ -358,24 +367,48 @@ class DecodeEngine:
         runner = getattr(self.verifier, "runner", self.verifier)
         cuts = [int(x) for x in os.environ.get("SAMD_GRAPH_SPLIT_LAYER", "3").split(",") if x.strip()]
         n_layers = len(getattr(runner, "w", {}).get("layers", ())) if hasattr(runner, "layer_hook") else 0
-        cuts = sorted({c for c in cuts if 0 < c < n_layers})
-        if not cuts:
+        # SAMD_EAGER_HEAD_LAYERS (default 0 = everything in the graphs): embedding + RoPE rows + this many decoder layers launched
+        # directly at every step, the graphs hold the rest.  Measured and NOT adopted (round 4, scripts/host_turnaround.py): the GPU gets
+        # its first packet ~20 us earlier, but eight Python-issued launches arrive ~8 us apart and the short kernels among them (5 us)
+        # leave bubbles -- 3053 vs 3028 us of wall per step with one eager layer.
+        eager = int(os.environ.get("SAMD_EAGER_HEAD_LAYERS", "0"))
+        eager = eager if 0 < eager < n_layers else 0
+        cuts = sorted({c for c in cuts if eager < c < n_layers})
+        if not cuts and not eager:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._enqueue_step(R)
         else:
             # SEVERAL graphs per step: hipGraphLaunch builds every packet of a graph before the GPU sees the first (~100 us for the step's
-            # ~265 nodes, during which the GPU idles); a short head graph (embedding + the first layers) starts the GPU after ~10 us and
-            # the rest is enqueued while it runs (scripts/host_turnaround.py).  SAMD_GRAPH_SPLIT_LAYER = the layers to cut before.
-            g = _GraphChain(len(cuts) + 1)
+            # ~265 nodes, during which the GPU idles); a short head graph (the first layers) starts the GPU early and the rest is
+            # enqueued while it runs (scripts/host_turnaround.py).  SAMD_GRAPH_SPLIT_LAYER = the layers to cut before.
+            def head():
+                def stop(li):
+                    if li >= eager:
+                        raise _StopForward()
+                runner.layer_hook = stop
+                try:
+                    self.verifier.verify(self.session, R)
+                except _StopForward:
+                    pass
+                finally:
+                    runner.layer_hook = None
+            g = _GraphChain(len(cuts) + 1, head if eager else None)
             cur = torch.cuda.current_stream(self.device)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 part = [0]
-                g.parts[0].capture_begin()
+                started = [not eager]
+                if not eager:
+                    g.parts[0].capture_begin()
 
                 def hook(li):
+                    if not started[0]:
+                        if li == eager:                                      # the launches before this layer ran directly (harmless: they
+                            g.parts[0].capture_begin()                       # write rows past the committed cache length); capture from here
+                            started[0] = True
+                        return
                     if li in cuts and part[0] < len(g.parts) - 1:            # a second pass over the layers must not index past the parts
                         g.parts[part[0]].capture_end()
                         part[0] += 1
@@ -387,7 +420,8 @@ class DecodeEngine:
                     # never leave the stream in capture mode: end the open part (its graph is discarded with `g`) before re-raising
                     runner.layer_hook = None
                     try:
-                        g.parts[part[0]].capture_end()
+                        if started[0]:
+                            g.parts[part[0]].capture_end()
                     except Exception:
                         pass
                     cur.wait_stream(side)
