@@ -31,7 +31,12 @@ extern "C" {
 #define SAMD_E_IO (-4)        /* file could not be read / written / has a bad header */
 #define SAMD_E_NODEVICE (-5)  /* no gfx950 device visible */
 
-#define SAMD_MAX_DRAFT 64     /* a draft (sequence or tree) holds at most 64 nodes: one wavefront, one u64 mask row */
+/* A draft (sequence or tree) holds at most 64 nodes: one wavefront builds and verifies it, one u64 mask row per node, one 64-row GEMM
+ * tile.  The reference takes any max_predicts / n_predicts (samd_sam_only/sam/static_sam.py:183); its shipped configurations use 40-63.
+ * The C ABI refuses samd_params_t values above 64 (SAMD_E_INVALID); the Python packages above it cap larger requests at 64 with a
+ * RuntimeWarning (samd_sam_only/sam/_common.py): decoding stays lossless, only the accept lengths of very long matches differ.
+ * INTEGRATION.md section A. */
+#define SAMD_MAX_DRAFT 64
 #define SAMD_TOPK 8           /* SO/sam/static_sam.py:137 keeps 8 successors per state */
 
 /* per-step report block (int32 words) copied to the host by samd_session_report_async:

@@ -75,8 +75,13 @@ class SamdConfig:
 
     def __post_init__(self):
         from samd_hip import MAX_DRAFT
-        if not 1 <= self.n_predicts <= MAX_DRAFT:
-            raise ValueError(f"n_predicts must be in [1, {MAX_DRAFT}] (one wavefront verifies one draft)")
+        if self.n_predicts < 1:
+            raise ValueError("n_predicts must be >= 1")
+        if self.n_predicts > MAX_DRAFT:
+            # as samd_sam_only.SamdConfig: drafts are capped at MAX_DRAFT nodes (lossless)
+            import warnings
+            warnings.warn(f"n_predicts = {self.n_predicts}: drafts are capped at {MAX_DRAFT} nodes on this implementation "
+                          "(output tokens are unaffected)", RuntimeWarning, stacklevel=2)
         if self.tree is None:
             if self.tree_method == "token_recycle":
                 self.tree = load_token_recycle(self.tree_path)

@@ -11,8 +11,11 @@ def dev_i32(values, device="cuda"):
 
 
 def so_params(max_predicts=60, alpha=4.0, K=8, len_bias=0):
+    """device parameters of the SAM-only variant.  A draft holds at most samd_hip.MAX_DRAFT (64) nodes -- one wavefront, one 64-bit
+    mask row per node (include/samd_hip.h SAMD_MAX_DRAFT); larger max_predicts are served with 64-node drafts (decoding stays lossless,
+    only the accept lengths of very long matches differ from the reference's)."""
     p = samd_hip.Params()
-    p.variant, p.max_predicts, p.alpha, p.K, p.len_bias = 0, int(max_predicts), float(alpha), int(K), int(len_bias)
+    p.variant, p.max_predicts, p.alpha, p.K, p.len_bias = 0, min(int(max_predicts), samd_hip.MAX_DRAFT), float(alpha), int(K), int(len_bias)
     p.n_predicts, p.len_threshold, p.static_null = 0, 0, 0
     return p
 
@@ -20,7 +23,7 @@ def so_params(max_predicts=60, alpha=4.0, K=8, len_bias=0):
 def s_params(n_predicts=40, len_threshold=5, len_bias=5, static_null=False):
     p = samd_hip.Params()
     p.variant, p.max_predicts, p.alpha, p.K = 1, 0, 0.0, 0
-    p.len_bias, p.n_predicts, p.len_threshold, p.static_null = int(len_bias), int(n_predicts), int(len_threshold), int(static_null)
+    p.len_bias, p.n_predicts, p.len_threshold, p.static_null = int(len_bias), min(int(n_predicts), samd_hip.MAX_DRAFT), int(len_threshold), int(static_null)
     return p
 
 

@@ -20,8 +20,15 @@ class SamdConfig:
 
     def __post_init__(self):
         from samd_hip import MAX_DRAFT
-        if not 1 <= self.max_predicts <= MAX_DRAFT:
-            raise ValueError(f"max_predicts must be in [1, {MAX_DRAFT}] (one wavefront verifies one draft)")
+        if self.max_predicts < 1:
+            raise ValueError("max_predicts must be >= 1")
+        if self.max_predicts > MAX_DRAFT:
+            # the reference takes any value (samd_sam_only/sam/static_sam.py:183); here one wavefront builds and verifies one draft, so
+            # drafts are capped at MAX_DRAFT nodes.  Decoding is lossless either way -- the same tokens come out -- only the accept
+            # lengths of matches longer than (MAX_DRAFT - 1) / alpha tokens differ.  INTEGRATION.md section A states the limit.
+            import warnings
+            warnings.warn(f"max_predicts = {self.max_predicts}: drafts are capped at {MAX_DRAFT} nodes on this implementation "
+                          "(output tokens are unaffected)", RuntimeWarning, stacklevel=2)
 
 
 class ForwardType(str, Enum):
