@@ -286,7 +286,8 @@ def lm_roofline(runner, iters=10, rows=16):
     import torch
     import samd_hip
     from samd_hip import _ptr, check, current_stream
-    if runner.wp is None or not runner.fused_mlp or any(l[k] is None for l in runner.wp["layers"] for k in ("wqkv", "wo", "wgu", "wdown")):
+    if runner.wp is None or not runner.fused_mlp or any(l[k] is None for l in runner.wp["layers"] for k in ("wo", "wgu", "wdown")) \
+            or any(l.get("wqkv") is None and l.get("wqkv64") is None for l in runner.wp["layers"]):      # (q|k|v: 128-column tiles OR the fused tile form)
         return None
     L, s, b = samd_hip.lib(), runner.shape, runner._buffers(rows)
     RP, part, dt = b["rows_pad"], b["part"], runner.dt
