@@ -227,6 +227,15 @@ int samd_session_read_draft(samd_session_t *s, samd_draft_host_t *out, void *str
  * round trip.  reverse_leaves as in samd_tree_buffers. */
 int samd_session_set_draft_if_deferred(samd_session_t *s, const int32_t *d_tokens, const int32_t *d_parent, int32_t n,
                                        int32_t reverse_leaves, void *stream);
+/* PUSHED REPORT (round 4).  samd_session_report_target allocates (once) a host-coherent block of SAMD_REPORT_INTS + 1 int32 for the
+ * session and returns its host address; from then on samd_session_step's kernel writes the report block there itself when it is done --
+ * the words, then, behind a system-scope release, a sequence number at [SAMD_REPORT_INTS] that grows by one per step.
+ * samd_report_wait spins on that word until it differs from last_seq (SAMD_OK) or timeout_us has passed (SAMD_E_CAPACITY).  The host
+ * thereby learns the verdict without the D2H copy node and the stream synchronisation behind the cache compaction -- what the
+ * reference pays as .item() / .tolist() syncs (samd_sam_only/samd_model.py:158-174).  The block belongs to the session. */
+int samd_session_report_target(samd_session_t *s, int32_t **out_host);
+int samd_report_wait(const int32_t *h_report, int32_t last_seq, int64_t timeout_us);
+
 /* enqueue one D2H copy of the SAMD_REPORT_INTS-word report block into h_dst (pinned host memory for a
  * truly asynchronous copy); no synchronisation -- the caller waits on the stream / an event. */
 int samd_session_report_async(samd_session_t *s, int32_t *h_dst, void *stream);

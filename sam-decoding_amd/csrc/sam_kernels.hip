@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 #include "sam_device.h"
 
@@ -110,6 +111,7 @@ struct StepArgs {
     int c0, c1, c2, c3;         // OP_SET_CURSORS
     int have_static;
     int only_if_deferred;       // OP_SET_DRAFT: install only when the last lookup returned type 2
+    int push_report;            // after everything else: write the report block to the session's host-coherent target (SessionDev::h_report)
 };
 
 __device__ __forceinline__ void load_draft(const SessionDev &D, StepShared &sh, int &type, int &n, int &nl, int &md) {
@@ -240,6 +242,20 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         __syncthreads();
         int nl, mxd; build_buffers(sh, A.n, A.reverse, nl, mxd);
         store_draft(D, sh, A.type, A.n, nl, mxd, 0, 0, 0, 0, A.reverse);
+    }
+    if (A.push_report && D.h_report) {
+        // the report block as the host reads it, straight into host-coherent memory: the words first (system-scope stores), then -- behind
+        // a system-scope release -- the sequence number the host polls.  One wave, so the fence orders every lane's stores.
+        wave_mem_sync();
+        for (int k = lane; k < SAMD_REPORT_INTS; k += WAVE)
+            __hip_atomic_store(D.h_report + k, D.dmeta[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int seq = D.push_seq[0] + 1;
+            D.push_seq[0] = seq;
+            __hip_atomic_store(D.h_report + SAMD_REPORT_INTS, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -582,7 +598,7 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
                  o_head = carve(4ull * D.cap_states), o_tail = carve(4ull * D.cap_states), o_hk = carve(8ull * H),
                  o_hd = carve(4ull * H), o_hn = carve(4ull * H), o_text = carve(4ull * D.cap_text),
                  o_tok = carve(4 * 64), o_par = carve(4 * 64), o_pos = carve(4 * 64), o_mask = carve(8 * 64), o_ret = carve(4 * 64 * 64),
-                 o_rep = carve(4 * SAMD_REPORT_INTS), o_st = carve(4), o_cl = carve(4);
+                 o_rep = carve(4 * SAMD_REPORT_INTS), o_st = carve(4), o_cl = carve(4), o_seq = carve(4);
     s->arena_bytes = off;
     if (hipMalloc(&s->arena, off) != hipSuccess) { free(s); samd_set_error("hipMalloc(session arena) failed"); return SAMD_E_HIP; }
     char *base = (char *)s->arena;
@@ -595,6 +611,7 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
     D.dmeta = rep + SAMD_REP_DMETA; D.verdict = rep + SAMD_REP_VERDICT; D.acc_tokens = rep + SAMD_REP_TOKENS;
     D.kv_index = rep + SAMD_REP_KVINDEX; D.counters = rep + SAMD_REP_COUNTERS; D.meta = rep + SAMD_REP_META;
     D.start_token = (int32_t *)(base + o_st); D.cache_length = (int32_t *)(base + o_cl);
+    D.push_seq = (int32_t *)(base + o_seq); D.h_report = nullptr;
     if (hipMemset(s->arena, 0, off) != hipSuccess) { (void)hipFree(s->arena); free(s); return SAMD_E_HIP; }
     *out = s;
     int rc = samd_session_reset(s, nullptr);
@@ -606,7 +623,37 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
 void samd_session_free(samd_session_t *s) {
     if (!s) return;
     if (s->arena) (void)hipFree(s->arena);
+    if (s->h_report_host) (void)hipHostFree(s->h_report_host);
     free(s);
+}
+
+int samd_session_report_target(samd_session_t *s, int32_t **out_host) {
+    if (!s || !out_host) return SAMD_E_INVALID;
+    if (!s->h_report_host) {
+        void *h = nullptr, *d = nullptr;
+        const size_t bytes = 4 * (SAMD_REPORT_INTS + 16);
+        if (hipHostMalloc(&h, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { samd_set_error("hipHostMalloc(report target) failed"); return SAMD_E_HIP; }
+        memset(h, 0, bytes);
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); samd_set_error("hipHostGetDevicePointer(report target) failed"); return SAMD_E_HIP; }
+        s->h_report_host = (int32_t *)h;
+        s->dev.h_report = (int32_t *)d;
+    }
+    *out_host = s->h_report_host;
+    return SAMD_OK;
+}
+
+int samd_report_wait(const int32_t *h_report, int32_t last_seq, int64_t timeout_us) {
+    if (!h_report) return SAMD_E_INVALID;
+    const volatile int32_t *seq = h_report + SAMD_REPORT_INTS;
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spin = 0;; spin++) {
+        if (*seq != last_seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return SAMD_OK; }
+        __builtin_ia32_pause();
+        if ((spin & 1023u) == 1023u) {
+            timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+            if ((t.tv_sec - t0.tv_sec) * 1000000ll + (t.tv_nsec - t0.tv_nsec) / 1000 > timeout_us) return SAMD_E_CAPACITY;
+        }
+    }
 }
 
 static int launch_session(samd_session_t *s, const samd_static_t *sam, const samd_params_t *p, StepArgs &A, void *stream) {
@@ -720,6 +767,7 @@ int samd_session_step(samd_session_t *s, const samd_static_t *sam, const samd_pa
     if (!p || !d_node_argmax || !s) return SAMD_E_INVALID;
     StepArgs A; memset(&A, 0, sizeof(A)); A.ops = OP_ACCEPT | OP_COMMIT | OP_DRAFT; A.node_argmax = d_node_argmax;
     A.start_token = s->dev.start_token;
+    A.push_report = 1;                                    // (no-op without samd_session_report_target)
     return launch_session(s, sam, p, A, stream);
 }
 

@@ -120,6 +120,11 @@ struct SessionDev {
     int32_t *counters;
     uint32_t hmask;
     int32_t cap_states, cap_text, max_tokens;
+    // PUSHED REPORT (round 4; null until samd_session_report_target): a host-coherent block of SAMD_REPORT_INTS + 1 words the step kernel
+    // writes itself when it is done -- the report, then a sequence number behind a system-scope release -- so that the host learns the
+    // verdict the moment the kernel has it, without a D2H copy node and a stream synchronisation behind the cache compaction
+    int32_t *h_report;
+    int32_t *push_seq;          // device word: pushes so far (the sequence number survives graph replays)
 };
 
 struct samd_session {
@@ -127,6 +132,7 @@ struct samd_session {
     void *arena;
     size_t arena_bytes;
     int32_t max_tokens;
+    int32_t *h_report_host;     // host address of dev.h_report (hipHostMalloc, coherent + mapped); owned by the session
 };
 
 // host image + device image of a static automaton

@@ -105,6 +105,8 @@ _PROTOS = {
     "samd_gemm_qkv_rope_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
     "samd_gemm_pairs_silu_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_cs_residual": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
+    "samd_session_report_target": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "samd_report_wait": (C.c_int, [_VP, _I32, _I64]),
     "samd_scripted_logits": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),
     "samd_scripted_logits_order1": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),
     "samd_session_device_views": (C.c_int, [_VP, _VP]),
@@ -432,6 +434,14 @@ class Session:
 
     def set_start_token(self, d_src):
         check(lib().samd_session_set_start_token(self._h, _ptr(d_src), current_stream()))
+
+    def report_target(self):
+        """the session's PUSHED-report block (include/samd_hip.h): int32[REPORT_INTS + 1] in host-coherent memory that the step kernel
+        writes itself; [REPORT_INTS] is the sequence number.  -> (numpy view, address for samd_report_wait)"""
+        out = _VP()
+        check(lib().samd_session_report_target(self._h, C.byref(out)))
+        arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_int32)), shape=(REPORT_INTS + 1,))
+        return arr, out
 
     def report_async(self, h_pinned):
         """enqueue the D2H copy of the per-step report block into a pinned int32[REPORT_INTS] tensor."""

@@ -203,6 +203,13 @@ class DecodeEngine:
         self.bucket_steps = {}               # row bucket -> decode steps run on it (bench.py: bucket_histogram)
         self._views = session.device_views()
         self._n_ptr = self._views["dmeta"] + 4
+        # PUSHED REPORT (round 4, include/samd_hip.h): the step kernel writes the report into host-coherent memory itself and the host
+        # polls its sequence number -- no D2H copy node, no stream synchronisation behind the cache compaction; the next step's graphs
+        # are launched while the compaction still runs.  The plain SAM-only engine only: plugins change the draft after the step kernel
+        # (Token Recycle's install) or read the report at their own pace.  SAMD_REPORT_PUSH=0: the copy + synchronise of rounds 1-3.
+        self._push = None
+        if recycle is None and type(self) is DecodeEngine and os.environ.get("SAMD_REPORT_PUSH", "1") != "0":
+            self._push = session.report_target()
 
     # ---- pieces ---------------------------------------------------------------------------------------
     def _recycle_update(self, d_tokens, logits, n_rows, d_n):
@@ -222,7 +229,8 @@ class DecodeEngine:
         if self.recycle is not None:
             self._install_tree()
         self.verifier.compact(self.session)
-        self.session.report_async(self.report_buf)
+        if self._push is None:
+            self.session.report_async(self.report_buf)
 
     def _ingest_beside(self, ids, prefill):
         """DraftModel.update(prompt) -- dyn add_tokens + static transfer_tokens (SO/draft.py:62-67; 2.8 us per token, one wavefront) --
@@ -266,6 +274,12 @@ class DecodeEngine:
         """one decode step on the current draft of n_next nodes; returns the report after it."""
         R = self.verifier.bucket(n_next)
         self.bucket_steps[R] = self.bucket_steps.get(R, 0) + 1
+        push = self._push
+        if push is not None:
+            g = self._graphs.get(R) if self.use_graphs else None
+            if self.use_graphs and g is None:
+                g = self._capture(R)                      # (capture first: it must not sit between reading the sequence number and the launch)
+            last = int(push[0][REPORT_INTS])
         if not self.use_graphs:
             self._enqueue_step(R)
         else:
@@ -273,6 +287,14 @@ class DecodeEngine:
             if g is None:
                 g = self._capture(R)
             g.replay()
+        if push is not None:
+            from . import lib
+            if lib().samd_report_wait(push[1], last, 5_000_000) != 0:
+                torch.cuda.current_stream().synchronize()            # surfaces a device fault; a healthy step has pushed by now
+                if int(push[0][REPORT_INTS]) == last:
+                    raise SamdError("the step kernel did not push its report")
+            self._report_np[:] = push[0][:REPORT_INTS]
+            return StepReport(self._report_np)
         torch.cuda.current_stream().synchronize()
         return StepReport(self._report_np)
 

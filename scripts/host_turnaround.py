@@ -2,6 +2,8 @@
 g.replay() (hipGraphLaunch), the stream synchronisation (= the step on the GPU + wake-up) and the Python between the wake-up and the next
 replay (report parsing, truncation, bookkeeping, the generator hop).  The GPU idles for the Python part plus the launch latency."""
 import os, sys, time
+os.environ["SAMD_REPORT_PUSH"] = "0"      # this script times the copy + synchronise form of a step (it replaces DecodeEngine.step by its own);
+                                          # the pushed report of round 4 is measured by bench.py A/B (SAMD_REPORT_PUSH=0|1)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "sam-decoding_amd")]
 import numpy as np
