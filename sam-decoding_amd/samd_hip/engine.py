@@ -387,7 +387,7 @@ class DecodeEngine:
         self._warm(R)
         torch.cuda.current_stream().synchronize()
         runner = getattr(self.verifier, "runner", self.verifier)
-        cuts = [int(x) for x in os.environ.get("SAMD_GRAPH_SPLIT_LAYER", "3").split(",") if x.strip()]
+        cuts = [int(x) for x in os.environ.get("SAMD_GRAPH_SPLIT_LAYER", "2").split(",") if x.strip()]
         n_layers = len(getattr(runner, "w", {}).get("layers", ())) if hasattr(runner, "layer_hook") else 0
         # SAMD_EAGER_HEAD_LAYERS (default 0 = everything in the graphs): embedding + RoPE rows + this many decoder layers launched
         # directly at every step, the graphs hold the rest.  Measured and NOT adopted (round 4, scripts/host_turnaround.py): the GPU gets
