@@ -227,6 +227,18 @@ int samd_session_read_draft(samd_session_t *s, samd_draft_host_t *out, void *str
  * round trip.  reverse_leaves as in samd_tree_buffers. */
 int samd_session_set_draft_if_deferred(samd_session_t *s, const int32_t *d_tokens, const int32_t *d_parent, int32_t n,
                                        int32_t reverse_leaves, void *stream);
+/* SEAM EXPERIMENT HOOKS (round 4; scripts/seam_probe.py, profiles/r04_attention.md section 5 -- not used by the product path).
+ * samd_tree_attention_signal = samd_tree_attention whose merge launch adds 1 to *d_arrive per (row, head) workgroup once its output is
+ * visible device-wide; samd_gemm_cs_residual_early = samd_gemm_cs_residual for o_proj (K = 4096, <= 8 rows) that requests its weights at
+ * entry and polls d_counter until (its own epoch + 1) * arrivals producers have arrived before it reads A -- so that it can be launched
+ * on a second stream BESIDE attention.  d_epoch int32[N / 16], zero-initialised. */
+int samd_tree_attention_signal(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
+                               int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
+                               const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
+                               int32_t *d_arrive, void *stream);
+int samd_gemm_cs_residual_early(const void *d_A, const void *d_Wg, int32_t N, int32_t K, void *d_x, float *d_ssq, int32_t dtype, const int32_t *d_counter,
+                                int32_t *d_epoch, int32_t arrivals, void *stream);
+
 /* PUSHED REPORT (round 4).  samd_session_report_target allocates (once) a host-coherent block of SAMD_REPORT_INTS + 1 int32 for the
  * session and returns its host address; from then on samd_session_step's kernel writes the report block there itself when it is done --
  * the words, then, behind a system-scope release, a sequence number at [SAMD_REPORT_INTS] that grows by one per step.

@@ -656,9 +656,14 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
 // Roundings are the reference's: the projection's output in the model dtype, then the residual sum in the model dtype
 // (LlamaDecoderLayer: hidden_states = residual + hidden_states), squares of the stored values (LlamaRMSNorm: x.float().pow(2)).
 // ================================================================================================
-template <typename TT, int ROWS>
+// EARLY (seam experiment, scripts/seam_probe.py / profiles/r04_attention.md section 5; K = 4096 only: two chunks per wave): the launch runs
+// on a second queue BESIDE the attention launches that produce A.  Every wave requests ALL of its weights at entry, then the workgroup
+// polls `counter` -- the producers' arrival count -- until this workgroup's own epoch says A is complete, and only then requests A.
+template <typename TT, int ROWS, bool EARLY = false>
 __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
-                                                                           typename TT::elem *__restrict__ x, float *__restrict__ ssq, int K, int N, int n_chunks) {
+                                                                           typename TT::elem *__restrict__ x, float *__restrict__ ssq, int K, int N, int n_chunks,
+                                                                           const int *__restrict__ counter = nullptr, int *__restrict__ epoch = nullptr,
+                                                                           int arrivals = 0) {
     typedef typename TT::elem E;
     typedef typename TT::vec8 V8;
     constexpr int CSD = 2;                                     // chunks in flight per wave
@@ -683,13 +688,15 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const t
     }
     floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
     u32x4 wr[CSD][4][2];
-    auto issue = [&](u32x4 (&dst)[4][2], int c, int buf) {
+    auto issue_w = [&](u32x4 (&dst)[4][2], int c) {
         const char *p = wgrp + (size_t)c * 8192;
 #pragma unroll
         for (int b = 0; b < 4; b++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
                 asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 1024 * (2 * b + j)) : "memory");
+    };
+    auto issue_a = [&](int c, int buf) {
 #pragma unroll
         for (int i = 0; i < AL; i++) {                         // the wave's own A chunk: 32 units of 16 B per row, unit u of row r at position u ^ (r & 15)
             const int slot = l + 64 * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
@@ -699,8 +706,11 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const t
             asm volatile("" ::: "memory");
         }
     };
+    auto issue = [&](u32x4 (&dst)[4][2], int c, int buf) { issue_w(dst, c); issue_a(c, buf); };
     auto phase = [&](u32x4 (&cur)[4][2], int c, int buf, bool more) {
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + AL) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // EARLY: both chunks' weights are older than any A load, so what may still fly while chunk 0 is consumed is chunk 1's A only
+        if (more) { if constexpr (EARLY) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(AL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + AL) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t xbase = lds_base + (uint32_t)buf * (16 * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -713,14 +723,36 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, 2) void k_gemm_cs_residual(const t
     };
     // chunks of this wave: w, w + 8, ...; two in flight, the LDS buffer of a chunk is refilled only after its reads (lgkmcnt(0) above)
     const int mine = (n_chunks - w + GEMM_WAVES - 1) / GEMM_WAVES;
-    if (mine > 0) issue(wr[0], w, 0);
-    if (mine > 1) issue(wr[1], w + GEMM_WAVES, 1);
-    for (int i = 0; i < mine; i += 2) {
-        phase(wr[0], w + GEMM_WAVES * i, 0, i + 1 < mine);
-        if (i + 2 < mine) issue(wr[0], w + GEMM_WAVES * (i + 2), 0);
-        if (i + 1 < mine) {
-            phase(wr[1], w + GEMM_WAVES * (i + 1), 1, i + 2 < mine);
-            if (i + 3 < mine) issue(wr[1], w + GEMM_WAVES * (i + 3), 1);
+    if constexpr (EARLY) {
+        if (mine > 0) issue_w(wr[0], w);
+        if (mine > 1) issue_w(wr[1], w + GEMM_WAVES);
+        __shared__ int my_epoch;
+        if (tid == 0) {
+            const int e = epoch[blockIdx.x];
+            const int target = (e + 1) * arrivals;
+            for (int spin = 0; spin < (1 << 22); spin++) {                 // bounded: a lost producer ends in wrong sums, not in a hung GPU
+                if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            my_epoch = e;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (mine > 0) issue_a(w, 0);
+        if (mine > 1) issue_a(w + GEMM_WAVES, 1);
+        if (mine > 0) phase(wr[0], w, 0, mine > 1);
+        if (mine > 1) phase(wr[1], w + GEMM_WAVES, 1, false);
+        if (tid == 0) epoch[blockIdx.x] = my_epoch + 1;
+    } else {
+        if (mine > 0) issue(wr[0], w, 0);
+        if (mine > 1) issue(wr[1], w + GEMM_WAVES, 1);
+        for (int i = 0; i < mine; i += 2) {
+            phase(wr[0], w + GEMM_WAVES * i, 0, i + 1 < mine);
+            if (i + 2 < mine) issue(wr[0], w + GEMM_WAVES * (i + 2), 0);
+            if (i + 1 < mine) {
+                phase(wr[1], w + GEMM_WAVES * (i + 1), 1, i + 2 < mine);
+                if (i + 3 < mine) issue(wr[1], w + GEMM_WAVES * (i + 3), 1);
+            }
         }
     }
     // ---- the eight k shares meet in LDS (the A buffers are dead), summed in wave order; residual, rounding, row sums of squares -----------
@@ -907,11 +939,39 @@ int samd_gemm_cs_residual(const void *d_A, const void *d_Wg, int32_t rows_pad, i
     hipError_t e = hipSuccess;
 #define GO(TT, ROWS, ET) do { static unsigned long long done = 0ull; \
         e = samd_reserve_lds((const void *)k_gemm_cs_residual<TT, ROWS>, lds, &done); \
-        if (e == hipSuccess) hipLaunchKernelGGL((k_gemm_cs_residual<TT, ROWS>), dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const ET *)d_A, (const ET *)d_Wg, (ET *)d_x, d_ssq, K, N, K / GEMM_KC); } while (0)
+        if (e == hipSuccess) hipLaunchKernelGGL((k_gemm_cs_residual<TT, ROWS>), dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const ET *)d_A, (const ET *)d_Wg, (ET *)d_x, d_ssq, K, N, K / GEMM_KC, (const int *)nullptr, (int *)nullptr, 0); } while (0)
     if (dtype == SAMD_F16) { if (rows_pad == 8) GO(GF16, 8, _Float16); else GO(GF16, 16, _Float16); }
     else { if (rows_pad == 8) GO(GBF16, 8, __bf16); else GO(GBF16, 16, __bf16); }
 #undef GO
     if (e != hipSuccess) { samd_set_error("samd_gemm_cs_residual: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+/* seam experiment hook (scripts/seam_probe.py): samd_gemm_cs_residual for o_proj (K = 4096, <= 8 rows) launched on a SECOND stream beside the
+ * attention launches; it requests its weights at entry and polls d_counter (samd_tree_attention_signal's arrivals) before it touches A.
+ * d_epoch int32[N / 16], zero-initialised, owned by the caller; arrivals = n_q_pad * n_heads of the producing merge launch. */
+int samd_gemm_cs_residual_early(const void *d_A, const void *d_Wg, int32_t N, int32_t K, void *d_x, float *d_ssq, int32_t dtype, const int32_t *d_counter,
+                                int32_t *d_epoch, int32_t arrivals, void *stream) {
+    if (!d_A || !d_Wg || !d_x || !d_ssq || !d_counter || !d_epoch || arrivals < 1 || N < 16 || N % 16 != 0 || K != 2 * GEMM_WAVES * GEMM_KC ||
+        (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_cs_residual_early: unsupported shape (K must be 4096, N %% 16 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+    }
+    constexpr int lds = GEMM_WAVES * 2 * 16 * GEMM_KC * 2;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    if (dtype == SAMD_F16) {
+        static unsigned long long done = 0ull;
+        e = samd_reserve_lds((const void *)k_gemm_cs_residual<GF16, 8, true>, lds, &done);
+        if (e == hipSuccess) hipLaunchKernelGGL((k_gemm_cs_residual<GF16, 8, true>), dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const _Float16 *)d_A, (const _Float16 *)d_Wg,
+                                                (_Float16 *)d_x, d_ssq, K, N, K / GEMM_KC, d_counter, d_epoch, arrivals);
+    } else {
+        static unsigned long long done = 0ull;
+        e = samd_reserve_lds((const void *)k_gemm_cs_residual<GBF16, 8, true>, lds, &done);
+        if (e == hipSuccess) hipLaunchKernelGGL((k_gemm_cs_residual<GBF16, 8, true>), dim3(N / 16), dim3(64 * GEMM_WAVES), lds, st, (const __bf16 *)d_A, (const __bf16 *)d_Wg,
+                                                (__bf16 *)d_x, d_ssq, K, N, K / GEMM_KC, d_counter, d_epoch, arrivals);
+    }
+    if (e != hipSuccess) { samd_set_error("samd_gemm_cs_residual_early: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 
 template <typename E>
 __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
-                                                      const int *__restrict__ d_L, const int *__restrict__ d_n, WarmArgs warm) {
+                                                      const int *__restrict__ d_L, const int *__restrict__ d_n, WarmArgs warm, int *__restrict__ arrive) {
     const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
     if (h >= n_heads) {                      // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
         const unsigned a = warm_next_projection(warm, (h - n_heads) * n_q_pad + row);
@@ -333,21 +333,33 @@ __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ 
     }
     int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
     E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d;
-    if (row >= n) { *dst = (E)0.f; return; }
-    // the splits k_tree_attention actually ran: split s owns the key tiles s, s + ATT_SPLITS, ...
-    const int ntiles = (d_L[0] + n + ATT_TILE - 1) / ATT_TILE;
-    const int used = ntiles < ATT_SPLITS ? ntiles : ATT_SPLITS;
-    float M = -INFINITY;
+    float res = 0.f;
+    if (row < n) {
+        // the splits k_tree_attention actually ran: split s owns the key tiles s, s + ATT_SPLITS, ...
+        const int ntiles = (d_L[0] + n + ATT_TILE - 1) / ATT_TILE;
+        const int used = ntiles < ATT_SPLITS ? ntiles : ATT_SPLITS;
+        float M = -INFINITY;
 #pragma unroll
-    for (int s = 0; s < ATT_SPLITS; s++) if (s < used) M = fmaxf(M, mv[s]);
-    float num = 0.f, den = 0.f;
+        for (int s = 0; s < ATT_SPLITS; s++) if (s < used) M = fmaxf(M, mv[s]);
+        float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int s = 0; s < ATT_SPLITS; s++) {
-        if (s >= used || mv[s] == -INFINITY) continue;
-        const float wgt = exp2f(mv[s] - M);
-        num += wgt * pv[s]; den += wgt * lv[s];
+        for (int s = 0; s < ATT_SPLITS; s++) {
+            if (s >= used || mv[s] == -INFINITY) continue;
+            const float wgt = exp2f(mv[s] - M);
+            num += wgt * pv[s]; den += wgt * lv[s];
+        }
+        res = den > 0.f ? num / den : 0.f;
     }
-    *dst = (E)(den > 0.f ? num / den : 0.f);
+    *dst = (E)res;
+    if (arrive) {
+        // seam experiment (scripts/seam_probe.py, profiles/r04_attention.md section 5): a consumer on another queue polls this counter
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ================================================================================================
@@ -1015,10 +1027,10 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                                     scale, d_workspace, workspace_bytes, nullptr, stream);
 }
 
-int samd_tree_attention_warm(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
-                             int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
-                             const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
-                             const samd_warm_t *next, void *stream) {
+static int tree_attention_impl(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
+                               int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
+                               const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
+                               const samd_warm_t *next, int *d_arrive, void *stream) {
     // the output projection's warm-up rides on the split launch (the longest glue launch of a layer) or on the merge launch
     const WarmArgs none = warm_args(nullptr);
     const WarmArgs wa_split = next && next->where == 0 ? warm_args(next) : none, wa = next && next->where != 0 ? warm_args(next) : none;
@@ -1037,15 +1049,32 @@ int samd_tree_attention_warm(const void *d_q, const void *d_k_cache, const void 
         hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
                            (const _Float16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
-        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa);
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     } else {
         hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
                            (const __bf16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
-        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa);
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     }
     LAUNCHCHK();
     return SAMD_OK;
+}
+
+int samd_tree_attention_warm(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
+                             int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
+                             const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
+                             const samd_warm_t *next, void *stream) {
+    return tree_attention_impl(d_q, d_k_cache, d_v_cache, d_out, dtype, n_q_pad, n_heads, n_kv_heads, head_dim, max_len, d_mask, d_cache_length, d_n, scale,
+                               d_workspace, workspace_bytes, next, nullptr, stream);
+}
+
+int samd_tree_attention_signal(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
+                               int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
+                               const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
+                               int32_t *d_arrive, void *stream) {
+    if (!d_arrive) return SAMD_E_INVALID;
+    return tree_attention_impl(d_q, d_k_cache, d_v_cache, d_out, dtype, n_q_pad, n_heads, n_kv_heads, head_dim, max_len, d_mask, d_cache_length, d_n, scale,
+                               d_workspace, workspace_bytes, nullptr, d_arrive, stream);
 }
 
 int64_t samd_tree_attention_rope_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim) {

@@ -105,6 +105,8 @@ _PROTOS = {
     "samd_gemm_qkv_rope_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
     "samd_gemm_pairs_silu_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_cs_residual": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
+    "samd_gemm_cs_residual_early": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _VP]),
+    "samd_tree_attention_signal": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32, _VP, _I64, _VP, _VP]),
     "samd_session_report_target": (C.c_int, [_VP, C.POINTER(_VP)]),
     "samd_report_wait": (C.c_int, [_VP, _I32, _I64]),
     "samd_scripted_logits": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I64, _I32, _VP]),

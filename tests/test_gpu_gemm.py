@@ -287,3 +287,47 @@ def test_norm_fold_kernels(dtype, H, K, inter):
     torch.cuda.synchronize()
     assert torch.equal(x8[:8], x1[:8]) and torch.equal(x8[8:], x0[8:])
     assert torch.equal(ssq8[:, :8], ssq2[:, :8]) and bool((ssq8[:, 8:] == -1.0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_seam_experiment_hooks_match_the_serial_launches(dtype):
+    """the two experiment entry points of profiles/r04_attention.md section 2b: samd_tree_attention_signal (the merge launch arrives on a
+    device counter) and samd_gemm_cs_residual_early (o_proj that requests its weights at entry and polls that counter before it reads A)
+    must give bit for bit what samd_tree_attention + samd_gemm_cs_residual give.  Run here in stream order (the producer first), twice, so
+    that the epoch bookkeeping is exercised without two queues."""
+    import math
+    from samd_hip import _ptr, check, current_stream, lib, torch_dtype_code
+    H, D, max_len, R, hidden, L0 = 32, 128, 512, 8, 4096, 200
+    dt = torch_dtype_code(dtype)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    kv = torch.randn((2, H, max_len, D), generator=g, device="cuda").to(dtype)
+    q = torch.randn((16, H, D), generator=g, device="cuda").to(dtype)
+    w_raw = (torch.randn((hidden, hidden), generator=g, device="cuda") * 0.02).to(dtype)
+    wg = torch.empty_like(w_raw)
+    check(lib().samd_gemm_pack_groups(_ptr(w_raw), _ptr(wg), hidden, hidden, current_stream()))
+    mask = torch.tensor([(1 << (i + 1)) - 1 if i < 63 else -1 for i in range(64)], dtype=torch.int64, device="cuda")
+    d_L = torch.tensor([L0], dtype=torch.int32, device="cuda"); d_n = torch.tensor([R - 1], dtype=torch.int32, device="cuda")
+    ws = torch.zeros(lib().samd_tree_attention_workspace(R, H, D), dtype=torch.uint8, device="cuda")
+    scale = 1.0 / math.sqrt(D)
+    outs = []
+    for early in (False, True):
+        attn = torch.zeros((16, H, D), device="cuda", dtype=dtype)
+        x = torch.zeros((16, hidden), device="cuda", dtype=dtype)
+        ssq = torch.zeros((hidden // 16, 16), device="cuda", dtype=torch.float32)
+        counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+        epoch = torch.zeros(hidden // 16, dtype=torch.int32, device="cuda")
+        for rep in range(2):
+            if early:
+                check(lib().samd_tree_attention_signal(_ptr(q), _ptr(kv[0]), _ptr(kv[1]), _ptr(attn), dt, R, H, H, D, max_len, _ptr(mask), _ptr(d_L), _ptr(d_n),
+                                                       scale, _ptr(ws), ws.numel(), _ptr(counter), current_stream()))
+                check(lib().samd_gemm_cs_residual_early(_ptr(attn), _ptr(wg), hidden, hidden, _ptr(x), _ptr(ssq), dt, _ptr(counter), _ptr(epoch), R * H,
+                                                        current_stream()))
+            else:
+                check(lib().samd_tree_attention(_ptr(q), _ptr(kv[0]), _ptr(kv[1]), _ptr(attn), dt, R, H, H, D, max_len, _ptr(mask), _ptr(d_L), _ptr(d_n),
+                                                scale, _ptr(ws), ws.numel(), current_stream()))
+                check(lib().samd_gemm_cs_residual(_ptr(attn), _ptr(wg), 8, hidden, hidden, _ptr(x), _ptr(ssq), dt, current_stream()))
+        torch.cuda.synchronize()
+        if early:
+            assert int(counter.item()) == 2 * R * H and epoch.tolist() == [2] * (hidden // 16)
+        outs.append((attn.clone(), x.clone(), ssq.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
