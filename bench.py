@@ -150,6 +150,52 @@ def synth_request_order1(rng, docs, vocab=VOCAB, prompt_len=512, total_len=2048,
     return out[:prompt_len], out
 
 
+def plant_order1_head(head, runner, dtype, hot=TR_HOT_VOCAB, alpha=4.0, beta=4.0, cold=10.0, shift=6.0):
+    """--variant eagle2 / eagle without EAGLE weights on the box: a draft head whose next-token distribution is exactly the order-1 request
+    source's (successor c of token b with probability TR_RANK_P[c]) -- what a trained head approximates for its LM -- so that the variant's
+    accept length measures the METHOD on that source instead of pricing a path fed by noise.  Construction (the one of the planted
+    parity fixture, tests/eagle_fixture_weights.py): hot token t gets the embedding ALPHA * q_t (signed Hadamard rows / sqrt(hidden):
+    orthonormal), fc passes the embedding through and adds BETA * u, the head's own layer is zero (its residual stream IS fc's output; the
+    kernels still stream every weight byte), and the shared lm_head row of a successor v of t carries ((log p + shift + COLD) / ALPHA) q_t
+    - (COLD / BETA) u: logit log p + shift in t's row, -COLD everywhere else.  The base model's own logits are not used by the scripted
+    acceptance, so its lm_head can hold the plant (the packed copy is rebuilt in place)."""
+    import math
+    import torch
+    import samd_hip
+    from samd_hip import _ptr, check, current_stream
+    dev, Hd, V = runner.device, head.hidden, runner.shape.vocab
+    assert hot - 3 < Hd and Hd & (Hd - 1) == 0, "needs hot - 3 < hidden = a power of two"
+    i = torch.arange(Hd, device=dev, dtype=torch.int32)
+    x = i[:, None] & i[None, :]
+    for sh in (16, 8, 4, 2, 1):
+        x ^= x >> sh
+    Hm = (1 - 2 * (x & 1)).to(torch.float32) / math.sqrt(Hd)
+    u, q = Hm[0], Hm[1:hot - 2]                                         # q[t - 3] for hot token t
+    g = torch.Generator(device=dev).manual_seed(11)
+    emb = torch.randn((V, Hd), generator=g, device=dev) * 0.02
+    emb[3:hot] = alpha * q
+    W = torch.randn((V, Hd), generator=g, device=dev) * 0.004 - (cold / beta) * u[None, :]
+    t = torch.arange(3, hot, device=dev, dtype=torch.int64)
+    for c, p in enumerate(TR_RANK_P):
+        h = (t * 10007 + c * 7919 + 12345) & 0x7FFFFFFF
+        h = (h * 2654435761) & 0xFFFFFFFF
+        v = 3 + h % (hot - 3)                                            # bench._succ1(t, c)
+        W.index_add_(0, v, ((math.log(p) + shift + cold) / alpha) * q)
+    with torch.no_grad():
+        head.embed_tokens.data.copy_(emb.to(dtype))
+        for name in ("q", "k", "v", "o", "gate", "up", "down"):
+            getattr(head, name).data.zero_()
+        head.post_ln.data.fill_(1.0)
+        head.fc_w.data.zero_()
+        head.fc_w.data[:, :Hd] = torch.eye(Hd, device=dev, dtype=dtype)
+        if head.fc_b is not None:
+            head.fc_b.data.copy_((beta * u).to(dtype))
+        runner.w["lm_head"].copy_(W.to(dtype))
+    if runner.wp and runner.wp.get("lm_head") is not None:
+        check(samd_hip.lib().samd_gemm_pack_weights(_ptr(runner.w["lm_head"]), _ptr(runner.wp["lm_head"]), V, Hd, current_stream()))
+    torch.cuda.synchronize()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def hip_time_ms(fn, iters):
     """average duration of fn() in ms, HIP events on the stream fn launches on (torch's current stream)."""
@@ -547,6 +593,9 @@ def main():
     ap.add_argument("--model", choices=["vicuna-7b", "llama3-8b"], default="vicuna-7b",
                     help="vicuna-7b fp16 = the headline configuration; llama3-8b bf16 = the shape of BASELINE configs[3] (informational; "
                          "the synthetic corpus keeps the 32000-token vocabulary)")
+    ap.add_argument("--eagle-head", choices=["planted", "random"], default="planted",
+                    help="--variant eagle2 / eagle: 'planted' = a draft head whose distribution IS the order-1 request source's (plant_order1_head: "
+                         "the variant's accept length is then a measurement on that source); 'random' = random-init head, the run prices the path (cost_only)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (the result is then not a benchmark)")
     ap.add_argument("--walk-streams", type=int, default=1 << 20)
     ap.add_argument("--walk-tokens", type=int, default=16)
@@ -609,6 +658,8 @@ def main():
     runner = LlamaRunner.random_init(mcfg, max_len, dtype, seed=0)
     # Token Recycle learns from the top-8 of every verified row: its scripted model also ranks the source's continuations
     tr = args.variant == "token_recycle"
+    planted = args.variant in ("eagle2", "eagle") and args.eagle_head == "planted" and args.acceptance == "scripted"
+    order1 = tr or planted                                        # the variants whose requests come from the order-1 source
     lm = (ScriptedAcceptance(runner, VOCAB, max_len, ranked_logits=tr, order1_hot_vocab=TR_HOT_VOCAB if tr else 0)
           if args.acceptance == "scripted" else runner)
 
@@ -632,6 +683,8 @@ def main():
             samd_cfg = S.SamdConfig(n_predicts=40, len_threshold=5, len_bias=5, tree_method=args.variant, tree_config=tree_cfg)
             head = (Eagle2Head if args.variant == "eagle2" else EagleHead)(tree_cfg, dtype=dtype, device="cuda")
             head.random_init(seed=3, std=0.02)
+            if planted:
+                plant_order1_head(head, runner, dtype)
             if args.variant == "eagle":
                 head.set_tree(StaticDraftTree(samd_cfg.tree))
             tree_model = (Eagle2 if args.variant == "eagle2" else Eagle)(samd_cfg, runner, dtype, "cuda", head=head)
@@ -645,7 +698,7 @@ def main():
 
     def requests():
         while True:
-            prompt, target = synth_request_order1(rng, docs) if tr else synth_request(rng, docs)
+            prompt, target = synth_request_order1(rng, docs) if order1 else synth_request(rng, docs)
             if args.acceptance == "scripted":
                 lm.set_target(target)
             yield prompt, target
@@ -817,7 +870,7 @@ def main():
             # `value` and `speedup_vs_ar` of such a run price the plugin PATH (head forwards + 63-node verify), they are not a result of
             # the method.  What the path would deliver at the accepted-token counts the reference publishes (README.md:55-57) follows
             # from this run's measured step time: speed-up = MAT x T_AR / T_step.
-            "cost_only": args.variant in ("eagle2", "eagle"),
+            "cost_only": args.variant in ("eagle2", "eagle") and not planted,
             # samd[token_recycle] (round 4): this variant's requests come from synth_request_order1 -- text whose next token depends
             # mostly on the last token, over a hot vocabulary, ranked by the scripted model's verify rows (samd_scripted_logits_order1) --
             # so the token-keyed [V, 8] table learns what the reference's learns on natural text (token_recycle.py:40-48) and the tree
@@ -825,7 +878,8 @@ def main():
             # (Rounds 1-3 ran it on the headline's order-2 source, where a token-keyed table accepts ~1.06.)
             "tree_steps_priced_not_predictive": False,
             "variant_source": ("order-1 source over %d hot ids, rank probabilities %s, mixed with corpus copies / repeats / noise (bench.synth_request_order1)"
-                               % (TR_HOT_VOCAB, list(TR_RANK_P))) if tr else None,
+                               % (TR_HOT_VOCAB, list(TR_RANK_P))) + ("; draft head planted with exactly that distribution (plant_order1_head)" if planted else "")
+                              if order1 else None,
             "projected_speedup_of_this_variant": variant_projection(args.variant, ar_tps, dt_max / args.steps * 1e3),
             "long_run": long_run, "timed_tokens": int(tokens_total), "session_kernel_phases": session_phases,
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
