@@ -517,6 +517,11 @@ int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total,
  * Roundings are LlamaDecoderLayer's / LlamaRMSNorm's; 1 / rms may differ from samd_rmsnorm's in the last bit (another summation order).
  * Call sites replaced: SO/samd_model.py:134-138 (input_layernorm, post_attention_layernorm and the two residual adds of every
  * LlamaDecoderLayer inside the verify forward). */
+/* samd_embed_rows_ssq + samd_rope_rows (head_dim 128) as ONE launch: the two open every norm-fold forward and do not depend on each
+ * other (round 4; arguments as of the two) */
+int samd_embed_rows_ssq_rope(const int32_t *d_tokens, const void *d_table, void *d_out, float *d_ssq, int32_t rows, int32_t hidden, int32_t vocab,
+                             int32_t dtype, const int32_t *d_rel_pos, const int32_t *d_base, const float *d_cos, const float *d_sin, float *d_cs,
+                             int32_t rope_rows, int32_t head_dim, int32_t max_pos, void *stream);
 int samd_embed_rows_ssq(const int32_t *d_tokens, const void *d_table, void *d_out, float *d_ssq, int32_t rows, int32_t hidden, int32_t vocab,
                         int32_t dtype, void *stream);
 int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,

@@ -92,6 +92,37 @@ __global__ __launch_bounds__(256) void k_embed_rows_ssq(const int *__restrict__ 
     }
 }
 
+// k_embed_rows_ssq and k_rope_rows in ONE launch: the two open every norm-fold forward, neither depends on the other, and each alone is a
+// launch at the latency floor (~5 us).  Blocks [0, rows): the embedding rows; the blocks behind them: cos | sin of the rope rows.
+template <typename T>
+__global__ __launch_bounds__(256) void k_embed_rows_ssq_rope(const int *__restrict__ tokens, const T *__restrict__ table, T *__restrict__ out,
+                                                             float *__restrict__ ssq, int rows, int hidden, int vocab, const int *__restrict__ rel_pos,
+                                                             const int *__restrict__ d_base, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                                                             float *__restrict__ cs, int rope_rows, int max_pos) {
+    if ((int)blockIdx.x >= rows) {
+        const int i = ((int)blockIdx.x - rows) * blockDim.x + threadIdx.x, r = i >> 6, j = i & 63;
+        if (r >= rope_rows) return;
+        int pos = d_base[0] + rel_pos[r];
+        pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+        cs[r * 128 + j] = cos_t[(size_t)pos * 64 + j];
+        cs[r * 128 + 64 + j] = sin_t[(size_t)pos * 64 + j];
+        return;
+    }
+    const int r = blockIdx.x;
+    int t = tokens[r]; t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+    const T *src = table + (size_t)t * hidden;
+    T *dst = out + (size_t)r * hidden;
+    for (int tile = threadIdx.x; tile < hidden / 16; tile += blockDim.x) {
+        const Vec8<T> a = ld8(src + 16 * tile), b = ld8(src + 16 * tile + 8);
+        st8(dst + 16 * tile, a); st8(dst + 16 * tile + 8, b);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const float fa = (float)a.v[j], fb = (float)b.v[j]; q += fa * fa; q += fb * fb; }
+        ssq[(size_t)tile * 16 + r] = q;
+    }
+}
+
+
 // HF LlamaRMSNorm: out = w * (x * rsqrt(mean(x^2) + eps)).to(dtype); optional fused residual add:
 // x <- x + delta first (stored back), as LlamaDecoderLayer does between its two halves.
 template <typename T, bool ADD>
@@ -228,6 +259,24 @@ int samd_embed_rows(const int32_t *d_tokens, const void *d_table, void *d_out, i
     if (dtype == SAMD_F16) hipLaunchKernelGGL(k_embed_rows<_Float16>, dim3(rows), dim3(256), 0, st, d_tokens, (const _Float16 *)d_table, (_Float16 *)d_out, hidden, vocab);
     else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_embed_rows<__bf16>, dim3(rows), dim3(256), 0, st, d_tokens, (const __bf16 *)d_table, (__bf16 *)d_out, hidden, vocab);
     else { samd_set_error("samd_embed_rows: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+int samd_embed_rows_ssq_rope(const int32_t *d_tokens, const void *d_table, void *d_out, float *d_ssq, int32_t rows, int32_t hidden, int32_t vocab,
+                             int32_t dtype, const int32_t *d_rel_pos, const int32_t *d_base, const float *d_cos, const float *d_sin, float *d_cs,
+                             int32_t rope_rows, int32_t head_dim, int32_t max_pos, void *stream) {
+    if (!d_tokens || !d_table || !d_out || !d_ssq || !d_rel_pos || !d_base || !d_cos || !d_sin || !d_cs || rows < 1 || rows > 16 || hidden % 16 != 0 ||
+        rope_rows < 1 || rope_rows > SAMD_MAX_DRAFT || head_dim != 128 || max_pos < 1) {
+        samd_set_error("samd_embed_rows_ssq_rope: invalid argument (<= 16 embedding rows, hidden %% 16 == 0, <= 64 rope rows, head_dim 128)"); return SAMD_E_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(rows + (rope_rows * 64 + 255) / 256);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL(k_embed_rows_ssq_rope<_Float16>, grid, dim3(256), 0, st, d_tokens, (const _Float16 *)d_table, (_Float16 *)d_out, d_ssq, rows, hidden, vocab,
+                                              d_rel_pos, d_base, d_cos, d_sin, d_cs, rope_rows, max_pos);
+    else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_embed_rows_ssq_rope<__bf16>, grid, dim3(256), 0, st, d_tokens, (const __bf16 *)d_table, (__bf16 *)d_out, d_ssq, rows, hidden, vocab,
+                                                    d_rel_pos, d_base, d_cos, d_sin, d_cs, rope_rows, max_pos);
+    else { samd_set_error("samd_embed_rows_ssq_rope: dtype must be f16/bf16"); return SAMD_E_INVALID; }
     LAUNCHCHK();
     return SAMD_OK;
 }

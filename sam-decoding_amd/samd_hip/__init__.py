@@ -102,6 +102,7 @@ _PROTOS = {
     "samd_session_set_start_token": (C.c_int, [_VP, _VP, _VP]),
     "samd_scripted_argmax": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP]),
     "samd_embed_rows_ssq": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "samd_embed_rows_ssq_rope": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_gemm_qkv_rope_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
     "samd_gemm_pairs_silu_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_cs_residual": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),

@@ -477,8 +477,13 @@ class LlamaRunner:
         L, s, dt, st = lib(), self.shape, self.dt, current_stream()
         x, ssq = b["x"], b["ssq"]
         rows_cs = 8 if R <= 8 else 16            # the complete-sum projections fetch only the rows a <= 8-node draft has
-        check(L.samd_embed_rows_ssq(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(x), _ptr(ssq), 16, s.hidden, s.vocab, dt, st))
-        check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R, s.head_dim, self.rope_rows, st))
+        if s.head_dim == 128 and os.environ.get("SAMD_FUSE_EMBED_ROPE", "1") != "0":
+            # embedding rows + their sums of squares and the rows' cos | sin: one launch (neither depends on the other)
+            check(L.samd_embed_rows_ssq_rope(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(x), _ptr(ssq), 16, s.hidden, s.vocab, dt, _ptr(d_relpos), _ptr(d_L),
+                                             _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R, s.head_dim, self.rope_rows, st))
+        else:
+            check(L.samd_embed_rows_ssq(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(x), _ptr(ssq), 16, s.hidden, s.vocab, dt, st))
+            check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R, s.head_dim, self.rope_rows, st))
         attn2d = b["attn"].view(b["attn"].shape[0], -1)
         for li, (w, wp) in enumerate(zip(self.w["layers"], self.wp["layers"])):
             if self.layer_hook is not None:
