@@ -275,17 +275,16 @@ class DecodeEngine:
         R = self.verifier.bucket(n_next)
         self.bucket_steps[R] = self.bucket_steps.get(R, 0) + 1
         push = self._push
-        if push is not None:
-            g = self._graphs.get(R) if self.use_graphs else None
-            if self.use_graphs and g is None:
-                g = self._capture(R)                      # (capture first: it must not sit between reading the sequence number and the launch)
-            last = int(push[0][REPORT_INTS])
-        if not self.use_graphs:
-            self._enqueue_step(R)
-        else:
+        g = None
+        if self.use_graphs:
             g = self._graphs.get(R)
             if g is None:
-                g = self._capture(R)
+                g = self._capture(R)                      # (before the sequence number is read: a capture warms the bucket with real launches)
+        if push is not None:
+            last = int(push[0][REPORT_INTS])
+        if g is None:
+            self._enqueue_step(R)
+        else:
             g.replay()
         if push is not None:
             from . import lib

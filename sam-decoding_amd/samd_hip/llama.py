@@ -200,6 +200,8 @@ class LlamaRunner:
         (meta tensors).  SAMD_RELEASE_ROW_MAJOR=1 does this at construction."""
         if self.row_major_released or not self.wp:
             return self.row_major_released
+        if self.native_gemm_max_rows < self.BUCKETS[-1]:
+            return False                                   # (a row bucket would fall back to the library GEMM, which reads the row-major matrices)
         need = ("wo", "wdown", "wgu")
         if self.wp["lm_head"] is None or any(l.get(k) is None for l in self.wp["layers"] for k in need) or \
                 any(l.get("wqkv") is None and l.get("wqkv64") is None for l in self.wp["layers"]):
