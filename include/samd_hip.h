@@ -510,6 +510,8 @@ int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total,
  *   samd_gemm_qkv_rope_norm  samd_gemm_qkv_rope reading the RESIDUAL STREAM d_x [16][K]: 1 / rms per row from d_ssq (added up in a fixed
  *                            order by every workgroup), h = (x / rms).to(dtype), a = norm_weight * h on the way into LDS;
  *   samd_gemm_pairs_silu_norm  samd_gemm_pairs_silu in the same way (post_attention_layernorm + gate | up + SiLU * up);
+ *                            both: rows_pad 16, or 8 (round 4): only rows 0..7 of d_x are fetched -- a draft of <= 8 nodes; rows 0..7 of the
+ *                            results are bit-identical, rows 8..15 are those of a zero input;
  *   samd_gemm_cs_residual    x[m][n] <- (x[m][n] + dtype((A W^T)[m][n])).to(dtype) for o_proj / down_proj with COMPLETE sums (one workgroup per 16
  *                            output columns and all of K; d_Wg = the [N][K] matrix packed by samd_gemm_pack_groups), and the new
  *                            d_ssq [N / 16][16] of the updated rows.  rows_pad 16, or 8: only rows 0..7 of d_A are read and only rows 0..7 of

@@ -271,6 +271,20 @@ __device__ __forceinline__ u32x4 norm_scale8(u32x4 xraw, u32x4 graw, float rs) {
     return out;
 }
 
+
+// counted wait of the weight stream: memory operations retire in issue order, so chunk c has landed when at most `younger` x PC
+// operations (PC = this wave's memory operations per chunk) may still fly
+template <int DEPTH, int PC>
+__device__ __forceinline__ void gemm_wait_younger(int younger) {
+    if constexpr (PC == 0) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    else {
+        if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * PC) : "memory");
+        else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * PC) : "memory");
+        else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(PC) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    }
+}
+
 // ================================================================================================
 // q|k|v projection with RoPE and the K/V row write as its epilogue (round 3): the k_rope_kv launch and the fp32 split-K partials of the
 // q|k|v projection disappear (Vicuna-7B: 5 us and 1.5 MB written + read back per layer).  An epilogue needs COMPLETE sums, so no split-K
@@ -284,7 +298,9 @@ __device__ __forceinline__ u32x4 norm_scale8(u32x4 xraw, u32x4 graw, float rs) {
 // The stream itself is k_gemm_skinny's: LDS-DMA'd A chunks shared by all waves, hand-issued nt weight loads with DEPTH chunks in flight
 // (32 KiB chunks: DEPTH 4 = the same 128 KiB per workgroup), counted waits, bare barriers.
 // ================================================================================================
-template <typename TT, int RT, int DEPTH, int CG, bool NORM>
+// AR (NORM only; round 4): activation rows a workgroup fetches -- 16, or 8 for a draft of <= 8 nodes: waves 0-3 stage rows 0-7, waves 4-7
+// stage nothing (rows 8-15 of the LDS tiles are zeroed once), a sixth less of what the CU's memory pipe ingests beside the weights
+template <typename TT, int RT, int DEPTH, int CG, bool NORM, int AR = 16>
 __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES / 2) void k_gemm_qkv_rope(
         const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W, int K, int n_chunks,
         const float *__restrict__ cs, const int *__restrict__ d_L, const int *__restrict__ d_n,
@@ -305,6 +321,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES /
     // waves 0 .. 2 CG - 1 stream and multiply (column group cg, k half kh); with 48-column tiles waves 6, 7 only help staging A
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, n = l & 15, g = l >> 4;
     const bool streams = CG == 4 || w < 2 * CG;
+    static_assert(AR == 16 || (AR == 8 && NORM && RT == 1), "8 activation rows: the norm-fold kernels only");
+    const bool stager = AR == 16 || w < GEMM_WAVES / 2;                          // wave-uniform: rows 0..7 belong to threads 0..255
     const int cg = CG == 4 ? (w & 3) : (streams ? w % CG : 0), kh = CG == 4 ? (w >> 2) : (streams ? w / CG : 0);
     const char *wtile = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * CH;
     const uint32_t wlane = (uint32_t)(64 * (CG * kh + cg) + l) * 16;
@@ -343,11 +361,14 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES /
     };
     auto issue = [&](u32x4 (&dst)[2][2], int c, int buf, int d) {
         if (streams) { load_wb(dst, c, 0); load_wb(dst, c, 1); }
+        if (stager) {
 #pragma unroll
-        for (int i = 0; i < XV; i++) stage_xi(c, buf, i, d);
+            for (int i = 0; i < XV; i++) stage_xi(c, buf, i, d);
+        }
     };
     auto scale_to_lds = [&](int buf, int d) {      // NORM: this thread's units of the landed chunk -> LDS, scaled (same positions as the DMA's)
         if constexpr (NORM) {
+            if (!stager) return;
 #pragma unroll
             for (int i = 0; i < XV; i++) {
                 const int slot = tid + NT * i, row = slot >> 5;
@@ -357,17 +378,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES /
         }
     };
     auto landed = [&](int younger, int buf, int d) {   // memory ops retire in issue order: chunk c has landed when only the younger ones may still fly
-        if (streams) {
-            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (WL + XL)) : "memory");
-            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (WL + XL)) : "memory");
-            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(WL + XL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        } else {                                   // a staging-only wave has XL operations per chunk in flight
-            if (DEPTH > 3 && younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XL) : "memory");
-            else if (DEPTH > 2 && younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XL) : "memory");
-            else if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-        }
+        if (streams) { if (stager) gemm_wait_younger<DEPTH, WL + XL>(younger); else gemm_wait_younger<DEPTH, WL>(younger); }
+        else { if (stager) gemm_wait_younger<DEPTH, XL>(younger); else gemm_wait_younger<DEPTH, 0>(younger); }   // (a staging-only / an idle wave)
         if constexpr (NORM) { scale_to_lds(buf, d); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -409,10 +421,16 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES /
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
         if (d < n_chunks) issue(wr[d], d, d, d);
+    if constexpr (AR == 8) {                        // rows 8..15 of every A buffer: zero, once (the waves that stage nothing write them)
+        if (!stager) {
+#pragma unroll
+            for (int bz = 0; bz < NB; bz++) *reinterpret_cast<u32x4 *>(&xs[bz][0][0] + (size_t)tid * 8) = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
     if constexpr (NORM) {                           // the partial sums were requested before the chunks: they have landed when only the chunks' operations fly
         if (n_chunks >= DEPTH) {
-            if (streams) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * (WL + XL)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * XL) : "memory");
+            if (streams) { if (stager) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * (WL + XL)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * WL) : "memory"); }
+            else { if (stager) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * XL) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
         } else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         norm_finish<NT>(na, norm_sv, norm_part, norm_rs);
     }
@@ -497,7 +515,7 @@ static int qkv_tile_groups(int n_heads_total) {
 //   its rows interleaved in groups of 16 (group 2p = gate rows 16p.., group 2p + 1 = up rows 16p..) -- samd_gemm_pack_groups.
 // Stream, A staging and waits are k_gemm_skinny's (two chunks in flight, counted vmcnt, bare barriers).
 // ================================================================================================
-template <typename TT, int RT, int DEPTH, bool NORM>
+template <typename TT, int RT, int DEPTH, bool NORM, int AR = 16>          // AR: see k_gemm_qkv_rope
 __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WAVES / 2) void k_gemm_pairs_silu(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                                                                      typename TT::elem *__restrict__ out, int K, int inter, int n_chunks, int n_pairs, NormArgs na) {
     typedef typename TT::elem E;
@@ -513,6 +531,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     // this workgroup's pairs [p0, p1): an even deal of n_pairs over the grid
     const int p0 = (int)((long long)blockIdx.x * n_pairs / gridDim.x), p1 = (int)((long long)(blockIdx.x + 1) * n_pairs / gridDim.x);
     const bool active = w < 2 * (p1 - p0);                                       // wave-uniform
+    static_assert(AR == 16 || (AR == 8 && NORM && RT == 1), "8 activation rows: the norm-fold kernels only");
+    const bool stager = AR == 16 || w < GEMM_WAVES / 2;                          // wave-uniform: rows 0..7 belong to threads 0..255
     const int gi = 2 * p0 + w;                                                    // this wave's column group
     const char *wgrp = reinterpret_cast<const char *>(W) + (size_t)(active ? gi : 0) * n_chunks * 8192;
     const uint32_t wlane = (uint32_t)l * 16;
@@ -536,6 +556,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     u32x4 xr[NORM ? DEPTH : 1][NORM ? XV : 1], gr[NORM ? DEPTH : 1][NORM ? XV : 1];
     __shared__ float norm_part[NORM ? (NT / 16) * 16 : 1], norm_rs[NORM ? 16 : 1];
     auto stage_x = [&](int c, int buf, int d) {
+        if (!stager) return;
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
@@ -551,18 +572,18 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
             }
         }
     };
-    // a wave without a column group issues no weight loads, so its counted waits leave only its A pieces out
+    // a wave without a column group issues no weight loads, one that stages no rows no A loads: its counted waits leave those out
     auto landed = [&](int younger, int buf, int d) {
-        if (DEPTH > 3 && younger >= 3) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (8 + XL)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * XL) : "memory"); }
-        else if (DEPTH > 2 && younger >= 2) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * (8 + XL)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * XL) : "memory"); }
-        else if (younger >= 1) { if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + XL) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XL) : "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        if (active) { if (stager) gemm_wait_younger<DEPTH, 8 + XL>(younger); else gemm_wait_younger<DEPTH, 8>(younger); }
+        else { if (stager) gemm_wait_younger<DEPTH, XL>(younger); else gemm_wait_younger<DEPTH, 0>(younger); }
         if constexpr (NORM) {
+            if (stager) {
 #pragma unroll
-            for (int i = 0; i < XV; i++) {
-                const int slot = tid + NT * i, row = slot >> 5;
-                const u32x4 v = norm_scale8<E>(xr[d][i], gr[d][i], norm_rs[row]);
-                *reinterpret_cast<u32x4 *>(&xs[buf][0][0] + (size_t)slot * 8) = v;
+                for (int i = 0; i < XV; i++) {
+                    const int slot = tid + NT * i, row = slot >> 5;
+                    const u32x4 v = norm_scale8<E>(xr[d][i], gr[d][i], norm_rs[row]);
+                    *reinterpret_cast<u32x4 *>(&xs[buf][0][0] + (size_t)slot * 8) = v;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -606,10 +627,16 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
         if (d < n_chunks) { if (active) load_w(wr[d], d); stage_x(d, d, d); }
+    if constexpr (AR == 8) {                        // rows 8..15 of every A buffer: zero, once
+        if (!stager) {
+#pragma unroll
+            for (int bz = 0; bz < NB; bz++) *reinterpret_cast<u32x4 *>(&xs[bz][0][0] + (size_t)tid * 8) = (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
     if constexpr (NORM) {                           // the partial sums were requested before the chunks (see k_gemm_qkv_rope)
         if (n_chunks >= DEPTH) {
-            if (active) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * (8 + XL)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * XL) : "memory");
+            if (active) { if (stager) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * (8 + XL)) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * 8) : "memory"); }
+            else { if (stager) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(DEPTH * XL) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
         } else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         norm_finish<NT>(na, norm_sv, norm_part, norm_rs);
     }
@@ -827,30 +854,30 @@ static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t 
 #undef GO
 }
 
-template <typename TT, int RT, int DEPTH, int CG, bool NORM = false>
+template <typename TT, int RT, int DEPTH, int CG, bool NORM = false, int AR = 16>
 static hipError_t qkv_rope_launch(hipStream_t st, const void *A, const void *W, int K, int tiles, const float *cs, const int *d_L, const int *d_n, void *q, void *k, void *v,
                                   int H, int Hkv, long long max_len, NormArgs na = NormArgs{nullptr, nullptr, 0, 0.f, 0.f}) {
     constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 2 * 16 * RT * 16 * CG * 4, lds = lds_a > lds_e ? lds_a : lds_e;
     if constexpr (lds > 60000) {
         static unsigned long long done = 0ull;
-        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_qkv_rope<TT, RT, DEPTH, CG, NORM>, lds + 4096, &done);
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_qkv_rope<TT, RT, DEPTH, CG, NORM, AR>, lds + 4096, &done);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH, CG, NORM>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
+    hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH, CG, NORM, AR>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
                        cs, d_L, d_n, (typename TT::elem *)q, (typename TT::elem *)k, (typename TT::elem *)v, H, Hkv, max_len, na);
     return hipSuccess;
 }
 
-template <typename TT, int RT, int DEPTH, bool NORM = false>
+template <typename TT, int RT, int DEPTH, bool NORM = false, int AR = 16>
 static hipError_t pairs_silu_launch(hipStream_t st, int grid, const void *A, const void *W, void *out, int K, int inter, int n_pairs,
                                     NormArgs na = NormArgs{nullptr, nullptr, 0, 0.f, 0.f}) {
     constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 4 * 16 * RT * 16 * 4, lds = lds_a > lds_e ? lds_a : lds_e;
     if constexpr (lds > 60000) {
         static unsigned long long done = 0ull;
-        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_pairs_silu<TT, RT, DEPTH, NORM>, lds + 4096, &done);
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_pairs_silu<TT, RT, DEPTH, NORM, AR>, lds + 4096, &done);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((k_gemm_pairs_silu<TT, RT, DEPTH, NORM>), dim3(grid), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W,
+    hipLaunchKernelGGL((k_gemm_pairs_silu<TT, RT, DEPTH, NORM, AR>), dim3(grid), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W,
                        (typename TT::elem *)out, K, inter, K / GEMM_KC, n_pairs, na);
     return hipSuccess;
 }
@@ -913,9 +940,9 @@ int samd_gemm_pack_groups(const void *d_W, void *d_packed, int32_t N, int32_t K,
 
 int samd_gemm_pairs_silu_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_Wg, int32_t rows_pad, int32_t inter, int32_t K,
                               void *d_out, int32_t dtype, void *stream) {
-    if (!d_x || !d_ssq || !d_norm_weight || !d_Wg || !d_out || rows_pad != 16 || inter < 16 || inter % 16 != 0 || K < GEMM_KC || K % GEMM_KC != 0 ||
+    if (!d_x || !d_ssq || !d_norm_weight || !d_Wg || !d_out || (rows_pad != 16 && rows_pad != 8) || inter < 16 || inter % 16 != 0 || K < GEMM_KC || K % GEMM_KC != 0 ||
         K / 16 > 32 * NORM_NS || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
-        samd_set_error("samd_gemm_pairs_silu_norm: unsupported shape (16 rows, inter %% 16 == 0, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+        samd_set_error("samd_gemm_pairs_silu_norm: unsupported shape (8 or 16 rows, inter %% 16 == 0, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
     }
     const int n_cu = samd_cu_count();
     const int n_pairs = inter / 16;
@@ -923,8 +950,12 @@ int samd_gemm_pairs_silu_norm(const void *d_x, const float *d_ssq, const void *d
     while ((n_pairs + grid - 1) / grid > 4) grid += n_cu;
     const NormArgs na{d_ssq, d_norm_weight, K / 16, 1.f / (float)K, eps};
     hipStream_t st = (hipStream_t)stream;
-    const hipError_t e = dtype == SAMD_F16 ? pairs_silu_launch<GF16, 1, 3, true>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na)
-                                           : pairs_silu_launch<GBF16, 1, 3, true>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na);
+    // rows_pad 8: a draft of <= 8 nodes -- only rows 0..7 of x are fetched (the tile stays 16 rows; outputs of rows 8..15 are zero)
+    const hipError_t e = rows_pad == 8
+        ? (dtype == SAMD_F16 ? pairs_silu_launch<GF16, 1, 3, true, 8>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na)
+                             : pairs_silu_launch<GBF16, 1, 3, true, 8>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na))
+        : (dtype == SAMD_F16 ? pairs_silu_launch<GF16, 1, 3, true>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na)
+                             : pairs_silu_launch<GBF16, 1, 3, true>(st, grid, d_x, d_Wg, d_out, K, inter, n_pairs, na));
     if (e != hipSuccess) { samd_set_error("samd_gemm_pairs_silu_norm: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
@@ -1043,17 +1074,23 @@ int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_n
                             const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache,
                             int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream) {
     if (!d_x || !d_ssq || !d_norm_weight || !d_W64 || !d_cs || !d_cache_length || !d_n || !d_q_out || !d_k_cache || !d_v_cache || head_dim != 128 || n_heads < 1 ||
-        n_kv_heads < 1 || rows_pad != 16 || K < GEMM_KC || K % GEMM_KC != 0 || K / 16 > 32 * NORM_NS || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
-        samd_set_error("samd_gemm_qkv_rope_norm: unsupported shape (16 rows, head_dim 128, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
+        n_kv_heads < 1 || (rows_pad != 16 && rows_pad != 8) || K < GEMM_KC || K % GEMM_KC != 0 || K / 16 > 32 * NORM_NS || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_qkv_rope_norm: unsupported shape (8 or 16 rows, head_dim 128, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
     }
     const int groups = qkv_tile_groups(n_heads + 2 * n_kv_heads);
     const int tiles = (n_heads + 2 * n_kv_heads) * 128 / (16 * groups);
     const NormArgs na{d_ssq, d_norm_weight, K / 16, 1.f / (float)K, eps};
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-#define GO(TT, CG) e = qkv_rope_launch<TT, 1, 4, CG, true>(st, d_x, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len, na)
-    if (groups == 3) { if (dtype == SAMD_F16) GO(GF16, 3); else GO(GBF16, 3); }
-    else { if (dtype == SAMD_F16) GO(GF16, 4); else GO(GBF16, 4); }
+#define GO(TT, CG, AR) e = qkv_rope_launch<TT, 1, 4, CG, true, AR>(st, d_x, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len, na)
+    // rows_pad 8: a draft of <= 8 nodes -- only rows 0..7 of x are fetched (the tile stays 16 rows)
+    if (rows_pad == 8) {
+        if (groups == 3) { if (dtype == SAMD_F16) GO(GF16, 3, 8); else GO(GBF16, 3, 8); }
+        else { if (dtype == SAMD_F16) GO(GF16, 4, 8); else GO(GBF16, 4, 8); }
+    } else {
+        if (groups == 3) { if (dtype == SAMD_F16) GO(GF16, 3, 16); else GO(GBF16, 3, 16); }
+        else { if (dtype == SAMD_F16) GO(GF16, 4, 16); else GO(GBF16, 4, 16); }
+    }
 #undef GO
     if (e != hipSuccess) { samd_set_error("samd_gemm_qkv_rope_norm: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();

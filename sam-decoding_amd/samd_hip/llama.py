@@ -479,6 +479,7 @@ class LlamaRunner:
         L, s, dt, st = lib(), self.shape, self.dt, current_stream()
         x, ssq = b["x"], b["ssq"]
         rows_cs = 8 if R <= 8 else 16            # the complete-sum projections fetch only the rows a <= 8-node draft has
+        rows_a = rows_cs if os.environ.get("SAMD_NORM_ROWS8", "1") != "0" else 16      # ... and so do the norm-applying ones (round 4)
         if s.head_dim == 128 and os.environ.get("SAMD_FUSE_EMBED_ROPE", "1") != "0":
             # embedding rows + their sums of squares and the rows' cos | sin: one launch (neither depends on the other)
             check(L.samd_embed_rows_ssq_rope(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(x), _ptr(ssq), 16, s.hidden, s.vocab, dt, _ptr(d_relpos), _ptr(d_L),
@@ -490,13 +491,13 @@ class LlamaRunner:
         for li, (w, wp) in enumerate(zip(self.w["layers"], self.wp["layers"])):
             if self.layer_hook is not None:
                 self.layer_hook(li)
-            check(L.samd_gemm_qkv_rope_norm(_ptr(x), _ptr(ssq), _ptr(w["ln1"]), s.eps, _ptr(wp["wqkv64"]), 16, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
+            check(L.samd_gemm_qkv_rope_norm(_ptr(x), _ptr(ssq), _ptr(w["ln1"]), s.eps, _ptr(wp["wqkv64"]), rows_a, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
                                             _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, self.max_len, dt, st))
             check(L.samd_tree_attention_warm(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
                                              s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
                                              _ptr(b["ws"]), b["ws_bytes"], None, st))
             check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(wp["wo_g"]), rows_cs, s.hidden, attn2d.shape[1], _ptr(x), _ptr(ssq), dt, st))
-            check(L.samd_gemm_pairs_silu_norm(_ptr(x), _ptr(ssq), _ptr(w["ln2"]), s.eps, _ptr(wp["wgu"]), 16, s.inter, s.hidden, _ptr(b["act"]), dt, st))
+            check(L.samd_gemm_pairs_silu_norm(_ptr(x), _ptr(ssq), _ptr(w["ln2"]), s.eps, _ptr(wp["wgu"]), rows_a, s.inter, s.hidden, _ptr(b["act"]), dt, st))
             check(L.samd_gemm_cs_residual(_ptr(b["act"]), _ptr(wp["wdown_g"]), rows_cs, s.hidden, s.inter, _ptr(x), _ptr(ssq), dt, st))
         check(L.samd_rmsnorm(_ptr(x), None, _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, 0, 0, st))
         wl = self.wp["lm_head"]

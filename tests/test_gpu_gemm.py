@@ -252,6 +252,15 @@ def test_norm_fold_kernels(dtype, H, K, inter):
     for a, b in zip(*outs):
         scale = max(1.0, b.float().abs().max().item())
         assert (a.float() - b.float()).abs().max().item() <= 4 * ulp * scale
+    # rows_pad 8 (a draft of <= 8 nodes: only rows 0..7 of x are fetched): rows 0..7 of q / K / V bit-identical to the 16-row launch
+    d_n8 = torch.tensor([7], dtype=torch.int32, device="cuda")
+    eight = []
+    for rows_pad in (16, 8):
+        q = torch.zeros((16, H, D), device="cuda", dtype=dtype); kc = torch.zeros((H, max_len, D), device="cuda", dtype=dtype); vc = torch.zeros_like(kc)
+        samd_hip.check(Lb.samd_gemm_qkv_rope_norm(P(x), P(ssq), P(gamma), eps, P(W64), rows_pad, K, P(cs), P(d_L), P(d_n8), P(q), P(kc), P(vc), H, H, D, max_len, dc, st))
+        eight.append((q, kc, vc))
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(*eight)) and eight[1][1][:, L:L + 7].abs().sum().item() > 0
     # ---- gate|up + SiLU with the post-attention norm folded in
     Wg, Wu = rnd(inter, K, sc=K ** -0.5), rnd(inter, K, sc=K ** -0.5)
     Wp = _pack_pairs(Wg, Wu, dtype)
@@ -267,6 +276,10 @@ def test_norm_fold_kernels(dtype, H, K, inter):
         act.append(o)
     torch.cuda.synchronize()
     assert (act[1].float() - act[0].float()).abs().max().item() <= 4 * ulp * max(1.0, act[0].float().abs().max().item())
+    o8 = torch.full((16, inter), 7.0, device="cuda", dtype=dtype)
+    samd_hip.check(Lb.samd_gemm_pairs_silu_norm(P(x), P(ssq), P(gamma), eps, P(Wp), 8, inter, K, P(o8), dc, st))
+    torch.cuda.synchronize()
+    assert torch.equal(o8[:8], act[1][:8]) and o8[8:].abs().sum().item() == 0         # rows 8..15: silu(0) * 0
     # ---- complete-sum projection + residual + sums of squares (down_proj shape: K2 = inter rounded to the chunk size)
     K2 = (inter // 256) * 256 or 256
     A2, W2 = rnd(16, K2), rnd(hidden, K2, sc=K2 ** -0.5)
