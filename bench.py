@@ -894,6 +894,12 @@ def main():
             # `roofline` = the SAM traversal kernel (the one BASELINE.json's north star asks to be priced against HBM peak);
             # `roofline_lm` = the kernel that takes most of a step's time, priced the same way
             "roofline": roof, "roofline_lm": lm_roofline(runner), "roofline_lm_rows64": lm_roofline(runner, rows=64), "cpu_baseline": cpu,
+            # the whole decode step of the most frequent bucket against the HBM peak: the weight bytes a step streams (every projection once,
+            # lm_head, norms) / the step's graph time -- what the six launches per layer, the attention pair and the non-LM kernels leave of
+            # the 8 TB/s (profiles/r04_attention.md accounts for the difference kernel by kernel)
+            "roofline_step": ({"bound": "hbm", "bucket_rows": 8, "achieved": round(runner.weight_bytes() / (breakdown["8"]["step_ms"] * 1e-3) / 1e9, 1),
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(runner.weight_bytes() / (breakdown["8"]["step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "alg_bytes_per_step": int(runner.weight_bytes()), "step_ms": breakdown["8"]["step_ms"]} if "8" in breakdown else None),
             "setup": {"static_build_s": round(build_s, 2), "host": f"{os.cpu_count()} cores"},
         }
         print(json.dumps(out), flush=True)
