@@ -535,6 +535,22 @@ def variant_projection(variant, ar_tps, ms_per_step):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def step_accounting(seconds, steps, turnover, bucket_hist, breakdown):
+    """see the `step_accounting` comment in main(): everything in ms per step unless named otherwise"""
+    decode_ms = (seconds - turnover["s"]) * 1e3 / max(steps, 1)
+    weighted, covered = 0.0, 0
+    for R, n in bucket_hist.items():
+        if R in breakdown:
+            weighted += n * breakdown[R]["step_ms"]
+            covered += n
+    out = {"request_starts_in_timed_region": turnover["n"], "request_start_ms_each": round(turnover["s"] * 1e3 / turnover["n"], 3) if turnover["n"] else None,
+           "request_start_share_of_timed_region": round(turnover["s"] / seconds, 4), "decode_ms_per_step": round(decode_ms, 4)}
+    if covered:
+        out["graph_replay_ms_per_step_same_buckets"] = round(weighted / covered, 4)
+        out["host_gap_us_per_step"] = round((decode_ms - weighted / covered) * 1e3, 1)
+    return out
+
+
 def launch_command(n_gpus, argv, port=None):
     """the torch.distributed.run command line for N ranks of this script on one node (one process per GPU, RCCL over xGMI)."""
     if port is None:
@@ -712,9 +728,23 @@ def main():
             for new_ids, rep in model._run(ids, gcfg, gcfg.max_new_tokens):
                 yield len(new_ids)
 
+    # request turnover (reset + prefill + prompt ingest + the first draft = engine.start, synchronous) is part of the timed region when
+    # a request ends inside it; it is clocked here so that the per-step figure can also be read without it (`step_accounting`)
+    turnover = {"n": 0, "s": 0.0}
+    _engine_start = model.engine.start
+
+    def _timed_start(*a, **kw):
+        t_s = time.perf_counter()
+        r = _engine_start(*a, **kw)
+        turnover["n"] += 1
+        turnover["s"] += time.perf_counter() - t_s
+        return r
+    model.engine.start = _timed_start
+
     it = steps_forever()
     for _ in range(args.warmup):
         next(it)
+    turnover["n"], turnover["s"] = 0, 0.0
     for v in model.lookup_stats.values():
         v[0] = v[1] = 0
     model.engine.bucket_steps.clear()
@@ -762,6 +792,8 @@ def main():
             step_times.append(round((time.perf_counter() - ts) * 1e3, 3))
     fence()
     dt = time.perf_counter() - t0
+    turnover_timed = dict(turnover)
+    model.engine.start = _engine_start
     if step_times is not None:
         print("step wall times (ms):", step_times, file=sys.stderr, flush=True)
     stats = {k: list(v) for k, v in model.lookup_stats.items()}
@@ -863,6 +895,10 @@ def main():
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
             "per_rank": [dict(r, ms_per_step=round(r["seconds"] / args.steps * 1e3, 4)) for r in per_rank], "bucket_histogram": bucket_hist,
+            # rank 0's timed region taken apart: request turnovers that fell into it (engine.start, clocked on the host), the decode steps
+            # without them, and what the same steps cost as back-to-back graph replays of their row buckets (step_breakdown_by_rows) --
+            # the difference is what the host adds between replays (report wait, bucket choice, launch)
+            "step_accounting": step_accounting(dt, args.steps, turnover_timed, bucket_hist, breakdown),
             "static_sam_distribution": {"how": "RCCL broadcast from rank 0 + samd_static_adopt_device" if world > 1 else "host image -> HBM upload",
                                         "ms": round(broadcast_ms, 2), "ms_per_rank": [r["static_sam_distribution_ms"] for r in per_rank],
                                         "bytes": int(sam_info["device_bytes"])},
