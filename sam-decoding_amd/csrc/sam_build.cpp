@@ -282,6 +282,7 @@ void samd_static_free(samd_static_t *s) {
     if (s->d_chain) (void)hipFree(s->d_chain);
     if (s->d_root16) (void)hipFree(s->d_root16);
     if (s->d_d1hash) (void)hipFree(s->d_d1hash);
+    if (s->d_rc_bits) (void)hipFree(s->d_rc_bits);
     if (s->d_topk_cnt) (void)hipFree(s->d_topk_cnt);
     free(s);
 }

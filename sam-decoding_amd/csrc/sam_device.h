@@ -108,103 +108,109 @@ __device__ __forceinline__ ChainWord chain_half(unsigned lo, unsigned hi) {
     w.used = W / 2; w.have_next = 0;
     return w;
 }
-
-// position of the cursor's state in the ROOT-CHILD HASH (samd_common.h): valid (slots > 0) only while the cursor sits on the state it
-// reached through the root table
-struct RootChild { int base, slots; };
-__device__ __forceinline__ RootChild rootchild_none() { RootChild r; r.base = 0; r.slots = 0; return r; }
-
-// ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown; ntok = the token
-// after `tok` (-1 when unknown).  pre = root16[ptok] when pre.x != 0xFFFFFFFF: a cursor that follows a chain entry and SEES that its next
-// token will leave the run through a flagged entry requests the root child's entry one token early, so that the climb is one round trip.
+// the FIRST entry of a state's chain word (the bigram table's entries of large vocabularies have room for one): one transition, then the
+// full word of the state reached is fetched
 template <int W>
-__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, int &len, int tok, int ptok, int ntok, ChainWord &cw, RootChild &rc,
-                                                 uint4 &pre) {
+__device__ __forceinline__ ChainWord chain_first(unsigned first) {
+    ChainWord w;
+    w.lo = (unsigned long long)first | (W == 8 ? 0xFFFFFFFFFFFF0000ull : 0xFFFFFFFF00000000ull);
+    w.hi = w.nlo = w.nhi = ~0ull;
+    w.used = W - 1; w.have_next = 0;
+    return w;
+}
+
+// A cursor that sits on the root child of token a is carried as idx = -2 - a (samd_common.h, BIGRAM TABLE) and resolved where an index is
+// written out.
+__device__ __forceinline__ bool st_on_child(int idx) { return idx <= -2; }
+__device__ __forceinline__ int st_child_of(int tok) { return -2 - tok; }
+__device__ __forceinline__ int st_resolve(const StaticDev &S, int idx) { return idx <= -2 ? (int)S.root16[-2 - idx].x : idx; }
+// does token t have a root child?  `bits` = S.rc_bits or its copy in LDS
+__device__ __forceinline__ bool st_has_child(const StaticDev &S, const uint32_t *bits, int t) {
+    return t < S.vocab && ((bits[(unsigned)t >> 5] >> (t & 31)) & 1u);
+}
+// the root's transition on `tok`: no memory beyond the bitmap
+__device__ __forceinline__ void st_from_root(const StaticDev &S, const uint32_t *bits, int tok, int &idx, int &len) {
+    if (st_has_child(S, bits, tok)) { idx = st_child_of(tok); len = 1; } else { idx = 0; len = 0; }
+}
+
+// ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown.
+// `bits`: see st_has_child.  With the bigram table (S.bigram) the function may leave idx in the unresolved form (st_on_child).
+template <int W>
+__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw) {
     constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
-    const uint4 pre_in = pre;
-    pre.x = 0xFFFFFFFFu;
-    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); rc.slots = 0; return 1; }
+    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); return 1; }
     const unsigned ent = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
     const bool is_tok = (ent & LOW) != LOW;                  // a chain token (the end marker is all-ones)
     if (is_tok && (ent & LOW) == (unsigned)tok) {            // register path
-        idx += 1; len += 1; rc.slots = 0;
+        idx += 1; len += 1;
         if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
         else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
         // a FULL word used up: the run may go on -- its next word was requested one token ago (below); without it (a word that came
         // in with one entry left) fetch the new state's word now.  A word that ended early marks the end of the run.
-        bool in_regs = true;
         if (++cw.used == W) {
             if (cw.have_next) { cw.lo = cw.nlo; cw.hi = cw.nhi; cw.nlo = cw.nhi = ~0ull; cw.used = 0; cw.have_next = 0; }
-            else { cw = chain_load(S, idx); in_regs = false; }
+            else { cw = chain_load(S, idx); return 1; }
         }
-        if (in_regs) {
-            const unsigned e2 = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
-            const bool tok2 = (e2 & LOW) != LOW;
-            if (cw.used == W - 1 && tok2) {                  // one entry left and the run goes on: the word of the state after it
-                const uint4 c = S.chain[idx + 1];
-                cw.nlo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
-                cw.nhi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
-                cw.have_next = 1;
-            }
-            // the next call will climb from here (flagged entry, another token): request the root child's entry now
-            if (ntok >= 0 && S.root16 != nullptr && tok2 && !(e2 & HI) && (e2 & LOW) != (unsigned)ntok) pre = S.root16[tok];
+        const unsigned e2 = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+        if (cw.used == W - 1 && (e2 & LOW) != LOW) {         // one entry left and the run goes on: the word of the state after it
+            const uint4 c = S.chain[idx + 1];
+            cw.nlo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
+            cw.nhi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
+            cw.have_next = 1;
         }
         return 1;
     }
-    const bool known_climb = is_tok && !(ent & HI) && ptok >= 0 && S.root16 != nullptr;
+    const bool have_table = S.bigram != nullptr;
+    // flagged entry: idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.  transfer_state visits idx, hops
+    // (length <- states[link].length) and looks for `tok` there -- in the bigram table under (ptok, tok)
+    const bool climbing = is_tok && !(ent & HI) && ptok >= 0 && have_table;
     cw = chain_none();
-    int visited = 0;
-    bool hopped = false;
-    int base = rc.base, slots = rc.slots;
-    rc.slots = 0;
-    if (known_climb) {
-        // flagged entry: idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.  transfer_state visits idx,
-        // hops (length <- states[link].length) and looks for `tok` there.
-        uint4 r = pre_in;
-        if (r.x == 0xFFFFFFFFu) r = S.root16[ptok];
-        visited = 1; idx = (int)r.x; len = (int)r.w; base = (int)r.y; slots = (int)r.z; hopped = true;
+    int visited = climbing ? 1 : 0;
+    const bool probing = climbing || st_on_child(idx);
+    if (!probing && idx == 0 && have_table) {                // at the root: no request at all
+        st_from_root(S, bits, tok, idx, len);
+        return 1;
     }
-    // THE FIRST LOAD OF EVERY LANE IS ONE INSTRUCTION: 16 bytes from a per-lane address -- a slot of a root child's hashed block (the
-    // climbing lanes and the lanes that sit on a root child: all edges of that state are there, one probe decides), the root's entry
-    // for `tok`, or word 0 of the cursor's node.  A wave advances in lock-step, so what it pays per token is the number of dependent
-    // PHASES, not of loads: with the kinds in separate branches a token cost their sum (profiles/r04_walk.md).
-    const bool probing = slots != 0;
-    const bool tok_ok = tok < S.vocab;
-    const bool at_root = !probing && idx == 0 && tok_ok && S.root16 != nullptr;
-    const uint32_t m = (uint32_t)slots;
-    uint32_t h = probing ? samd_spill_hash(tok, m) : 0u;
-    const uint4 *addr = probing ? S.d1hash + base + h : at_root ? S.root16 + tok : reinterpret_cast<const uint4 *>(S.nodes + idx);
-    // where a failed probe ends: the root's entry for `tok`, requested with the probe (an L2 hit, no HBM request)
-    uint4 rt = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
-    if (probing && tok_ok) rt = S.root16[tok];
+    // THE FIRST LOAD OF EVERY LANE IS ONE INSTRUCTION: 16 bytes from a per-lane address -- a slot of the bigram table (the climbing lanes
+    // and the lanes that sit on a root child: one probe decides) or word 0 of the cursor's node.  A wave advances in lock-step, so what it
+    // pays per token is the number of dependent PHASES, not of loads: with the kinds in separate branches a token cost their sum
+    // (profiles/r04_walk.md).
+    const int a = climbing ? ptok : -2 - idx;
+    uint32_t h = probing ? samd_bigram_hash(a, tok) & S.bigram_mask : 0u;
+    const uint4 *addr = probing ? S.bigram + h : reinterpret_cast<const uint4 *>(S.nodes + idx);
     const uint4 first = *addr;
     if (probing) {
-        const uint4 *tab = S.d1hash + base;
         uint4 e = first;
-        for (uint32_t probes = 1; (int)e.x != tok && (int)e.x != -1 && probes < m; probes++) { h = (h + 1) & (m - 1); e = tab[h]; }
-        if ((int)e.x == tok) { idx = (int)e.y; len += 1; cw = chain_half<W>(e.z, e.w); return visited + 1; }
-        // no edge in the block = that state visited too, then the hop to ITS suffix link, the root
-        const int nx = (int)rt.x;
-        if (nx >= 0) { idx = nx; len = 1; rc.base = (int)rt.y; rc.slots = (int)rt.z; } else { idx = 0; len = 0; }
+        bool hit = false;
+        for (uint32_t probes = 0; probes <= S.bigram_mask; probes++) {
+            if (W == 8) hit = (e.x & 0x3FFFFFFFu) == ((unsigned)a | ((unsigned)tok << 15)) && tok < 0x8000;
+            else hit = (e.x & 0x7FFFFFFFu) == (unsigned)a && (e.y & 0x7FFFFFFFu) == (unsigned)tok;
+            if (hit || e.x == 0xFFFFFFFFu) break;
+            h = (h + 1) & S.bigram_mask; e = S.bigram[h];
+        }
+        if (hit) {
+            if (climbing) {
+                const unsigned lb = W == 8 ? e.x >> 30 : (e.x >> 31) | ((e.y >> 31) << 1);
+                len = lb < 3 ? (int)lb + 1 : (int)S.root16[a].w;
+            }
+            len += 1;
+            if (W == 8) { idx = (int)e.y; cw = chain_half<W>(e.z, e.w); }
+            else { idx = (int)e.z; cw = chain_first<W>(e.w); }
+            return visited + 1;
+        }
+        // no edge in the table = that state visited too, then the hop to ITS suffix link, the root
+        st_from_root(S, bits, tok, idx, len);
         return visited + 2;
     }
-    if (at_root) {
-        const int nx = (int)first.x;
-        // (no word is fetched for a landing through the root table: a depth-1 state is rarely left through its rank-0 edge --
-        // measured 0.401 ms per launch with the fetch against 0.374 without)
-        if (nx >= 0) { idx = nx; len += 1; rc.base = (int)first.y; rc.slots = (int)first.z; } else { idx = 0; len = 0; }
-        return visited + 1;
-    }
-    bool use_first = idx != 0;
+    bool hopped = false, use_first = true;
     for (;;) {
         visited++;
         if (idx == 0) {
-            int nx = -1;
-            if (tok_ok) {
-                if (S.root16) { const uint4 r = S.root16[tok]; nx = (int)r.x; rc.base = (int)r.y; rc.slots = nx >= 0 ? (int)r.z : 0; }
-                else nx = S.root_next[tok];
+            if (have_table) st_from_root(S, bits, tok, idx, len);
+            else {
+                const int nx = tok < S.vocab ? S.root_next[tok] : -1;
+                if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
             }
-            if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; }
             return visited;
         }
         const int4 *np = reinterpret_cast<const int4 *>(S.nodes + idx);
@@ -241,11 +247,13 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, int &idx, i
 // has them, so that a run of tokens that follows the corpus costs one load per 8 (4) tokens instead of one per token
 __device__ __forceinline__ void st_transfer_tokens(const StaticDev &S, int &idx, int &len, const int *toks, int n) {
     if (S.chain && S.chain_w == 8) {
-        ChainWord cw = chain_none(); RootChild rc = rootchild_none(); uint4 pre = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
-        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, idx, len, toks[i], i ? toks[i - 1] : -1, i + 1 < n ? toks[i + 1] : -1, cw, rc, pre);
+        ChainWord cw = chain_none();
+        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, S.rc_bits, idx, len, toks[i], i ? toks[i - 1] : -1, cw);
+        idx = st_resolve(S, idx);
     } else if (S.chain) {
-        ChainWord cw = chain_none(); RootChild rc = rootchild_none(); uint4 pre = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
-        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, idx, len, toks[i], i ? toks[i - 1] : -1, i + 1 < n ? toks[i + 1] : -1, cw, rc, pre);
+        ChainWord cw = chain_none();
+        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, S.rc_bits, idx, len, toks[i], i ? toks[i - 1] : -1, cw);
+        idx = st_resolve(S, idx);
     } else {
         for (int i = 0; i < n; i++) st_transfer(S, idx, len, toks[i]);
     }

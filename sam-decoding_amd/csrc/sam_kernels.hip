@@ -17,7 +17,8 @@ static inline StaticDev static_view(const samd_static_t *s) {
     v.nodes = s->d_nodes; v.root_next = s->d_root; v.spill = s->d_spill; v.text = s->d_text;
     v.n_states = (int32_t)s->n_states; v.vocab = (int32_t)s->vocab; v.n_text = (int32_t)s->n_text; v.kind = s->kind;
     v.chain = (const uint4 *)s->d_chain; v.chain_w = s->vocab <= 32767 ? 8 : 4;
-    v.root16 = (const uint4 *)s->d_root16; v.d1hash = (const uint4 *)s->d_d1hash;
+    v.root16 = (const uint4 *)s->d_root16; v.bigram = (const uint4 *)s->d_d1hash; v.bigram_mask = s->n_d1hash > 0 ? (uint32_t)(s->n_d1hash - 1) : 0u;
+    v.rc_bits = (const uint32_t *)s->d_rc_bits;
     v.topk_cnt = (const int32_t *)s->d_topk_cnt;
     return v;
 }
@@ -36,25 +37,31 @@ static inline StaticDev static_view(const samd_static_t *s) {
 template <int W, bool CHAIN>
 __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__restrict__ cursors,
                                                      const int32_t *__restrict__ tokens, int B, int T, int commit,
-                                                     int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total) {
+                                                     int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total, int lds_words) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long visited = 0;
+    // which tokens have a root child: vocab bits, in LDS when the launch reserved room for them (samd_common.h, BIGRAM TABLE)
+    extern __shared__ uint32_t walk_bits[];
+    const uint32_t *bits = S.rc_bits;
+    if (CHAIN && lds_words > 0) {
+        for (int k = threadIdx.x; k < lds_words; k += blockDim.x) walk_bits[k] = S.rc_bits[k];
+        __syncthreads();
+        bits = walk_bits;
+    }
     if (b < B) {
         int2 c = reinterpret_cast<const int2 *>(cursors)[b];
         int idx = c.x, len = c.y;
         int tok = tokens[b];
         ChainWord cw = chain_none();
-        RootChild rc = rootchild_none();
-        uint4 pre = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
         int ptok = -1;
         for (int t = 0; t < T; t++) {
             const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;
-            if (CHAIN) visited += st_transfer_chain<W>(S, idx, len, tok, ptok, t + 1 < T ? nxt : -1, cw, rc, pre);
+            if (CHAIN) visited += st_transfer_chain<W>(S, bits, idx, len, tok, ptok, cw);
             else visited += st_transfer(S, idx, len, tok);
-            if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(idx, len);
+            if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(CHAIN ? st_resolve(S, idx) : idx, len);
             ptok = tok; tok = nxt;
         }
-        if (commit) reinterpret_cast<int2 *>(cursors)[b] = make_int2(idx, len);
+        if (commit) reinterpret_cast<int2 *>(cursors)[b] = make_int2(CHAIN ? st_resolve(S, idx) : idx, len);
     }
     if (visited_total) {
         for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
@@ -411,46 +418,66 @@ static void launch_walk(const samd_static_t *sam, int blocks, int threads, hipSt
                         int commit, int32_t *d_trace, unsigned long long *d_visited) {
     static const bool use_chain = [] { const char *e = getenv("SAMD_WALK_CHAIN"); return !(e && e[0] == '0'); }();
     const StaticDev v = static_view(sam);
-    if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, false>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
-    else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, true>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
-    else hipLaunchKernelGGL((k_static_walk<4, true>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited);
+    // the child bitmap rides in LDS when it is small enough to leave the occupancy alone (8 workgroups of 256 per CU: 160 KiB / 8)
+    const int bit_words = v.rc_bits ? (int)((v.vocab + 31) / 32) : 0;
+    const int lds_words = bit_words * 4 <= 20480 ? bit_words : 0;
+    if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, false>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited, 0);
+    else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited, lds_words);
+    else hipLaunchKernelGGL((k_static_walk<4, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited, lds_words);
 }
 
-// root-child hash (samd_common.h): sizes, then fill.  One thread per vocabulary id.
-__global__ __launch_bounds__(256) void k_d1_sizes(const SamNode *__restrict__ nodes, const int32_t *__restrict__ root_next, int vocab, int32_t *__restrict__ sizes) {
+// bigram table (samd_common.h): count the root children's edges, then fill.  One thread per vocabulary id.
+__global__ __launch_bounds__(256) void k_bg_count(const SamNode *__restrict__ nodes, const int32_t *__restrict__ root_next, int vocab, unsigned long long *__restrict__ total) {
+    const int tok = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long d = 0;
+    if (tok < vocab) { const int dst = root_next[tok]; if (dst > 0) d = (unsigned long long)nodes[dst].deg; }
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(total, d);
+}
+__global__ __launch_bounds__(256) void k_bg_fill(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, const int32_t *__restrict__ root_next,
+                                                 int vocab, const uint4 *__restrict__ chain, uint4 *__restrict__ root16, uint4 *__restrict__ table, uint32_t mask,
+                                                 uint32_t *__restrict__ rc_bits, int W) {
     const int tok = blockIdx.x * blockDim.x + threadIdx.x;
     if (tok >= vocab) return;
     const int dst = root_next[tok];
-    int m = 0;
-    if (dst > 0) {
-        const int deg = nodes[dst].deg;
-        if (deg > SAMD_INLINE_EDGES) { m = 8; while (m < 4 * deg) m <<= 1; }      // load factor <= 1/4: 1.17 probes per hit, 1.39 per miss (1/2: 1.5 / 2.5)
-    }
-    sizes[tok] = m;
-}
-__global__ __launch_bounds__(256) void k_d1_fill(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, const int32_t *__restrict__ root_next,
-                                                 int vocab, const long long *__restrict__ offsets, const int32_t *__restrict__ sizes,
-                                                 const uint4 *__restrict__ chain, uint4 *__restrict__ root16, uint4 *__restrict__ hash) {
-    const int tok = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tok >= vocab) return;
-    const int dst = root_next[tok], m = sizes[tok];
-    const long long base = offsets[tok];
-    root16[tok] = make_uint4((unsigned)dst, (unsigned)base, (unsigned)m, dst > 0 ? (unsigned)(nodes[dst].length & SAMD_LEN_MASK) : 0u);
-    if (m == 0) return;
-    uint4 *tab = hash + base;
+    const unsigned length = dst > 0 ? (unsigned)(nodes[dst].length & SAMD_LEN_MASK) : 0u;
+    root16[tok] = make_uint4((unsigned)dst, 0u, 0u, length);
+    if (dst <= 0) return;
+    atomicOr(rc_bits + (tok >> 5), 1u << (tok & 31));
+    const unsigned lb = length - 1 < 3u ? length - 1 : 3u;
+    // slots are claimed by compare-and-swap on the key word(s); the other words follow (a reader only runs after the launch)
     auto put = [&](int t, int d) {
         if (t < 0) return;
-        uint32_t h = samd_spill_hash(t, (uint32_t)m);
-        while ((int)tab[h].x != -1) { if ((int)tab[h].x == t) return; h = (h + 1) & (uint32_t)(m - 1); }     // (the spill head repeats ranks 5..7)
+        uint32_t h = samd_bigram_hash(tok, t) & mask;
         const uint4 c = d > 0 ? chain[d] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        tab[h] = make_uint4((unsigned)t, (unsigned)d, c.x, c.y);                                          // edge + the first half of its target's chain word
+        if (W == 8) {
+            const unsigned key = (unsigned)tok | ((unsigned)t << 15) | (lb << 30);
+            for (;;) {
+                unsigned *kp = reinterpret_cast<unsigned *>(table + h);
+                const unsigned old = atomicCAS(kp, 0xFFFFFFFFu, key);
+                if (old == 0xFFFFFFFFu) { kp[1] = (unsigned)d; kp[2] = c.x; kp[3] = c.y; return; }
+                if (old == key) return;                                                                   // (the spill head repeats ranks 5..7)
+                h = (h + 1) & mask;
+            }
+        } else {
+            const unsigned long long key = (unsigned long long)((unsigned)tok | ((lb & 1u) << 31)) | ((unsigned long long)((unsigned)t | ((lb >> 1) << 31)) << 32);
+            for (;;) {
+                unsigned long long *kp = reinterpret_cast<unsigned long long *>(table + h);
+                const unsigned long long old = atomicCAS(kp, ~0ull, key);
+                if (old == ~0ull) { unsigned *wp = reinterpret_cast<unsigned *>(kp); wp[2] = (unsigned)d; wp[3] = c.x; return; }
+                if (old == key) return;
+                h = (h + 1) & mask;
+            }
+        }
     };
     const int *w = reinterpret_cast<const int *>(nodes + dst);
     for (int k = 0; k < SAMD_INLINE_EDGES; k++) put(w[SAMD_EDGE_WORD(k)], w[SAMD_EDGE_WORD(k) + 1]);
     const int deg = w[5];
-    const SamEdge *sp = spill + w[14];
-    const uint32_t slots = samd_spill_slots(deg);
-    for (uint32_t k = 0; k < SAMD_SPILL_HEAD + slots; k++) put(sp[k].tok, sp[k].dst);
+    if (deg > SAMD_INLINE_EDGES) {
+        const SamEdge *sp = spill + w[14];
+        const uint32_t slots = samd_spill_slots(deg);
+        for (uint32_t k = 0; k < SAMD_SPILL_HEAD + slots; k++) put(sp[k].tok, sp[k].dst);
+    }
 }
 
 // top-k counts (samd_common.h): one thread per (state, rank)
@@ -476,40 +503,43 @@ static int derive_topk_counts(samd_static_t *s, hipStream_t st) {
 
 static int derive_root_hash(samd_static_t *s, hipStream_t st) {
     static const bool enabled = [] { const char *e = getenv("SAMD_ROOT_HASH"); return !(e && e[0] == '0'); }();      // A/B switch, read once
-    if (!enabled || s->vocab < 1 || s->vocab > (1 << 24)) return SAMD_OK;
     if (s->d_root16) { (void)hipFree(s->d_root16); s->d_root16 = nullptr; }
     if (s->d_d1hash) { (void)hipFree(s->d_d1hash); s->d_d1hash = nullptr; }
+    if (s->d_rc_bits) { (void)hipFree(s->d_rc_bits); s->d_rc_bits = nullptr; }
+    s->n_d1hash = 0;
+    if (!enabled || s->vocab < 1 || s->vocab > (1 << 24) || !s->d_chain) return SAMD_OK;
     const int vocab = (int)s->vocab;
-    int32_t *d_sizes = nullptr; long long *d_off = nullptr;
-    if (hipMalloc((void **)&d_sizes, (size_t)vocab * 4) != hipSuccess || hipMalloc((void **)&d_off, (size_t)vocab * 8) != hipSuccess) {
-        if (d_sizes) (void)hipFree(d_sizes);
-        samd_set_error("hipMalloc(root-child hash sizes) failed"); return SAMD_E_HIP;
-    }
     const unsigned blocks = (unsigned)((vocab + 255) / 256);
-    hipLaunchKernelGGL(k_d1_sizes, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_root, vocab, d_sizes);
-    std::vector<int32_t> sizes(vocab);
-    std::vector<long long> off(vocab);
+    unsigned long long *d_total = nullptr, total = 0;
     int rc = SAMD_OK;
-    if (hipMemcpyAsync(sizes.data(), d_sizes, (size_t)vocab * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
-    long long total = 0;
-    for (int i = 0; i < vocab && rc == SAMD_OK; i++) { off[i] = total; total += sizes[i]; }
-    if (rc == SAMD_OK && total >= (1ll << 31)) { total = 0; rc = -1; }      // base does not fit 32 bits: go without the hash
-    if (rc == SAMD_OK && total > 0) {
-        if (hipMalloc(&s->d_root16, (size_t)vocab * 16) != hipSuccess || hipMalloc(&s->d_d1hash, (size_t)total * 16) != hipSuccess) rc = SAMD_E_HIP;
-        if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)total * 16, st) != hipSuccess ||
-                              hipMemcpyAsync(d_off, off.data(), (size_t)vocab * 8, hipMemcpyHostToDevice, st) != hipSuccess)) rc = SAMD_E_HIP;
+    if (hipMalloc((void **)&d_total, 8) != hipSuccess) { samd_set_error("hipMalloc(bigram count) failed"); return SAMD_E_HIP; }
+    if (hipMemsetAsync(d_total, 0, 8, st) != hipSuccess) rc = SAMD_E_HIP;
+    if (rc == SAMD_OK) {
+        hipLaunchKernelGGL(k_bg_count, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_root, vocab, d_total);
+        if (hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
+    }
+    (void)hipFree(d_total);
+    long long slots = 1024;
+    while (slots < 4 * (long long)total) slots <<= 1;                             // load factor in (1/8, 1/4]
+    if (rc == SAMD_OK && slots > (1ll << 31)) rc = -1;                            // the mask does not fit 32 bits: go without the table
+    const size_t bit_bytes = (size_t)((vocab + 31) / 32) * 4;
+    if (rc == SAMD_OK) {
+        if (hipMalloc(&s->d_root16, (size_t)vocab * 16) != hipSuccess || hipMalloc(&s->d_d1hash, (size_t)slots * 16) != hipSuccess ||
+            hipMalloc(&s->d_rc_bits, bit_bytes) != hipSuccess) rc = SAMD_E_HIP;
+        if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)slots * 16, st) != hipSuccess || hipMemsetAsync(s->d_rc_bits, 0, bit_bytes, st) != hipSuccess)) rc = SAMD_E_HIP;
         if (rc == SAMD_OK) {
-            hipLaunchKernelGGL(k_d1_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, d_off, d_sizes, (const uint4 *)s->d_chain, (uint4 *)s->d_root16, (uint4 *)s->d_d1hash);
+            hipLaunchKernelGGL(k_bg_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, (const uint4 *)s->d_chain, (uint4 *)s->d_root16,
+                               (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, vocab <= 32767 ? 8 : 4);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
         }
-        s->n_d1hash = total;
+        if (rc == SAMD_OK) s->n_d1hash = slots;
     }
-    (void)hipFree(d_sizes); (void)hipFree(d_off);
     if (rc != SAMD_OK) {
         if (s->d_root16) { (void)hipFree(s->d_root16); s->d_root16 = nullptr; }
         if (s->d_d1hash) { (void)hipFree(s->d_d1hash); s->d_d1hash = nullptr; }
+        if (s->d_rc_bits) { (void)hipFree(s->d_rc_bits); s->d_rc_bits = nullptr; }
         s->n_d1hash = 0;
-        if (rc == SAMD_E_HIP) { samd_set_error("root-child hash derivation failed"); return rc; }
+        if (rc == SAMD_E_HIP) { samd_set_error("bigram table derivation failed"); return rc; }
     }
     return SAMD_OK;
 }

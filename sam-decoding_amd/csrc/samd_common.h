@@ -55,6 +55,12 @@ SAMD_HD static inline uint32_t samd_spill_slots(int32_t deg) {
     while (m < need) m <<= 1;
     return m;
 }
+// slot of the token pair (a, b) in the bigram table (StaticDev), before masking
+SAMD_HD static inline uint32_t samd_bigram_hash(int32_t a, int32_t b) {
+    uint32_t h = (uint32_t)a * 0x9E3779B1u + (uint32_t)b * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    return h ^ (h >> 13);
+}
 SAMD_HD static inline uint32_t samd_spill_hash(int32_t tok, uint32_t slots) {
     return (((uint32_t)tok * 0x9E3779B1u) >> 7) & (slots - 1);
 }
@@ -68,16 +74,23 @@ struct StaticDev {
     int32_t n_states, vocab, n_text, kind;
     const uint4 *chain;         // chain words (may be null: every transition then goes through the nodes)
     int32_t chain_w;            // tokens per chain word: 8 (u16) or 4 (u32)
-    // ROOT-CHILD HASH (device-only, derived at upload; may be null).  The states one token below the root are where a walk lands after
-    // every mismatch, and in a real corpus they have the highest degrees of the automaton (every token that ever followed t): resolving
-    // a transition there through the node costs its line, its tail and a probe of its spill block -- three dependent round trips, two
-    // HBM lines.  root16[tok] = {dst, base, slots, length[dst]} extends the dense root table (root_next) by the position of a hashed block that
-    // holds ALL edges of dst (ranks 0..4 included; slots = power of two >= 4 x deg, samd_spill_hash, linear probing, empty = (-1,-1);
-    // slots = 0 for children of degree <= 5, which resolve inside their node line anyway).  A cursor that just landed through the root
-    // table carries (base, slots) and resolves its next token with ONE probe: found -> the edge; not found -> no edge at all, and the
-    // suffix link of a root child is the root (its shortest string has length 1), so the node is never loaded.
+    // BIGRAM TABLE (device-only, derived at upload; may be null; round 4: replaces round 3's per-child hashed blocks).  The states one token
+    // below the root are where a walk lands after every mismatch, and in a real corpus they have the highest degrees of the automaton.  ONE
+    // open-addressing table holds every edge of every root child, keyed by the token pair: (a, b) -> {state of the string "a b" ..., first
+    // half of its chain word}.  A cursor that sits on the child of `a` therefore needs nothing from memory to know where to look for `b` --
+    // and, since its edges are the only thing a walk ever asks of such a state, it needs no state index either: the walk kernels carry
+    // "on the child of token a" as idx = -2 - a and resolve it (root16[a].x) only where an index is written out.  Landing there -- from the
+    // root, or from a failed lookup (no edge = the child visited too, its suffix link is the root: its shortest string has length 1) -- costs
+    // no request at all: whether token t has a child is one bit of rc_bits (vocab bits, copied to LDS by the batched walk).
+    //   entry, vocab <= 32767 (chain_w 8): {a | b << 15 | lb << 30, dst, chain[dst].x, chain[dst].y}
+    //   entry, larger vocabularies (chain_w 4): {a | (lb & 1) << 31, b | (lb >> 1) << 31, dst, chain[dst].x}
+    //   lb = min(length[child of a] - 1, 3): what a climbing cursor's match length becomes there (3 = read root16[a].w); empty = all-ones;
+    //   slot = samd_bigram_hash(a, b) & bigram_mask, linear probing, load factor <= 1/4.
+    // root16[tok] = {dst, 0, 0, length[dst]} (dst = -1: no child).
     const uint4 *root16;
-    const uint4 *d1hash;        // 16-byte entries {tok, dst, first half of chain[dst]} (round 4), empty = all-ones
+    const uint4 *bigram;
+    uint32_t bigram_mask;
+    const uint32_t *rc_bits;
     // TOP-K COUNTS (device-only, derived at upload; may be null): topk_cnt[8 s + k] = cnt_endpos of state s's rank-k successor, the
     // numerators of the best-first tree's child probabilities (static_sam.py:205-210).  Without it an expansion is two dependent round
     // trips (the parent's node for the edges, then the children's nodes for their counts); with it one.
@@ -152,9 +165,10 @@ struct samd_static {
     int uploaded;
     int borrowed;               // device image owned by the caller (samd_static_adopt_device)
     void *d_chain;              // chain words, derived on the device from d_nodes (always owned by the handle)
-    void *d_root16, *d_d1hash;  // root-child hash (StaticDev), derived with the chain words; owned by the handle
+    void *d_root16, *d_d1hash;  // root entries and the bigram table (StaticDev), derived with the chain words; owned by the handle
+    void *d_rc_bits;            // which tokens have a root child (StaticDev); owned by the handle
     void *d_topk_cnt;           // top-k counts (StaticDev), KIND_COUNT only; owned by the handle
-    int64_t n_d1hash;           // its slots
+    int64_t n_d1hash;           // the bigram table's slots (a power of two)
 };
 
 // sam_kernels.hip: (re)derive the chain words from the device image; called by upload / adopt and lazily by the walks

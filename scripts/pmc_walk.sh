@@ -7,10 +7,10 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/${1:-pmc_r2}
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/walk_trace -o w -- python3 scripts/walk_probe.py > $OUT/walk_trace.txt 2>&1
+timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/walk_trace -o w -- python3 scripts/walk_probe.py > $OUT/walk_trace.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY TCP_TCC_READ_REQ_sum"; do
   tag=$(echo $c | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/walk_$tag -o w -- python3 scripts/walk_probe.py > $OUT/walk_$tag.txt 2>&1
+  timeout -k 5 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/walk_$tag -o w -- python3 scripts/walk_probe.py > $OUT/walk_$tag.txt 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, json, sys
