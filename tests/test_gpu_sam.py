@@ -185,6 +185,61 @@ def test_static_walk_known_climbs(vocab):
             i, l = ora.transfer_state(i, l, int(toks[t, b]))
             assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (b, t)
     assert int(visited.item()) == walk_visited(ora.export(), toks)
+
+
+@pytest.mark.parametrize("base", [10, 40000])
+def test_static_walk_climb_into_long_root_child(base):
+    """the bigram table (csrc/samd_common.h) keeps min(length[child of a] - 1, 3) beside every pair of a: what a climbing cursor's match
+    length becomes at that child.  Here token b is always preceded by the same run, so its root child holds strings of length 1 .. k + 1
+    (k = 1, 2, 3, 5: the two-bit field and its escape to root16[a].w); a cursor that follows `x ... b` in registers and then meets a token
+    that follows b only in another document climbs from a one-edge state straight into that child (reference: static_sam.py:98-107).
+    Both entry forms (vocabulary <= 32767 and above), every (index, length) and the visited-state count against the oracle, and the
+    same streams through the session's committed walk (st_transfer_tokens: resolved cursor)."""
+    docs, streams = [], []
+    t = base
+    for k in (1, 2, 3, 5):
+        run = list(range(t, t + k)); b = t + k; x, y, c, d = t + k + 1, t + k + 2, t + k + 3, t + k + 4
+        tail_c = list(range(t + k + 5, t + k + 15)); tail_d = list(range(t + k + 15, t + k + 25))
+        t += k + 30
+        docs += [[x] + run + [b, c] + tail_c, [y] + run + [b, d] + tail_d]
+        streams.append([x] + run + [b, d] + tail_d[:6])                       # climb, probe hits: length k + 1, then + 1
+        streams.append([y] + run + [b, c] + tail_c[:6])
+        streams.append([x] + run + [b, tail_c[3]] + tail_c[4:9])               # climb, probe misses, lands on another child
+        streams.append(run + [b, d, tail_d[0], c])                             # from the root through the child of run[0]
+    vocab = t + 5
+    docs += [[z] for z in range(base, vocab, 7)]
+    n_max = max(len(q) for q in streams)
+    prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    ora = O.StaticSAM.build(docs, 2)
+    toks = np.array([q + [docs[0][0]] * (n_max - len(q)) for q in streams], dtype=np.int32).T.copy()
+    T, B = toks.shape
+    cur = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    trace = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.walk(cur, dev(toks), commit=True, trace=trace)
+    prod.walk(torch.zeros_like(cur), dev(toks), commit=False, visited=visited)
+    got, fin = trace.cpu().numpy(), cur.cpu().numpy()
+    lengths = ora.export()["length"]
+    seen_long = 0
+    for b in range(B):
+        i, l = 0, 0
+        for tt in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[tt, b]))
+            assert (int(got[tt, b, 0]), int(got[tt, b, 1])) == (i, l), (b, tt)
+        assert (int(fin[b, 0]), int(fin[b, 1])) == (i, l)
+    for k_i, k in enumerate((1, 2, 3, 5)):                                     # the climb did land with the child's own length
+        q = streams[4 * k_i]
+        assert int(got[k + 2, 4 * k_i, 1]) == k + 2, (k, got[:, 4 * k_i, 1])
+        seen_long += int(k + 1 > 3)                                            # child length >= 4: the field's escape value
+    assert seen_long == 2
+    assert int(visited.item()) == walk_visited(ora.export(), toks)
+    # the single-wavefront path (st_transfer_tokens): committed cursor after each stream
+    sess = samd_hip.Session(256)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for b in range(B):
+        sess.reset()
+        sess.static_walk(prod, dev(toks[:, b].copy()), T, commit=True, d_out=out)
+        assert out.cpu().tolist() == [int(got[T - 1, b, 0]), int(got[T - 1, b, 1])], b
     check_stream_major_walk(prod, toks, got, cur, int(visited.item()))
     # the single-wavefront form (the session kernel's committed transfer: st_transfer_tokens) walks the same streams
     sess = samd_hip.Session(256)
