@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     auto load_v = [&](int key0) {                      // thread handles key pair (2p, 2p+1) x one 8-wide d chunk, twice
 #pragma unroll
         for (int it = 0; it < 2; it++) {
-            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+            const int p = tid >> 3, ch = (tid & 7) + 8 * it, d0 = 8 * ch;      // a wave's instruction = 8 key rows x 128 contiguous bytes
             int ka = key0 + 2 * p, kb = ka + 1;
             ka = ka < (int)max_len ? ka : (int)max_len - 1; kb = kb < (int)max_len ? kb : (int)max_len - 1;
             vra[it] = *reinterpret_cast<const uint4 *>(vbase + (size_t)ka * ATT_D + d0);
@@ -221,10 +221,13 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
         if (t != split && active) load_k(key0);
         __syncthreads();                                   // previous tile's Vt / Pw reads are done
         if (t != split) load_v(key0);
-        // ---- stage V^T (key pairs packed per dword); rows past L + n are zero: their P is 0, but 0 x garbage could be NaN
+        // ---- stage V^T (key pairs packed per dword); rows past L + n are zero: their P is 0, but 0 x garbage could be NaN.
+        //      A wave's load instruction covers 8 key rows x 128 contiguous bytes (round 4: 32 rows x 32 bytes before -- four times the
+        //      requests for the same lines; 13.55 -> 13.25 us per layer at L = 800).  The LDS writes below are 4-way bank-conflicted in this
+        //      order; an XOR swizzle of the key-pair index that removes the conflicts costs more in address arithmetic than it saves (13.5)
 #pragma unroll
         for (int it = 0; it < 2; it++) {
-            const int p = tid & 31, ch = (tid >> 5) + 8 * it, d0 = 8 * ch;
+            const int p = tid >> 3, ch = (tid & 7) + 8 * it, d0 = 8 * ch;      // a wave's instruction = 8 key rows x 128 contiguous bytes
             const int ka = key0 + 2 * p, kb = ka + 1;
             const uint4 ra = ka < total ? vra[it] : make_uint4(0, 0, 0, 0), rb = kb < total ? vrb[it] : make_uint4(0, 0, 0, 0);
             const unsigned short *ea = reinterpret_cast<const unsigned short *>(&ra);
