@@ -319,9 +319,11 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 template <typename E>
 __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
                                                       const int *__restrict__ d_L, const int *__restrict__ d_n, WarmArgs warm, int *__restrict__ arrive) {
-    const int row = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
-    if (h >= n_heads) {                      // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
-        const unsigned a = warm_next_projection(warm, (h - n_heads) * n_q_pad + row);
+    // workgroup (head, row): the linear workgroup id is head + n_heads x row, so with 32 heads a head's merge runs on XCD head % 8 -- the XCD whose
+    // L2 its sixteen split workgroups (k_tree_attention's grid is (head, split)) just wrote the partials through (round 4; (row, head) before)
+    const int h = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
+    if (row >= n_q_pad) {                    // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
+        const unsigned a = warm_next_projection(warm, (row - n_q_pad) * n_heads + h);
         if (a == 0x9E3779B9u && n_q_pad < 0) out[0] = (E)0.f;     // never true: keeps the loads alive
         return;
     }
@@ -1037,7 +1039,7 @@ static int tree_attention_impl(const void *d_q, const void *d_k_cache, const voi
     // the output projection's warm-up rides on the split launch (the longest glue launch of a layer) or on the merge launch
     const WarmArgs none = warm_args(nullptr);
     const WarmArgs wa_split = next && next->where == 0 ? warm_args(next) : none, wa = next && next->where != 0 ? warm_args(next) : none;
-    const int warm_rows = n_q_pad > 0 ? (warm_blocks(wa) + n_q_pad - 1) / n_q_pad : 0;       // extra blockIdx.y rows of the merge launch
+    const int warm_rows = (warm_blocks(wa) + n_heads - 1) / n_heads;                         // extra blockIdx.y rows of the merge launch
     const int warm_splits = (warm_blocks(wa_split) + n_heads - 1) / n_heads;                 // extra blockIdx.y rows of the split launch
     if (!d_q || !d_k_cache || !d_v_cache || !d_out || !d_mask || !d_cache_length || !d_n || !d_workspace) { samd_set_error("samd_tree_attention: null pointer"); return SAMD_E_INVALID; }
     if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 ||
@@ -1052,12 +1054,12 @@ static int tree_attention_impl(const void *d_q, const void *d_k_cache, const voi
         hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
                            (const _Float16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
-        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
+        hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     } else {
         hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
                            (const __bf16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
-        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_q_pad, n_heads + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
+        hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     }
     LAUNCHCHK();
     return SAMD_OK;
