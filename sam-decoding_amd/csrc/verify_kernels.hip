@@ -133,6 +133,14 @@ template <> struct Mfma<BF16> {
     static __device__ __forceinline__ floatx4 run(bf16x8 a, bf16x8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
+// blockIdx.x -> query head, XCD-aware (round 4).  Workgroups go to the 8 XCDs round-robin by linear id = blockIdx.x + gridDim.x * blockIdx.y,
+// so with a head count that is a multiple of 8 all workgroups of one blockIdx.x share an XCD and its L2.  Heads are dealt to the XCDs in
+// CONTIGUOUS groups of n_heads / 8: the query heads of one KV head (grouped-query attention: Llama-3 has 4 per KV head) then read that head's
+// K / V through ONE L2 instead of four, and the merge launch (same mapping) finds a head's partials in the L2 that wrote them.
+__device__ __forceinline__ int att_head_of_block(int bx, int n_heads) {
+    return (n_heads & 7) == 0 ? (bx & 7) * (n_heads >> 3) + (bx >> 3) : bx;
+}
+
 template <typename TT>
 __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
                                                         const typename TT::elem *__restrict__ vc, float *__restrict__ ws,
@@ -144,7 +152,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     __shared__ __attribute__((aligned(16))) E Vt[ATT_D * VT_STRIDE];
     __shared__ __attribute__((aligned(16))) E Pw[4 * 16 * P_STRIDE];
 
-    const int h = blockIdx.x, split = blockIdx.y;
+    const int h = att_head_of_block(blockIdx.x, n_heads), split = blockIdx.y;
     if (split >= ATT_SPLITS) {               // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
         const unsigned a = warm_next_projection(warm, (split - ATT_SPLITS) * n_heads + h);
         if (a == 0x9E3779B9u && n_q_pad < 0) ws[0] = 0.f;         // never true: keeps the loads alive
@@ -319,9 +327,9 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 template <typename E>
 __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ ws, E *__restrict__ out, int n_q_pad, int n_heads,
                                                       const int *__restrict__ d_L, const int *__restrict__ d_n, WarmArgs warm, int *__restrict__ arrive) {
-    // workgroup (head, row): the linear workgroup id is head + n_heads x row, so with 32 heads a head's merge runs on XCD head % 8 -- the XCD whose
-    // L2 its sixteen split workgroups (k_tree_attention's grid is (head, split)) just wrote the partials through (round 4; (row, head) before)
-    const int h = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
+    // workgroup (head slot, row) with k_tree_attention's head mapping (att_head_of_block): a head's merge runs on the XCD whose L2 its sixteen
+    // split workgroups just wrote the partials through (round 4; the grid was (row, head) before)
+    const int h = att_head_of_block(blockIdx.x, n_heads), row = blockIdx.y, d = threadIdx.x;
     if (row >= n_q_pad) {                    // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
         const unsigned a = warm_next_projection(warm, (row - n_q_pad) * n_heads + h);
         if (a == 0x9E3779B9u && n_q_pad < 0) out[0] = (E)0.f;     // never true: keeps the loads alive

@@ -7,10 +7,11 @@ import torch
 import samd_hip
 from samd_hip import _ptr, check, lib
 
-Ls = [int(a) for a in sys.argv[1:]] or [800]
+Ls = [int(a) for a in sys.argv[1:] if a.isdigit()] or [800]
 H, D, layers, max_len = 32, 128, 32, 2048
+Hkv = 8 if "gqa" in sys.argv[1:] else H          # "gqa": Llama-3-8B geometry (4 query heads per KV head)
 Lib = lib()
-kv = (torch.randn((layers, 2, H, max_len, D), device="cuda") * 0.5).half()
+kv = (torch.randn((layers, 2, Hkv, max_len, D), device="cuda") * 0.5).half()
 s0 = torch.cuda.Stream()
 st = samd_hip.C.c_void_p(s0.cuda_stream)
 mask = torch.tensor([(1 << (i + 1)) - 1 if i < 63 else -1 for i in range(64)], dtype=torch.int64, device="cuda")
@@ -24,7 +25,7 @@ for L0 in Ls:
 
         def run():
             for li in range(layers):
-                check(Lib.samd_tree_attention(_ptr(q), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, H, D, max_len, _ptr(mask), _ptr(d_L), _ptr(d_n),
+                check(Lib.samd_tree_attention(_ptr(q), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, Hkv, D, max_len, _ptr(mask), _ptr(d_L), _ptr(d_n),
                                               1.0 / math.sqrt(D), _ptr(ws), ws.numel(), st))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s0):
@@ -37,4 +38,4 @@ for L0 in Ls:
                 g.replay()
             s0.synchronize()
         row.append((time.perf_counter() - t0) / 40 * 1e6 / layers)
-    print(f"L={L0}: 8 rows {row[0]:.2f} us/layer, 16 rows {row[1]:.2f}")
+    print(f"H={H} Hkv={Hkv} L={L0}: 8 rows {row[0]:.2f} us/layer, 16 rows {row[1]:.2f}")
