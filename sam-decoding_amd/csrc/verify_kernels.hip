@@ -338,12 +338,16 @@ __global__ __launch_bounds__(128) void k_attn_combine(const float *__restrict__ 
     // every split's (m, l, O[d]) is loaded before anything is consumed, and before the two scalars that say how many
     // splits ran are known: one memory round trip for the whole kernel.  Splits that did not run hold older partials
     // (the workspace always has ATT_SPLITS slots); they are ignored below.
+    // (m, l) of split s: ONE 8-byte load by lane s of each wave, handed round by shuffles -- as 32 wave-wide loads of one address each they
+    // were two thirds of this launch's requests, and a latency-bound launch pays per request (profiles/r04_attention.md section 2d)
     float mv[ATT_SPLITS], lv[ATT_SPLITS], pv[ATT_SPLITS];
+    const int lane = d & 63;
+    float2 ml = make_float2(-INFINITY, 0.f);
+    if (lane < ATT_SPLITS) ml = *reinterpret_cast<const float2 *>(ws + (((size_t)lane * n_q_pad + row) * n_heads + h) * (ATT_D + 2) + ATT_D);
 #pragma unroll
-    for (int s = 0; s < ATT_SPLITS; s++) {
-        const float *p = ws + (((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
-        mv[s] = p[ATT_D]; lv[s] = p[ATT_D + 1]; pv[s] = p[d];
-    }
+    for (int s = 0; s < ATT_SPLITS; s++) pv[s] = ws[(((size_t)s * n_q_pad + row) * n_heads + h) * (ATT_D + 2) + d];
+#pragma unroll
+    for (int s = 0; s < ATT_SPLITS; s++) { mv[s] = __shfl(ml.x, s); lv[s] = __shfl(ml.y, s); }
     int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
     E *dst = out + ((size_t)row * n_heads + h) * ATT_D + d;
     float res = 0.f;
