@@ -227,13 +227,15 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
 struct NormArgs { const float *ssq; const void *g; int tiles; float inv_hidden; float eps; };
 
 // the partial sums are REQUESTED before the first weight chunks (hand-issued loads, so that the counted waits of the stream stay exact) and
-// added up once those chunks are in flight: NORM_NS loads per thread whatever the tile count (clamped + zeroed past the end)
+// added up once those chunks are in flight: up to NORM_NS loads per thread (rounds past the tile count are skipped, the last one is clamped + zeroed)
 #define NORM_NS 16
 template <int NT>
 __device__ __forceinline__ void norm_issue(const NormArgs &na, float (&sv)[NORM_NS]) {
     const int tid = threadIdx.x, row = tid & 15, p = tid >> 4;
 #pragma unroll
     for (int k = 0; k < NORM_NS; k++) {
+        sv[k] = 0.f;
+        if ((NT / 16) * k >= na.tiles) continue;             // (uniform) nothing of this round exists: K = 4096 needs 8 of the 16 rounds
         int t = p + (NT / 16) * k;
         t = t < na.tiles ? t : na.tiles - 1;
         const float *src = na.ssq + (size_t)t * 16 + row;
@@ -241,8 +243,15 @@ __device__ __forceinline__ void norm_issue(const NormArgs &na, float (&sv)[NORM_
     }
 }
 template <int NT>
-__device__ __forceinline__ void norm_finish(const NormArgs &na, const float (&sv)[NORM_NS], float *part /* [NT / 16][16] */, float *rs /* [16] */) {
+__device__ __forceinline__ void norm_finish(const NormArgs &na, float (&sv)[NORM_NS], float *part /* [NT / 16][16] */, float *rs /* [16] */) {
     const int tid = threadIdx.x, row = tid & 15, p = tid >> 4;
+    // the caller's counted wait has just retired the loads of norm_issue.  The compiler does not know that those asm statements were
+    // asynchronous: this statement re-defines their destinations HERE, so that no use can be scheduled above the wait and the registers
+    // stay reserved until it (without it a build with branches around the loads consumed a register one instruction after its load was
+    // issued and recycled it as an address while the load was in flight)
+    static_assert(NORM_NS == 16, "");
+    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]),
+                      "+v"(sv[8]), "+v"(sv[9]), "+v"(sv[10]), "+v"(sv[11]), "+v"(sv[12]), "+v"(sv[13]), "+v"(sv[14]), "+v"(sv[15]) : : "memory");
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NORM_NS; k++) s += (p + (NT / 16) * k < na.tiles) ? sv[k] : 0.f;
@@ -372,6 +381,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES /
 #pragma unroll
             for (int i = 0; i < XV; i++) {
                 const int slot = tid + NT * i, row = slot >> 5;
+                // (re-defined here, behind the counted wait: the compiler does not know that the asm loads that produced them were asynchronous)
+                asm volatile("" : "+v"(xr[d][i]), "+v"(gr[d][i]) : : "memory");
                 const u32x4 v = norm_scale8<E>(xr[d][i], gr[d][i], norm_rs[row]);
                 *reinterpret_cast<u32x4 *>(&xs[buf][0][0] + (size_t)slot * 8) = v;
             }
@@ -581,6 +592,8 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
 #pragma unroll
                 for (int i = 0; i < XV; i++) {
                     const int slot = tid + NT * i, row = slot >> 5;
+                    // (re-defined here, behind the counted wait: the compiler does not know that the asm loads that produced them were asynchronous)
+                    asm volatile("" : "+v"(xr[d][i]), "+v"(gr[d][i]) : : "memory");
                     const u32x4 v = norm_scale8<E>(xr[d][i], gr[d][i], norm_rs[row]);
                     *reinterpret_cast<u32x4 *>(&xs[buf][0][0] + (size_t)slot * 8) = v;
                 }
