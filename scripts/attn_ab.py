@@ -1,5 +1,5 @@
 """attn_ab.py -- samd_tree_attention (split launch + merge launch) alone, 32 layers with their own K/V in one hipGraph, microseconds per layer
-at the 8- and 16-row buckets; for same-box A/Bs of two builds of the library (scripts/ab_lib.sh).   usage: python scripts/attn_ab.py [L ...]"""
+at the 8-, 16-, 32- and 64-row buckets; for same-box A/Bs of two builds of the library (scripts/ab_lib.sh).   usage: python scripts/attn_ab.py [L ...]"""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "sam-decoding_amd")]
@@ -17,9 +17,9 @@ st = samd_hip.C.c_void_p(s0.cuda_stream)
 mask = torch.tensor([(1 << (i + 1)) - 1 if i < 63 else -1 for i in range(64)], dtype=torch.int64, device="cuda")
 for L0 in Ls:
     row = []
-    for R in (8, 16):
-        q = torch.randn((16, H, D), device="cuda").half()
-        out = torch.zeros((16, H, D), device="cuda", dtype=torch.float16)
+    for R in (8, 16, 32, 64):
+        q = torch.randn((64, H, D), device="cuda").half()
+        out = torch.zeros((64, H, D), device="cuda", dtype=torch.float16)
         d_L = torch.tensor([L0], dtype=torch.int32, device="cuda"); d_n = torch.tensor([R - 1], dtype=torch.int32, device="cuda")
         ws = torch.zeros(Lib.samd_tree_attention_workspace(R, H, D), dtype=torch.uint8, device="cuda")
 
@@ -38,4 +38,4 @@ for L0 in Ls:
                 g.replay()
             s0.synchronize()
         row.append((time.perf_counter() - t0) / 40 * 1e6 / layers)
-    print(f"H={H} Hkv={Hkv} L={L0}: 8 rows {row[0]:.2f} us/layer, 16 rows {row[1]:.2f}")
+    print(f"H={H} Hkv={Hkv} L={L0}: 8 rows {row[0]:.2f} us/layer, 16 rows {row[1]:.2f}, 32 rows {row[2]:.2f}, 64 rows {row[3]:.2f}")
