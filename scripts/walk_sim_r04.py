@@ -1,6 +1,7 @@
 """walk_sim_r04.py -- CPU replay of bench.py's batched-walk workload through round 4's transition rule (flagged chain entries,
 root-child hash with half words): HBM requests by kind per visited state and per stream, dependent rounds per wave.  See
-profiles/r04_walk.md.   usage: python scripts/walk_sim_r04.py [corpus_tokens] [cursors] [half-word entries]"""
+profiles/r04_walk.md.  (It models the per-child hashed blocks of the first half of round 4; with the bigram table that replaced them the
+"root(L2)" lines below cost no request at all and probes of small root children are table look-ups too.)   usage: python scripts/walk_sim_r04.py [corpus_tokens] [cursors] [half-word entries]"""
 import os, sys, collections
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

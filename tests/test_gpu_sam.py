@@ -140,12 +140,13 @@ def test_static_walk_long_runs_use_chain_words(base):
 
 @pytest.mark.parametrize("vocab", [1000, 32767, 32768, 90000])
 def test_static_walk_known_climbs(vocab):
-    """round 4 (csrc/sam_device.h "Round 4"): a chain entry whose top bit is clear says that its state has ONE edge and that its suffix
-    link is a child of the root; a cursor holding the word resolves a mismatch there through root16[previous token] and one probe of
-    that child's hashed block -- without loading the state or its link.  Exercised here: climbs that end at the root (miss), climbs
-    whose probe HITS (the offending token does follow the previous token elsewhere), links to root children of degree <= 5 (no block:
-    node path), mismatches on the first / a middle / the last entry of a word and right after a half word from the hash, token ids at
-    the top of the vocabulary (32766 in 15-bit entries; vocab 32768 and 90000 take the 31-bit form), and the visited-state count.
+    """round 4 (csrc/sam_device.h, csrc/samd_common.h BIGRAM TABLE): a chain entry whose top bit is clear says that its state has ONE edge and
+    that its suffix link is a child of the root; a cursor holding the word resolves a mismatch there with one look-up of (previous token,
+    token) in the bigram table -- without loading the state or its link.  Exercised here: climbs that end at the root (miss), climbs
+    whose look-up HITS (the offending token does follow the previous token elsewhere), root children of every degree (1 .. 13 edges: all
+    of them live in the table), mismatches on the first / a middle / the last entry of a word and right after a half word from the table,
+    token ids at the top of the vocabulary (32766 in 15-bit entries; vocab 32768 and 90000 take the 31-bit form), and the visited-state
+    count.
     Every (index, length) against the oracle."""
     rng = np.random.default_rng(vocab)
     ids = rng.permutation(np.arange(3, vocab - 2))[:400].tolist()
