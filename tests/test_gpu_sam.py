@@ -251,6 +251,81 @@ def test_static_walk_climb_into_long_root_child(base):
         assert out.cpu().tolist() == [int(got[T - 1, b, 0]), int(got[T - 1, b, 1])], b
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_static_walk_random_corpora(seed):
+    """random small corpora of every shape the bigram table has to get right (vocabularies from 40 ids to 70000 -- both entry forms --,
+    documents made of shared segments so that root children range from one edge to dozens, tokens that always follow the same run),
+    random streams: corpus copies with noise, unseen in-vocabulary ids, out-of-vocabulary and negative ids, restarts from non-root
+    cursors of an earlier launch.  Every (index, length), the committed cursors and the visited-state count against the oracle
+    (transfer_state, static_sam.py:98-107), the stream-major kernel and the session's single-wavefront walk on the same streams."""
+    rng = np.random.default_rng(1000 + seed)
+    vocab = [40, 700, 5000, 32767, 32768, 70000][seed % 6]
+    ids = rng.choice(np.arange(3, vocab), size=min(vocab - 3, 300), replace=False)
+    segs = [rng.choice(ids, size=int(rng.integers(2, 12))).tolist() for _ in range(30)]
+    docs = []
+    for _ in range(int(rng.integers(8, 40))):
+        d = []
+        for _ in range(int(rng.integers(1, 6))):
+            d += segs[int(rng.integers(0, len(segs)))]
+            if rng.random() < 0.3:
+                d.append(int(rng.choice(ids)))
+        docs.append(d)
+    docs += [[int(t)] for t in ids[::5]]
+    prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    ora = O.StaticSAM.build(docs, 2)
+    T, B = 24, 96
+    toks = np.zeros((T, B), dtype=np.int64)
+    for b in range(B):
+        q = []
+        while len(q) < T:
+            d = docs[int(rng.integers(0, len(docs)))]
+            a = int(rng.integers(0, len(d)))
+            q += d[a:a + int(rng.integers(1, 10))]
+            r = rng.random()
+            if r < 0.25:
+                q.append(int(rng.choice(ids)))                       # a token of the corpus, out of place
+            elif r < 0.35:
+                q.append(int(rng.integers(3, vocab)))                # possibly never seen
+            elif r < 0.40:
+                q.append(int(rng.integers(vocab, vocab + 5)))        # out of vocabulary
+            elif r < 0.43:
+                q.append(-1)
+        toks[:, b] = q[:T]
+    toks = toks.astype(np.int32)
+    cur = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    trace = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.walk(cur, dev(toks), commit=True, trace=trace)
+    prod.walk(torch.zeros_like(cur), dev(toks), commit=False, visited=visited)
+    got, fin = trace.cpu().numpy(), cur.cpu().numpy()
+    want_fin = np.zeros((B, 2), dtype=np.int64)
+    for b in range(B):
+        i, l = 0, 0
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[t, b]))
+            assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (seed, b, t)
+        want_fin[b] = (i, l)
+    assert (fin == want_fin).all()
+    assert int(visited.item()) == walk_visited(ora.export(), toks)
+    check_stream_major_walk(prod, toks, got, cur, int(visited.item()))
+    # a second launch continues from the committed cursors (states of any depth, root children among them)
+    toks2 = toks[::-1].copy()
+    trace2 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    prod.walk(cur, dev(toks2), commit=True, trace=trace2)
+    got2 = trace2.cpu().numpy()
+    for b in range(0, B, 2):
+        i, l = int(want_fin[b, 0]), int(want_fin[b, 1])
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks2[t, b]))
+            assert (int(got2[t, b, 0]), int(got2[t, b, 1])) == (i, l), (seed, b, t)
+    sess = samd_hip.Session(256)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for b in range(0, B, 8):
+        sess.reset()
+        sess.static_walk(prod, dev(toks[:, b].copy()), T, commit=True, d_out=out)
+        assert out.cpu().tolist() == [int(want_fin[b, 0]), int(want_fin[b, 1])], (seed, b)
+
+
 def test_static_walk_empty_and_ragged():
     prod = samd_hip.StaticAutomaton.build([[3, 4, 5, 3, 4, 6]], 2, 0).upload()
     cur = torch.zeros((0, 2), dtype=torch.int32, device="cuda")
