@@ -890,6 +890,7 @@ def main():
                                    f"len_bias 0, K 8; prompts 512 tokens, max_new_tokens 512, max_cache_len {max_len}",
                        "model_shape": args.model, "layers": mcfg["num_hidden_layers"], "corpus_tokens": int(args.corpus_tokens),
                        "static_sam_states": int(sam_info["n_states"]), "static_sam_bytes": int(sam_info["device_bytes"]),
+                       "static_sam_derived_bytes": auto.derived_info(),
                        "acceptance": args.acceptance, "variant": args.variant, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
                        "hipgraphs": not args.no_graphs},
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),

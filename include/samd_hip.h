@@ -96,6 +96,10 @@ int samd_static_upload(samd_static_t *sam);
 /* out: [0]=n_states [1]=n_edges [2]=n_spill_edges [3]=vocab (root table size) [4]=device bytes [5]=kind
  *      [6]=n_text [7]=uploaded */
 int samd_static_info(const samd_static_t *sam, int64_t out[8]);
+/* what the upload DERIVES on the device next to the image (csrc/samd_common.h): out[0] = bytes of the chain words, out[1] = bytes of the
+ * bigram table with its root entries and child bitmap, out[2] = bytes of the top-k count table, out[3] = slots of the bigram table
+ * (a power of two, >= 16 x the number of root-child edges by default: SAMD_BIGRAM_SLOTS_PER_PAIR); zeros for what was not derived. */
+int samd_static_derived_info(const samd_static_t *sam, int64_t out[4]);
 /* host read-back of the built automaton (tests / converters): arrays sized from samd_static_info.
  * Edges come state-major in STORED order: the first min(deg,8) are the top-k order of
  * init_topk_next (SO/sam/static_sam.py:140-146), the rest ascending by token. */

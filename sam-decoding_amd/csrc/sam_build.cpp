@@ -295,6 +295,15 @@ int samd_static_info(const samd_static_t *s, int64_t out[8]) {
     return SAMD_OK;
 }
 
+int samd_static_derived_info(const samd_static_t *s, int64_t out[4]) {
+    if (!s || !out) return SAMD_E_INVALID;
+    out[0] = s->d_chain ? s->n_states * 16 : 0;
+    out[1] = s->d_d1hash ? s->n_d1hash * 16 + s->vocab * 16 + ((s->vocab + 31) / 32) * 4 : 0;
+    out[2] = s->d_topk_cnt ? s->n_states * (int64_t)SAMD_TOPK * 4 : 0;
+    out[3] = s->d_d1hash ? s->n_d1hash : 0;
+    return SAMD_OK;
+}
+
 int samd_static_export(const samd_static_t *s, int32_t *h_link, int32_t *h_length, int32_t *h_aux, int32_t *h_deg,
                        int32_t *h_edge_tok, int32_t *h_edge_dst) {
     if (!s || !s->h_nodes) { samd_set_error("samd_static_export: no host image"); return SAMD_E_INVALID; }

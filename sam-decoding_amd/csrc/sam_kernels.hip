@@ -519,8 +519,13 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st) {
         if (hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
     }
     (void)hipFree(d_total);
+    // slots per pair: a lock-step wave pays a second probe round whenever ANY of its 64 lanes collides, so the table is kept very sparse --
+    // measured on the bench automaton (4.5 M pairs, same box): >= 2 x pairs 0.188 ms per launch, 4 x 0.176, 8 x 0.170, 16 x 0.166 (2 GB).
+    // SAMD_BIGRAM_SLOTS_PER_PAIR overrides (2 .. 64); whatever it says, the table stays under 8 GB as long as 2 x pairs fit in that
+    static const int per_pair = [] { const char *e = getenv("SAMD_BIGRAM_SLOTS_PER_PAIR"); const int v = e ? atoi(e) : 16; return v < 2 ? 2 : (v > 64 ? 64 : v); }();
     long long slots = 1024;
-    while (slots < 4 * (long long)total) slots <<= 1;                             // load factor in (1/8, 1/4]
+    while (slots < per_pair * (long long)total) slots <<= 1;                       // load factor in (1 / 2 per_pair, 1 / per_pair]
+    while (slots * 16 > (8ll << 30) && slots >= 4 * (long long)total) slots >>= 1;
     if (rc == SAMD_OK && slots > (1ll << 31)) rc = -1;                            // the mask does not fit 32 bits: go without the table
     const size_t bit_bytes = (size_t)((vocab + 31) / 32) * 4;
     if (rc == SAMD_OK) {

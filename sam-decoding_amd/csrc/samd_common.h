@@ -85,7 +85,7 @@ struct StaticDev {
     //   entry, vocab <= 32767 (chain_w 8): {a | b << 15 | lb << 30, dst, chain[dst].x, chain[dst].y}
     //   entry, larger vocabularies (chain_w 4): {a | (lb & 1) << 31, b | (lb >> 1) << 31, dst, chain[dst].x}
     //   lb = min(length[child of a] - 1, 3): what a climbing cursor's match length becomes there (3 = read root16[a].w); empty = all-ones;
-    //   slot = samd_bigram_hash(a, b) & bigram_mask, linear probing, load factor <= 1/4.
+    //   slot = samd_bigram_hash(a, b) & bigram_mask, linear probing, load factor <= 1/16 by default (sam_kernels.hip derive_root_hash: why).
     // root16[tok] = {dst, 0, 0, length[dst]} (dst = -1: no child).
     const uint4 *root16;
     const uint4 *bigram;

@@ -73,6 +73,7 @@ _PROTOS = {
     "samd_static_free": (None, [_VP]),
     "samd_static_upload": (C.c_int, [_VP]),
     "samd_static_info": (C.c_int, [_VP, _VP]),
+    "samd_static_derived_info": (C.c_int, [_VP, _VP]),
     "samd_static_export": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_static_device_image": (C.c_int, [_VP, _VP, _VP]),
     "samd_static_alloc_like": (C.c_int, [_VP, _VP]),
@@ -305,6 +306,13 @@ class StaticAutomaton:
         check(lib().samd_static_info(self._h, out))
         keys = ("n_states", "n_edges", "n_spill", "vocab", "device_bytes", "kind", "n_text", "uploaded")
         return dict(zip(keys, list(out)))
+
+    def derived_info(self):
+        """what upload() derived on the device next to the image: bytes of the chain words, of the bigram table (+ root entries, child
+        bitmap) and of the top-k counts, and the bigram table's slots (include/samd_hip.h samd_static_derived_info)"""
+        out = (C.c_int64 * 4)()
+        check(lib().samd_static_derived_info(self._h, out))
+        return dict(zip(("chain_bytes", "bigram_bytes", "topk_count_bytes", "bigram_slots"), list(out)))
 
     def export(self):
         i = self.info()
