@@ -529,8 +529,14 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st) {
     if (rc == SAMD_OK && slots > (1ll << 31)) rc = -1;                            // the mask does not fit 32 bits: go without the table
     const size_t bit_bytes = (size_t)((vocab + 31) / 32) * 4;
     if (rc == SAMD_OK) {
-        if (hipMalloc(&s->d_root16, (size_t)vocab * 16) != hipSuccess || hipMalloc(&s->d_d1hash, (size_t)slots * 16) != hipSuccess ||
-            hipMalloc(&s->d_rc_bits, bit_bytes) != hipSuccess) rc = SAMD_E_HIP;
+        // the table is an accelerator, not part of the image: when the device cannot spare its preferred size, halve it down to 2 slots per pair,
+        // and when even that does not fit go without it (walks then resolve root children through their nodes)
+        while (hipMalloc(&s->d_d1hash, (size_t)slots * 16) != hipSuccess) {
+            s->d_d1hash = nullptr; (void)hipGetLastError();
+            if (slots < 4 * (long long)total || slots <= 1024) { rc = -1; break; }
+            slots >>= 1;
+        }
+        if (rc == SAMD_OK && (hipMalloc(&s->d_root16, (size_t)vocab * 16) != hipSuccess || hipMalloc(&s->d_rc_bits, bit_bytes) != hipSuccess)) { (void)hipGetLastError(); rc = -1; }
         if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)slots * 16, st) != hipSuccess || hipMemsetAsync(s->d_rc_bits, 0, bit_bytes, st) != hipSuccess)) rc = SAMD_E_HIP;
         if (rc == SAMD_OK) {
             hipLaunchKernelGGL(k_bg_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, (const uint4 *)s->d_chain, (uint4 *)s->d_root16,
