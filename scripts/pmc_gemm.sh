@@ -4,10 +4,10 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_gemm
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o g -- python3 scripts/gemm_probe.py > $OUT/trace.txt 2>&1
+timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o g -- python3 scripts/gemm_probe.py > $OUT/trace.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$tag -o g -- python3 scripts/gemm_probe.py > $OUT/$tag.txt 2>&1
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$tag -o g -- python3 scripts/gemm_probe.py > $OUT/$tag.txt 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json
