@@ -563,12 +563,25 @@ def launch_command(n_gpus, argv, port=None):
             "--master-port", str(port), os.path.abspath(__file__)] + rest
 
 
-def launch_ranks(n_gpus, argv, dry=False):
+def visible_gpus():
+    """GPUs this process could hand to its ranks.  torch.cuda.device_count() counts devices without creating a HIP context on this
+    image, so the launcher may still spawn afterwards (a process that touched the GPU must never be replaced, and is not)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(n_gpus, argv, dry=False, need_gpus=True):
     import subprocess
     cmd = launch_command(n_gpus, argv)
     if dry:
         print(json.dumps({"launch": cmd, "n_gpus": n_gpus}), flush=True)
         return 0
+    if need_gpus:
+        have = visible_gpus()
+        if have < n_gpus:
+            # one clear line instead of N ranks dying in torch.cuda.set_device (evaluation/eval_vicuna.py:39-48 asserts the same way)
+            print(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this node shows {have}; nothing was launched", file=sys.stderr, flush=True)
+            return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
     for line in child.stdout:                              # rank 0 prints the one JSON line; everything else passes through too
@@ -590,7 +603,8 @@ def launch_selftest(args):
         dist.init_process_group("gloo")
     total, dt_max, per_rank = parallel.reduce_throughput(100 * (rank + 1), 1.0 + rank, extra={"static_sam_distribution_ms": 5.0 + rank})
     if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": world, "gpus_flag": args.gpus, "value": total / dt_max, "per_rank": per_rank}), flush=True)
+        print(json.dumps({"selftest": True, "n_gpus": world, "gpus_flag": args.gpus, "value": total / dt_max, "per_rank": per_rank,
+                          "rccl_ranks_seen": len(per_rank)}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -628,7 +642,7 @@ def main():
     # replaced once anything touched the GPU, and nothing below has yet), relay rank 0's JSON line, exit with the child's code.
     # The reference does the same split with Ray actors on contiguous question chunks (evaluation/eval_vicuna.py:39-68).
     if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], dry=args.dry_launch))
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], dry=args.dry_launch, need_gpus=not args.launch_selftest))
     if args.dry_launch:
         print(json.dumps({"launch": None, "reason": "single process: --gpus 1 or already inside a launcher"}), flush=True)
         return
@@ -896,6 +910,8 @@ def main():
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
             "per_rank": [dict(r, ms_per_step=round(r["seconds"] / args.steps * 1e3, 4)) for r in per_rank], "bucket_histogram": bucket_hist,
+            # size of the all_gather that produced `value` (parallel.reduce_throughput): a SCALE record is checkable mechanically -- it must equal n_gpus
+            "rccl_ranks_seen": len(per_rank),
             # rank 0's timed region taken apart: request turnovers that fell into it (engine.start, clocked on the host), the decode steps
             # without them, and what the same steps cost as back-to-back graph replays of their row buckets (step_breakdown_by_rows) --
             # the difference is what the host adds between replays (report wait, bucket choice, launch)

@@ -44,6 +44,18 @@ def test_two_ranks_are_spawned_reduced_and_relayed():
     assert d["per_rank"] == [{"rank": 0, "tokens": 100, "seconds": 1.0, "static_sam_distribution_ms": 5.0},
                              {"rank": 1, "tokens": 200, "seconds": 2.0, "static_sam_distribution_ms": 6.0}]    # every rank's own figures
     assert abs(d["value"] - 300 / 2.0) < 1e-9                                 # SUM of tokens / MAX of time
+    assert d["rccl_ranks_seen"] == 2                                          # the size of the all_gather behind `value`
+
+
+def test_more_ranks_than_gpus_is_one_clear_line_and_nothing_is_spawned():
+    """VERDICT r04 #9: `--gpus N` on a node with fewer GPUs must not start N ranks that die one by one (this container has none)."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip("this node has 8 GPUs")
+    r = _run("--gpus", "8", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 2 and "needs 8 visible GPUs" in r.stderr and "nothing was launched" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_child_failure_becomes_the_exit_code():
