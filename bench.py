@@ -221,23 +221,33 @@ def walk_source_sha16():
     return h.hexdigest()[:16]
 
 
-def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
-    """the SAM traversal kernel in batched-streams form: B independent cursors x T tokens per launch."""
+WALK_BIGRAM_SLOTS_PER_PAIR = 16       # the batched walk's table sparsity (profiles/r04_walk.md); the product default is 4 (include/samd_hip.h)
+
+
+def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=WALK_BIGRAM_SLOTS_PER_PAIR, vocab=VOCAB):
+    """the SAM traversal kernel in batched-streams form: B independent cursors x T tokens per launch.  The launch asks for the bigram
+    table at `slots_per_pair` (samd_static_set_bigram_slots: a lock-step wave pays for any lane's collision; a request's one-cursor
+    walks do not care, so the decode loop above ran on the 4-per-pair default) and the bytes that costs are reported with it."""
     import torch
+    sam.set_bigram_slots(slots_per_pair)
+    derived = sam.derived_info()
     n_docs, doc_len = docs.shape
     # token streams: copied corpus spans with 10 % noise, time-major [T, B]
     d = rng.integers(0, n_docs, B)
     s = rng.integers(0, doc_len - T, B)
     toks = docs[d[None, :], (s[None, :] + np.arange(T)[:, None])]
     noise = rng.random((T, B)) < 0.10
-    toks = np.where(noise, rng.integers(3, VOCAB, (T, B)), toks).astype(np.int32)
+    toks = np.where(noise, rng.integers(3, vocab, (T, B)), toks).astype(np.int32)
     d_toks = torch.from_numpy(np.ascontiguousarray(toks)).cuda()
     cursors = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
     visited = torch.zeros(1, dtype=torch.int64, device="cuda")
-    sam.walk(cursors, d_toks, commit=False, visited=visited)
+    # the timed launch RETURNS its result, as the reference's lookup does (static_sam.py:122-125): every stream's final (index, length)
+    # goes to `result` (8 B per stream stored; rounds 1-4 timed a launch that dropped them); the cursors stay, so every launch does the same work
+    result = torch.empty((B, 2), dtype=torch.int32, device="cuda")
+    sam.lookup_batch(cursors, d_toks, result, visited=visited)
     torch.cuda.synchronize()
     n_visited = int(visited.item())
-    ms = hip_time_ms(lambda: sam.walk(cursors, d_toks, commit=False), iters)
+    ms = hip_time_ms(lambda: sam.lookup_batch(cursors, d_toks, result), iters)
     alg_bytes = 16.0 * n_visited
     gbps = alg_bytes / (ms * 1e-3) / 1e9
     # HBM traffic per launch from the PMC passes of the same kernel and configuration (collected separately with
@@ -254,6 +264,8 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None):
         pass
     return dict(bound="hbm", kernel="k_static_walk", achieved=round(gbps, 2), peak=HBM_PEAK_GBPS, unit="GB/s",
                 frac=round(gbps / HBM_PEAK_GBPS, 5), traffic=traffic, traffic_from=traffic_from, launch_ms=round(ms, 4), streams=B, tokens_per_stream=T,
+                result_bytes_written_per_launch=8 * B, entry_point="samd_static_lookup_batch (out-of-place: the walk's result is stored)",
+                bigram_slots_per_pair=slots_per_pair, derived_bytes=derived,
                 visited_states=n_visited, alg_bytes_per_launch=int(alg_bytes), transitions_per_s=round(B * T / (ms * 1e-3), 1),
                 line_bytes_per_launch=int(64 * n_visited), line_gbps=round(64.0 * n_visited / (ms * 1e-3) / 1e9, 2),
                 # the walk is bound by the rate of scattered 64-byte requests (scripts/hbm_probe.hip: ~48.6 G/s whatever their size);
@@ -678,6 +690,7 @@ def main():
     torch.cuda.synchronize()
     broadcast_ms = (time.perf_counter() - t_bc) * 1e3          # world > 1: RCCL broadcast of the image + adopt; world 1: host -> HBM upload
     sam_info = auto.info()
+    derived_decode = auto.derived_info()                       # what the decode loop runs on: the default table (4 slots per pair)
     sam = SO.sam.StaticSAM._from_automaton(auto)
 
     mcfg = dict(VICUNA_7B if args.model == "vicuna-7b" else LLAMA3_8B)
@@ -904,7 +917,7 @@ def main():
                                    f"len_bias 0, K 8; prompts 512 tokens, max_new_tokens 512, max_cache_len {max_len}",
                        "model_shape": args.model, "layers": mcfg["num_hidden_layers"], "corpus_tokens": int(args.corpus_tokens),
                        "static_sam_states": int(sam_info["n_states"]), "static_sam_bytes": int(sam_info["device_bytes"]),
-                       "static_sam_derived_bytes": auto.derived_info(),
+                       "static_sam_derived_bytes": derived_decode,
                        "acceptance": args.acceptance, "variant": args.variant, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
                        "hipgraphs": not args.no_graphs},
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),

@@ -98,8 +98,14 @@ int samd_static_upload(samd_static_t *sam);
 int samd_static_info(const samd_static_t *sam, int64_t out[8]);
 /* what the upload DERIVES on the device next to the image (csrc/samd_common.h): out[0] = bytes of the chain words, out[1] = bytes of the
  * bigram table with its root entries and child bitmap, out[2] = bytes of the top-k count table, out[3] = slots of the bigram table
- * (a power of two, >= 16 x the number of root-child edges by default: SAMD_BIGRAM_SLOTS_PER_PAIR); zeros for what was not derived. */
+ * (a power of two, >= 4 x the number of root-child edges by default: SAMD_BIGRAM_SLOTS_PER_PAIR / samd_static_set_bigram_slots); zeros for
+ * what was not derived.  These bytes are resident per GPU replica NEXT to samd_static_info's device bytes (the image). */
 int samd_static_derived_info(const samd_static_t *sam, int64_t out[4]);
+/* re-size the bigram table of an uploaded automaton: slots_per_pair in 2 .. 64 (0 = the default, 4).  A tuning entry with no reference
+ * counterpart: a sparser table only helps the BATCHED walk (samd_static_walk* / samd_static_lookup_batch: 64 cursors in lock-step pay a
+ * second probe round when any collides -- 16 per pair measured best, profiles/r04_walk.md); one-cursor walks of a session are
+ * indifferent.  Capped at 8 GB and at an eighth of the free device memory; results are identical at every size.  Blocking. */
+int samd_static_set_bigram_slots(samd_static_t *sam, int32_t slots_per_pair, void *stream);
 /* host read-back of the built automaton (tests / converters): arrays sized from samd_static_info.
  * Edges come state-major in STORED order: the first min(deg,8) are the top-k order of
  * init_topk_next (SO/sam/static_sam.py:140-146), the rest ascending by token. */
@@ -130,6 +136,13 @@ int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t
  * device).  bench.py multiplies it by 16 B to get the algorithmic bytes. */
 int samd_static_walk_counted(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
                              int32_t commit, uint64_t *d_visited, void *stream);
+
+/* StaticSAM.lookup over B cursors -- SO/sam/static_sam.py:122-125: the pair transfer_state reaches is RETURNED, cur_index / cur_length
+ * stay.  d_cursors int32 [B][2] (read only), d_tokens int32 [T][B] (time-major; T = 1 is the reference's lookup, T > 1 the same over a
+ * token run), d_out int32 [B][2] = the (index, length) every stream ends on.  d_visited (optional, u64 on the device) accumulates the
+ * visited states.  This is the launch bench.py times for `roofline`: it produces the walk's result (8 B per stream written). */
+int samd_static_lookup_batch(const samd_static_t *sam, const int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
+                             int32_t *d_out, uint64_t *d_visited, void *stream);
 
 /* The same walk over STREAM-MAJOR tokens: d_tokens int32 [B][T] (stream b's tokens contiguous -- what a caller that holds B token
  * sequences has), d_trace (optional) int32 [B][T][2].  Results are identical to samd_static_walk's: the token matrix is transposed

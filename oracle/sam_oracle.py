@@ -19,6 +19,8 @@ f32p = C.POINTER(C.c_float)
 
 
 def build(force=False):
+    if os.environ.get("SAM_ORACLE_LIB"):                   # a sanitizer build of the same source (scripts/asan_cpu.sh)
+        return os.environ["SAM_ORACLE_LIB"]
     so = os.path.join(_HERE, "libsam_oracle.so")
     src = os.path.join(_HERE, "sam_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

@@ -361,27 +361,48 @@ int samd_static_save(const samd_static_t *s, const char *path) {
 // will follow must stay inside the image, otherwise a damaged file turns into a wild device read.
 static bool image_is_sane(const samd_static_t *s, const char **why) {
     const int64_t n = s->n_states;
+    int64_t n_edges = 0;
     auto dst_ok = [&](int32_t tok, int32_t dst) { return tok < 0 ? true : (dst >= 0 && dst < n); };
+    if (s->kind != SAMD_KIND_COUNT && s->kind != SAMD_KIND_ENDPOS) { *why = "unknown automaton kind"; return false; }
+    if (s->h_nodes[0].link != -1 || (s->h_nodes[0].length & SAMD_LEN_MASK) != 0) { *why = "state 0 is not a root"; return false; }
     for (int64_t i = 0; i < n; i++) {
         const SamNode &nd = s->h_nodes[i];
-        if (nd.link < -1 || nd.link >= n) { *why = "suffix link out of range"; return false; }
+        // transfer_state climbs `index = states[index].link` until the root (static_sam.py:99-101): every non-root link must name a state of
+        // strictly smaller length, or a damaged image becomes a walk that never ends (or leaves the image through link -1) on the device
+        if (i > 0 && (nd.link < 0 || nd.link >= n)) { *why = "suffix link out of range"; return false; }
+        if (i > 0 && (s->h_nodes[nd.link].length & SAMD_LEN_MASK) >= (nd.length & SAMD_LEN_MASK)) { *why = "suffix link does not shorten the match"; return false; }
         if (nd.deg < 0) { *why = "negative degree"; return false; }
         if (!dst_ok(nd.e0_tok, nd.e0_dst) || !dst_ok(nd.e1_tok, nd.e1_dst) || !dst_ok(nd.e2_tok, nd.e2_dst) ||
             !dst_ok(nd.e3_tok, nd.e3_dst) || !dst_ok(nd.e4_tok, nd.e4_dst)) { *why = "edge target out of range"; return false; }
         if (nd.deg > SAMD_INLINE_EDGES) {
+            if ((int64_t)nd.deg - SAMD_INLINE_EDGES > s->n_spill) { *why = "degree exceeds the spill region"; return false; }
             int64_t slots = (int64_t)SAMD_SPILL_HEAD + samd_spill_slots(nd.deg);
             if (nd.spill < 0 || (int64_t)nd.spill + slots > s->n_spill) { *why = "spill block out of range"; return false; }
             for (int64_t k = 0; k < slots; k++) {
                 const SamEdge &e = s->h_spill[nd.spill + k];
                 if (!dst_ok(e.tok, e.dst)) { *why = "spill edge target out of range"; return false; }
             }
+            // the block must hold exactly the edges `deg` promises (ranks 5..7 up front, repeated in the hashed part): samd_static_export
+            // writes what it finds there into arrays the caller sized from the degrees
+            const SamEdge *sp = s->h_spill + nd.spill;
+            const int32_t nhead = std::min<int32_t>(nd.deg, SAMD_TOPK) - SAMD_INLINE_EDGES;
+            int64_t rest = 0;
+            for (int64_t k = SAMD_SPILL_HEAD; k < slots; k++) {
+                if (sp[k].tok == -1) continue;
+                bool in_head = false;
+                for (int32_t h = 0; h < nhead; h++) in_head |= (sp[h].tok == sp[k].tok);
+                rest += !in_head;
+            }
+            if (SAMD_INLINE_EDGES + nhead + rest != nd.deg) { *why = "spill block does not hold the state's degree"; return false; }
         }
+        n_edges += nd.deg;
         if (s->kind == SAMD_KIND_ENDPOS && (nd.aux < 0 || nd.aux >= std::max<int64_t>(1, s->n_text))) {
             *why = "end position outside the text"; return false;
         }
     }
     for (int64_t t = 0; t < s->vocab; t++)
         if (s->h_root[t] < -1 || s->h_root[t] >= n) { *why = "root table entry out of range"; return false; }
+    if (n_edges != s->n_edges) { *why = "edge count differs from the sum of the degrees"; return false; }     // (callers size export arrays from it)
     return true;
 }
 
@@ -393,6 +414,17 @@ int samd_static_load(const char *path, samd_static_t **out) {
     if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "SAMDHIP1", 8) != 0 || h.version != SAMD_ABI_VERSION ||
         h.n_states < 1 || h.n_spill < 0 || h.vocab < 0 || h.n_text < 0) {
         fclose(f); samd_set_error("%s: not a SAMDHIP1 image", path); return SAMD_E_IO;
+    }
+    // the header's sizes against the file's length BEFORE anything is allocated from them: a damaged header must not become a
+    // multi-terabyte malloc (or a size_t overflow) -- every count is first bounded by what a file of this length could hold
+    long file_len = -1;
+    if (fseek(f, 0, SEEK_END) == 0) file_len = ftell(f);
+    const int64_t body = (int64_t)file_len - (int64_t)sizeof(FileHeader);
+    if (file_len < 0 || fseek(f, (long)sizeof(FileHeader), SEEK_SET) != 0 || body < 0 || h.n_states >= (1ll << 31) || h.n_edges < 0 ||
+        h.n_states > body / (int64_t)sizeof(SamNode) || h.vocab > body / 4 || h.n_spill > body / 8 || h.n_text > body / 4 ||
+        h.n_states * (int64_t)sizeof(SamNode) + h.vocab * 4 + h.n_spill * 8 + h.n_text * 4 != body ||
+        (h.kind != SAMD_KIND_COUNT && h.kind != SAMD_KIND_ENDPOS)) {
+        fclose(f); samd_set_error("%s: truncated or damaged image (header and file length disagree)", path); return SAMD_E_IO;
     }
     samd_static_t *s = (samd_static_t *)calloc(1, sizeof(samd_static_t));
     if (!s) { fclose(f); samd_set_error("out of host memory"); return SAMD_E_CAPACITY; }

@@ -35,8 +35,8 @@ static inline StaticDev static_view(const samd_static_t *s) {
 // first loads in flight together (r02: 0.383 ms, 6 % more requests from chain words fetched for tokens that then mismatch).
 // ================================================================================================
 template <int W, bool CHAIN>
-__global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__restrict__ cursors,
-                                                     const int32_t *__restrict__ tokens, int B, int T, int commit,
+__global__ __launch_bounds__(256) void k_static_walk(StaticDev S, const int32_t *cursors, int32_t *cursors_out,
+                                                     const int32_t *__restrict__ tokens, int B, int T,
                                                      int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total, int lds_words) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long visited = 0;
@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, int32_t *__res
             if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(CHAIN ? st_resolve(S, idx) : idx, len);
             ptok = tok; tok = nxt;
         }
-        if (commit) reinterpret_cast<int2 *>(cursors)[b] = make_int2(CHAIN ? st_resolve(S, idx) : idx, len);
+        // the result of the walk: the final (index, length) of every stream -- in place (transfer_tokens), into a separate array (lookup:
+        // the reference RETURNS the pair and leaves cur_index / cur_length alone, static_sam.py:122-125), or nowhere (cursors_out null)
+        if (cursors_out) reinterpret_cast<int2 *>(cursors_out)[b] = make_int2(CHAIN ? st_resolve(S, idx) : idx, len);
     }
     if (visited_total) {
         for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
@@ -414,16 +416,16 @@ int samd_device_info(int64_t out[4]) {
 }
 
 // SAMD_WALK_CHAIN=0 (read once) keeps every transition on the nodes: the A/B switch of profiles/r02_walk_pmc.md
-static void launch_walk(const samd_static_t *sam, int blocks, int threads, hipStream_t st, int32_t *d_cursors, const int32_t *d_tokens, int B, int T,
-                        int commit, int32_t *d_trace, unsigned long long *d_visited) {
+static void launch_walk(const samd_static_t *sam, int blocks, int threads, hipStream_t st, const int32_t *d_cursors, int32_t *d_out, const int32_t *d_tokens, int B, int T,
+                        int32_t *d_trace, unsigned long long *d_visited) {
     static const bool use_chain = [] { const char *e = getenv("SAMD_WALK_CHAIN"); return !(e && e[0] == '0'); }();
     const StaticDev v = static_view(sam);
     // the child bitmap rides in LDS when it is small enough to leave the occupancy alone (8 workgroups of 256 per CU: 160 KiB / 8)
     const int bit_words = v.rc_bits ? (int)((v.vocab + 31) / 32) : 0;
     const int lds_words = bit_words * 4 <= 20480 ? bit_words : 0;
-    if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, false>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited, 0);
-    else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited, lds_words);
-    else hipLaunchKernelGGL((k_static_walk<4, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_tokens, B, T, commit, d_trace, d_visited, lds_words);
+    if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, false>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, 0);
+    else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
+    else hipLaunchKernelGGL((k_static_walk<4, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
 }
 
 // bigram table (samd_common.h): count the root children's edges, then fill.  One thread per vocabulary id.
@@ -501,7 +503,7 @@ static int derive_topk_counts(samd_static_t *s, hipStream_t st) {
     return SAMD_OK;
 }
 
-static int derive_root_hash(samd_static_t *s, hipStream_t st) {
+static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg = 0) {
     static const bool enabled = [] { const char *e = getenv("SAMD_ROOT_HASH"); return !(e && e[0] == '0'); }();      // A/B switch, read once
     if (s->d_root16) { (void)hipFree(s->d_root16); s->d_root16 = nullptr; }
     if (s->d_d1hash) { (void)hipFree(s->d_d1hash); s->d_d1hash = nullptr; }
@@ -519,13 +521,19 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st) {
         if (hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
     }
     (void)hipFree(d_total);
-    // slots per pair: a lock-step wave pays a second probe round whenever ANY of its 64 lanes collides, so the table is kept very sparse --
-    // measured on the bench automaton (4.5 M pairs, same box): >= 2 x pairs 0.188 ms per launch, 4 x 0.176, 8 x 0.170, 16 x 0.166 (2 GB).
-    // SAMD_BIGRAM_SLOTS_PER_PAIR overrides (2 .. 64); whatever it says, the table stays under 8 GB as long as 2 x pairs fit in that
-    static const int per_pair = [] { const char *e = getenv("SAMD_BIGRAM_SLOTS_PER_PAIR"); const int v = e ? atoi(e) : 16; return v < 2 ? 2 : (v > 64 ? 64 : v); }();
+    // slots per pair: a lock-step wave of the BATCHED walk pays a second probe round whenever ANY of its 64 lanes collides, so that launch
+    // likes a very sparse table -- measured on the bench automaton (4.5 M pairs, same box): >= 2 x pairs 0.188 ms per launch, 4 x 0.176,
+    // 8 x 0.170, 16 x 0.166 (2 GB).  The product path (st_transfer_tokens: ONE cursor, uniform addresses) gains nothing from the sparsity, and
+    // the table is per GPU replica next to weights and KV cache, so the DEFAULT is 4 slots per pair (round 5; rounds 3-4: 16) and a caller that
+    // runs the batched walk asks for more: samd_static_set_bigram_slots() / SAMD_BIGRAM_SLOTS_PER_PAIR (2 .. 64).  Whatever is asked for, the
+    // table stays under 8 GB and under an eighth of the device memory free right now, as long as 2 x pairs fit in that.
+    static const int per_pair_env = [] { const char *e = getenv("SAMD_BIGRAM_SLOTS_PER_PAIR"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : (v > 64 ? 64 : v); }();
+    const int per_pair = per_pair_arg > 0 ? (per_pair_arg < 2 ? 2 : (per_pair_arg > 64 ? 64 : per_pair_arg)) : per_pair_env;
+    long long budget = 8ll << 30;
+    { size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (long long)(free_b / 8) < budget) budget = (long long)(free_b / 8); else (void)hipGetLastError(); }
     long long slots = 1024;
     while (slots < per_pair * (long long)total) slots <<= 1;                       // load factor in (1 / 2 per_pair, 1 / per_pair]
-    while (slots * 16 > (8ll << 30) && slots >= 4 * (long long)total) slots >>= 1;
+    while (slots * 16 > budget && slots >= 4 * (long long)total) slots >>= 1;
     if (rc == SAMD_OK && slots > (1ll << 31)) rc = -1;                            // the mask does not fit 32 bits: go without the table
     const size_t bit_bytes = (size_t)((vocab + 31) / 32) * 4;
     if (rc == SAMD_OK) {
@@ -567,13 +575,36 @@ int samd_static_derive_chain(samd_static_t *s, void *stream) {
     return rc != SAMD_OK ? rc : derive_topk_counts(s, (hipStream_t)stream);
 }
 
+int samd_static_set_bigram_slots(samd_static_t *s, int32_t slots_per_pair, void *stream) {
+    if (!s || !s->uploaded || !s->d_nodes || slots_per_pair < 0) { samd_set_error("samd_static_set_bigram_slots: invalid argument"); return SAMD_E_INVALID; }
+    if (!s->d_chain) return SAMD_OK;                                           // no derived tables on this handle: nothing to re-size
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SAMD_E_HIP;      // nothing may still read the table that is replaced
+    return derive_root_hash(s, (hipStream_t)stream, slots_per_pair);
+}
+
 int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
                      int32_t commit, int32_t *d_trace, void *stream) {
     if (!sam || !sam->uploaded || B < 0 || T < 0) { samd_set_error("samd_static_walk: invalid argument"); return SAMD_E_INVALID; }
     if (B == 0 || T == 0) return SAMD_OK;                 // empty batch / no tokens: nothing to do
     if (!d_cursors || !d_tokens) { samd_set_error("samd_static_walk: null pointer"); return SAMD_E_INVALID; }
     const int threads = 256, blocks = (B + threads - 1) / threads;
-    launch_walk(sam, blocks, threads, (hipStream_t)stream, d_cursors, d_tokens, B, T, commit, d_trace, (unsigned long long *)nullptr);
+    launch_walk(sam, blocks, threads, (hipStream_t)stream, d_cursors, commit ? d_cursors : nullptr, d_tokens, B, T, d_trace, (unsigned long long *)nullptr);
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+// lookup over B cursors: the walk's result goes to d_out, the cursors stay (static_sam.py:122-125 returns the pair and commits nothing)
+int samd_static_lookup_batch(const samd_static_t *sam, const int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,
+                             int32_t *d_out, uint64_t *d_visited, void *stream) {
+    if (!sam || !sam->uploaded || B < 0 || T < 0) { samd_set_error("samd_static_lookup_batch: invalid argument"); return SAMD_E_INVALID; }
+    if (B == 0) return SAMD_OK;
+    if (!d_cursors || !d_out || (T > 0 && !d_tokens)) { samd_set_error("samd_static_lookup_batch: null pointer"); return SAMD_E_INVALID; }
+    if (T == 0) {                                          // no token: the result is the cursor itself
+        if (d_out != d_cursors) HIPCHK(hipMemcpyAsync(d_out, d_cursors, (size_t)B * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return SAMD_OK;
+    }
+    const int threads = 256, blocks = (B + threads - 1) / threads;
+    launch_walk(sam, blocks, threads, (hipStream_t)stream, d_cursors, d_out, d_tokens, B, T, (int32_t *)nullptr, (unsigned long long *)d_visited);
     LAUNCHCHK();
     return SAMD_OK;
 }
@@ -584,7 +615,7 @@ int samd_static_walk_counted(const samd_static_t *sam, int32_t *d_cursors, const
                              int32_t commit, uint64_t *d_visited, void *stream) {
     if (!sam || !sam->uploaded || !d_cursors || !d_tokens || B <= 0 || T <= 0 || !d_visited) return SAMD_E_INVALID;
     const int threads = 256, blocks = (B + threads - 1) / threads;
-    launch_walk(sam, blocks, threads, (hipStream_t)stream, d_cursors, d_tokens, B, T, commit, (int32_t *)nullptr, (unsigned long long *)d_visited);
+    launch_walk(sam, blocks, threads, (hipStream_t)stream, d_cursors, commit ? d_cursors : nullptr, d_tokens, B, T, (int32_t *)nullptr, (unsigned long long *)d_visited);
     LAUNCHCHK();
     return SAMD_OK;
 }
@@ -600,7 +631,7 @@ static int walk_streams(const samd_static_t *sam, int32_t *d_cursors, const int3
     if (hipMallocAsync((void **)&tm, n * 4, st) != hipSuccess) { samd_set_error("samd_static_walk_streams: scratch allocation failed"); return SAMD_E_HIP; }
     if (d_trace && hipMallocAsync((void **)&tr, n * 8, st) != hipSuccess) { (void)hipFreeAsync(tm, st); samd_set_error("samd_static_walk_streams: scratch allocation failed"); return SAMD_E_HIP; }
     hipLaunchKernelGGL(k_transpose_i32<1>, dim3((T + 31) / 32, (B + 31) / 32), dim3(256), 0, st, d_tokens, tm, B, T);
-    launch_walk(sam, (B + 255) / 256, 256, st, d_cursors, tm, B, T, commit, tr, (unsigned long long *)d_visited);
+    launch_walk(sam, (B + 255) / 256, 256, st, d_cursors, commit ? d_cursors : nullptr, tm, B, T, tr, (unsigned long long *)d_visited);
     if (d_trace) hipLaunchKernelGGL(k_transpose_i32<2>, dim3((B + 31) / 32, (T + 31) / 32), dim3(256), 0, st, tr, d_trace, T, B);
     (void)hipFreeAsync(tm, st);
     if (tr) (void)hipFreeAsync(tr, st);

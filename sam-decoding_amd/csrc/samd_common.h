@@ -52,7 +52,7 @@ struct SamEdge { int32_t tok, dst; };
 // number of hash slots of a spill block (excluding the 3-entry head) for a state of degree deg > SAMD_INLINE_EDGES
 SAMD_HD static inline uint32_t samd_spill_slots(int32_t deg) {
     uint32_t need = 2u * (uint32_t)(deg - SAMD_INLINE_EDGES), m = 4;
-    while (m < need) m <<= 1;
+    while (m < need && m < 0x80000000u) m <<= 1;          // (a degree from a damaged image must not turn this into an endless loop)
     return m;
 }
 // slot of the token pair (a, b) in the bigram table (StaticDev), before masking

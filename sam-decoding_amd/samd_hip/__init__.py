@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsamd_hip.so")
+# SAMD_HIP_LIB: another build of the SAME library (scripts/asan_cpu.sh points the CPU tests at a host-sanitizer build); it must
+# export every entry point like the default one, and a missing file fails just as loudly
+LIB_PATH = os.environ.get("SAMD_HIP_LIB") or os.path.join(_HERE, "libsamd_hip.so")
 MAX_DRAFT = 64
 TOPK = 8
 # report block layout (include/samd_hip.h SAMD_REP_*)
@@ -74,6 +76,7 @@ _PROTOS = {
     "samd_static_upload": (C.c_int, [_VP]),
     "samd_static_info": (C.c_int, [_VP, _VP]),
     "samd_static_derived_info": (C.c_int, [_VP, _VP]),
+    "samd_static_set_bigram_slots": (C.c_int, [_VP, _I32, _VP]),
     "samd_static_export": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_static_device_image": (C.c_int, [_VP, _VP, _VP]),
     "samd_static_alloc_like": (C.c_int, [_VP, _VP]),
@@ -82,6 +85,7 @@ _PROTOS = {
     "samd_static_adopt_device": (C.c_int, [_VP, _VP, _VP]),
     "samd_static_walk": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "samd_static_walk_counted": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
+    "samd_static_lookup_batch": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP]),
     "samd_static_walk_streams": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "samd_static_walk_streams_counted": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP]),
     "samd_session_create": (C.c_int, [_I32, _VP]),
@@ -312,7 +316,15 @@ class StaticAutomaton:
         bitmap) and of the top-k counts, and the bigram table's slots (include/samd_hip.h samd_static_derived_info)"""
         out = (C.c_int64 * 4)()
         check(lib().samd_static_derived_info(self._h, out))
-        return dict(zip(("chain_bytes", "bigram_bytes", "topk_count_bytes", "bigram_slots"), list(out)))
+        d = dict(zip(("chain_bytes", "bigram_bytes", "topk_count_bytes", "bigram_slots"), list(out)))
+        d["resident_bytes"] = self.info()["device_bytes"] + d["chain_bytes"] + d["bigram_bytes"] + d["topk_count_bytes"]      # image + derived, per replica
+        return d
+
+    def set_bigram_slots(self, slots_per_pair=0):
+        """re-size the bigram table (include/samd_hip.h samd_static_set_bigram_slots): 0 = the default (4 per root-child edge); the batched
+        walk likes 16"""
+        check(lib().samd_static_set_bigram_slots(self._h, int(slots_per_pair), current_stream()))
+        return self
 
     def export(self):
         i = self.info()
@@ -377,6 +389,12 @@ class StaticAutomaton:
         else:
             check(lib().samd_static_walk(self._h, _ptr(cursors), _ptr(tokens), B, T, int(commit), _ptr(trace), current_stream()))
 
+
+    def lookup_batch(self, cursors, tokens, out, visited=None):
+        """StaticSAM.lookup over B cursors (SO/sam/static_sam.py:122-125): cursors int32 [B,2] stay, tokens int32 [T,B] (time-major),
+        out int32 [B,2] receives every stream's (index, length)."""
+        T, B = tokens.shape
+        check(lib().samd_static_lookup_batch(self._h, _ptr(cursors), _ptr(tokens), B, T, _ptr(out), _ptr(visited), current_stream()))
 
     def walk_streams(self, cursors, tokens, commit=True, trace=None, visited=None):
         """cursors int32 [B,2] (cuda), tokens int32 [B,T] (cuda, stream-major); trace int32 [B,T,2]."""

@@ -100,6 +100,21 @@ def test_static_walk_batched_vs_oracle(vocab, B, T):
     before = cur.clone()
     prod.walk(cur, dev(toks), commit=False)
     assert torch.equal(cur, before)
+    # the out-of-place lookup (static_sam.py:122-125 RETURNS the pair): same result and visited count as the committed walk, cursors untouched;
+    # from the root and from the non-root cursors a first pass left
+    root = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    res = torch.full((B, 2), -7, dtype=torch.int32, device="cuda")
+    v2 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.lookup_batch(root, dev(toks), res, visited=v2)
+    assert torch.equal(res, cur2) and root.abs().sum().item() == 0 and int(v2.item()) == int(visited.item())
+    rev = dev(toks[::-1].copy())
+    want = cur.clone()
+    prod.walk(want, rev, commit=True)
+    prod.lookup_batch(cur, rev, res)
+    assert torch.equal(res, want) and torch.equal(cur, before)
+    prod.lookup_batch(cur, rev[:1], res)                                     # T = 1: the reference's lookup(token)
+    for b in range(0, B, max(1, B // 32)):
+        assert tuple(res[b].tolist()) == ora.transfer_state(int(before[b, 0]), int(before[b, 1]), int(toks[T - 1, b]))
     # the stream-major kernel: same trace, cursors and visited-state count; also from non-root start cursors (a second pass)
     check_stream_major_walk(prod, toks, got, cur, int(visited.item()))
     trace2 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
@@ -326,6 +341,51 @@ def test_static_walk_random_corpora(seed):
         assert out.cpu().tolist() == [int(want_fin[b, 0]), int(want_fin[b, 1])], (seed, b)
 
 
+@pytest.mark.parametrize("vocab", [300, 70000])
+def test_bigram_table_size_changes_nothing_but_bytes(vocab):
+    """samd_static_set_bigram_slots: the table is an accelerator -- every size (and the default, 4 slots per root-child edge since round 5)
+    gives the same cursors, traces and visited-state counts; only derived_info's bytes move."""
+    rng = np.random.default_rng(5)
+    docs = [markov_stream(rng, 400, vocab=vocab) for _ in range(20)] + [[i] for i in range(vocab)]
+    flat = np.concatenate([np.asarray(d) for d in docs[:20]])
+    prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    B, T = 3000, 24
+    toks = np.empty((T, B), np.int32)
+    for b in range(B):
+        p = int(rng.integers(0, len(flat) - T))
+        seq = flat[p:p + T].copy()
+        noise = rng.random(T) < 0.2
+        seq[noise] = rng.integers(0, vocab, int(noise.sum()))
+        toks[:, b] = seq
+    d_toks, root = dev(toks), torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    base = prod.derived_info()
+    pairs_x4 = base["bigram_slots"]
+    assert pairs_x4 >= 1024
+    want, want_v = None, None
+    for per_pair in (0, 2, 16, 64, 4):
+        prod.set_bigram_slots(per_pair)
+        info = prod.derived_info()
+        if per_pair in (0, 4):
+            assert info["bigram_slots"] == pairs_x4                           # 0 = the default = 4 per pair
+        elif per_pair == 2:
+            assert info["bigram_slots"] * 2 == pairs_x4 or info["bigram_slots"] == 1024
+        else:
+            assert info["bigram_slots"] == pairs_x4 * per_pair // 4
+        assert info["resident_bytes"] == prod.info()["device_bytes"] + info["chain_bytes"] + info["bigram_bytes"] + info["topk_count_bytes"]
+        res = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+        v = torch.zeros(1, dtype=torch.int64, device="cuda")
+        prod.lookup_batch(root, d_toks, res, visited=v)
+        if want is None:
+            want, want_v = res.clone(), int(v.item())
+        assert torch.equal(res, want) and int(v.item()) == want_v, per_pair
+    ora = O.StaticSAM.build(docs, 2)
+    for b in range(0, B, 100):
+        i, l = 0, 0
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[t, b]))
+        assert tuple(want[b].tolist()) == (i, l)
+
+
 def test_static_walk_empty_and_ragged():
     prod = samd_hip.StaticAutomaton.build([[3, 4, 5, 3, 4, 6]], 2, 0).upload()
     cur = torch.zeros((0, 2), dtype=torch.int32, device="cuda")
@@ -336,6 +396,12 @@ def test_static_walk_empty_and_ragged():
     # negative / huge token ids fall back to the root like an absent key
     prod.walk(cur, dev([[3, -1, 10 ** 9], [4, 3, 3]]))
     assert cur.cpu().tolist() == [[2, 2], [1, 1], [1, 1]]
+    # the out-of-place lookup: empty batch; no tokens = the cursors themselves
+    prod.lookup_batch(torch.zeros((0, 2), dtype=torch.int32, device="cuda"), torch.zeros((4, 0), dtype=torch.int32, device="cuda"),
+                      torch.zeros((0, 2), dtype=torch.int32, device="cuda"))
+    res = torch.zeros((3, 2), dtype=torch.int32, device="cuda")
+    prod.lookup_batch(cur, torch.zeros((0, 3), dtype=torch.int32, device="cuda"), res)
+    assert res.cpu().tolist() == [[2, 2], [1, 1], [1, 1]]
     # the stream-major entry point: empty batch, no tokens, the same three streams
     prod.walk_streams(torch.zeros((0, 2), dtype=torch.int32, device="cuda"), torch.zeros((0, 4), dtype=torch.int32, device="cuda"))
     cur = torch.zeros((3, 2), dtype=torch.int32, device="cuda")
