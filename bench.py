@@ -103,6 +103,68 @@ def synth_request(rng, docs, vocab=VOCAB, prompt_len=512, total_len=2048, copy_m
     return out[:prompt_len], out
 
 
+SUMM_PROMPT_RANGE = (1024, 1536)       # article + instruction, tokens (CNN/DM articles through Vicuna's tokenizer: ~1-1.5 k)
+SUMM_NEW_RANGE = (128, 256)            # max_new_tokens of a summarization request
+
+
+def synth_request_summarization(rng, docs, vocab=VOCAB, prompt_range=SUMM_PROMPT_RANGE, new_range=SUMM_NEW_RANGE, span_mean=16.0,
+                                p_span=0.75, glue_mean=3.0, article_copy_mean=6.0, p_article_copy=0.30, article_fresh_mean=24.0):
+    """one request of the SUMMARIZATION-shaped workload (the category the north star's >= 2.5x is quoted on,
+    README.md:53): a long prompt and a short continuation that mostly copies spans OF THE PROMPT -- what an extractive-leaning summary of a
+    news article does, and why the dynamic automaton's sequence drafts (SO/sam/dyn_sam.py:116-121) carry this category in the reference.
+      prompt        = `prompt_range` tokens of "article": fresh text of the order-2 source (new documents, NOT in the static corpus: first
+                      two tokens random, so the corpus has almost none of its bigram contexts) interleaved with short copied corpus spans
+                      (stock phrases the static automaton knows; geometric, mean `article_copy_mean`)
+      continuation  = `new_range` tokens: with probability `p_span` a span copied from the prompt (geometric, mean `span_mean`; the judge's
+                      12-24), else glue -- a few tokens (geometric, mean `glue_mean`) of noise or of a copied corpus span
+    Returns (prompt, prompt + continuation, max_new_tokens).  Nothing here is tuned to an accept length; tests/test_bench_workloads_cpu.py
+    records what the reference's rule (oracle) does with it."""
+    n_docs, doc_len = docs.shape
+    P = int(rng.integers(prompt_range[0], prompt_range[1] + 1))
+    new = int(rng.integers(new_range[0], new_range[1] + 1))
+    art = []
+    while len(art) < P:
+        if rng.random() < p_article_copy:
+            ln = int(rng.geometric(1.0 / article_copy_mean))
+            d, s0 = int(rng.integers(0, n_docs)), int(rng.integers(0, doc_len - 1))
+            art.extend(docs[d, s0:s0 + ln].tolist())
+        else:
+            ln = int(rng.geometric(1.0 / article_fresh_mean)) + 2
+            a, b = int(rng.integers(3, vocab)), int(rng.integers(3, vocab))
+            seg = [a, b]
+            ch = rng.choice(4, size=ln, p=np.array([12, 6, 4, 3]) / 25.0)
+            for c in ch:
+                t = int(_succ(np.int64(seg[-2]), np.int64(seg[-1]), np.int64(c), vocab))
+                seg.append(t)
+            art.extend(seg)
+    art = art[:P]
+    out = list(art)
+    while len(out) < P + new + 64:                       # (+ the draft a last step may look ahead over)
+        if rng.random() < p_span:
+            ln = int(rng.geometric(1.0 / span_mean))
+            s0 = int(rng.integers(0, P - 1))
+            out.extend(art[s0:s0 + ln])
+        else:
+            ln = int(rng.geometric(1.0 / glue_mean))
+            if rng.random() < 0.5:
+                out.extend(rng.integers(3, vocab, ln).tolist())
+            else:
+                d, s0 = int(rng.integers(0, n_docs)), int(rng.integers(0, doc_len - 1))
+                out.extend(docs[d, s0:s0 + ln].tolist())
+    out = [t if t != EOS else 3 for t in out[:P + new + 64]]
+    return out[:P], out, new
+
+
+# two parameterisations of the summarization source, both reported (`summarization` object of the line):
+#   "readme_mat": how much of a summary is copied is NOT published, the speed-ups are -- README.md:53 gives 2.43x on summarization against
+#                 1.84x overall at 2.30 mean accepted tokens, i.e. ~2.30 x 2.43 / 1.84 = 3.0 accepted tokens per step on that category if a step
+#                 costs the same; p_span / glue_mean below make the reference's rule (CPU oracle, tests/test_bench_workloads_cpu.py) accept
+#                 ~3.1 on this source.  This is the figure `summarization.speedup_vs_ar` is quoted on.
+#   "copy_heavy": VERDICT r04's wording -- "mostly spans copied from the prompt (geometric, mean 12-24) with short glue": accepts ~5.6;
+#                 it is what drives the 32/48/64-row buckets hardest and is reported beside the first, not instead of it.
+SUMM_PROFILES = {"readme_mat": dict(p_span=0.35, span_mean=16.0, glue_mean=4.0),
+                 "copy_heavy": dict(p_span=0.75, span_mean=16.0, glue_mean=3.0)}
+
 TR_HOT_VOCAB = 2048            # ids [3, 2048) of the order-1 source of --variant token_recycle
 TR_RANK_P = (0.50, 0.20, 0.10, 0.07, 0.05, 0.04, 0.02, 0.02)
 
@@ -537,6 +599,95 @@ def named_breakdown(model, lm, prompt, n_steps=48):
             "non_lm_share": round(1.0 - tot[0] / max(sum(tot), 1e-9), 4)}
 
 
+def summarization_leg(model, ar, lm, docs, breakdown, n_requests, seed=2000, max_len=2048):
+    """the summarization-shaped workload (synth_request_summarization) through the SAME engine, kernels and SamdConfig as the headline,
+    outside the headline's timed region.  Per profile: `n_requests` requests decoded speculatively and the same requests autoregressively
+    (max_predicts = 1), every request timed as the reference times a turn -- synchronize; t0; generate(); synchronize -- so BOTH sides include
+    the prefill of the 1-1.5 k-token prompt (evaluation/eval_vicuna.py:179-189); tokens/s = sum of new tokens / sum of wall time and the
+    speed-up their ratio (evaluation/speed.py:26-30, :59-61).  Also: steps per row bucket, accepted tokens by draft type, what the request
+    starts cost, and the decode time attributed to each bucket from the back-to-back graph times of `breakdown` (step_breakdown_by_rows)."""
+    import torch
+    import samd_sam_only as SO
+    out = {}
+    for name, params in SUMM_PROFILES.items():
+        rng = np.random.default_rng(seed)
+        reqs = [synth_request_summarization(rng, docs, **params) for _ in range(n_requests)]
+        res = {}
+        for side, m in (("speculative", model), ("autoregressive", ar)):
+            eng = m.engine
+            starts = {"n": 0, "s": 0.0}
+            orig = eng.start
+
+            def timed_start(*a, _orig=orig, _st=starts, **kw):
+                t_s = time.perf_counter()
+                r = _orig(*a, **kw)
+                _st["n"] += 1
+                _st["s"] += time.perf_counter() - t_s
+                return r
+            eng.start = timed_start
+            for v in m.lookup_stats.values():
+                v[0] = v[1] = 0
+            eng.bucket_steps.clear()
+            wall = new_tokens = steps = 0
+            per_req = []
+            try:
+                for i, (prompt, target, new) in enumerate([reqs[0]] + reqs):            # request 0 once untimed: graphs of every bucket it meets exist
+                    lm.set_target(target)
+                    gcfg = SO.SamdGenerationConfig(max_new_tokens=new, max_cache_len=max_len)
+                    ids = torch.tensor([prompt], dtype=torch.long, device="cuda")
+                    if i == 0:
+                        for _ in m._run(ids, gcfg, new):
+                            pass
+                        for v in m.lookup_stats.values():
+                            v[0] = v[1] = 0
+                        eng.bucket_steps.clear()
+                        starts["n"], starts["s"] = 0, 0.0
+                        continue
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    nt = ns = 0
+                    for new_ids, _ in m._run(ids, gcfg, new):
+                        nt += len(new_ids)
+                        ns += 1
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    wall += dt
+                    new_tokens += nt
+                    steps += ns
+                    per_req.append((len(prompt), nt, ns, round(dt * 1e3, 2)))
+            finally:
+                eng.start = orig
+            hist = {str(k): v for k, v in sorted(eng.bucket_steps.items())}
+            decode_by_bucket = {R: round(n * breakdown[R]["step_ms"], 2) for R, n in hist.items() if R in breakdown}
+            res[side] = {"tokens_per_s": round(new_tokens / wall, 2), "new_tokens": new_tokens, "steps": steps, "wall_ms": round(wall * 1e3, 1),
+                         "mean_accepted_tokens": round(new_tokens / max(steps, 1), 3),
+                         "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in m.lookup_stats.items()},
+                         "bucket_histogram": hist,
+                         "request_start_ms_each": round(starts["s"] * 1e3 / max(starts["n"], 1), 3),
+                         "request_start_share_of_timed_region": round(starts["s"] / wall, 4),
+                         "decode_ms_per_step": round((wall - starts["s"]) * 1e3 / max(steps, 1), 4),
+                         # the decode time by row bucket: steps x that bucket's back-to-back graph time (ms, summed over the requests)
+                         "graph_ms_by_bucket": decode_by_bucket}
+        sp, arr = res["speculative"], res["autoregressive"]
+        wide = sum(v for R, v in sp["graph_ms_by_bucket"].items() if int(R) >= 32)
+        narrow_cost = sum(sp["bucket_histogram"].get(R, 0) for R in ("32", "48", "64")) * breakdown.get("8", {}).get("step_ms", 0.0)
+        out[name] = {
+            "source": dict(params, prompt_tokens=list(SUMM_PROMPT_RANGE), max_new_tokens=list(SUMM_NEW_RANGE), requests=n_requests, seed=seed),
+            "speculative": sp, "autoregressive": arr,
+            # BOTH sides include their prefill, as the reference's tokens/s does (new_tokens / wall_time per turn)
+            "speedup_vs_ar": round(sp["tokens_per_s"] / arr["tokens_per_s"], 3),
+            "speedup_vs_ar_decode_only": round((sp["new_tokens"] / (sp["wall_ms"] * (1 - sp["request_start_share_of_timed_region"])))
+                                               / (arr["new_tokens"] / (arr["wall_ms"] * (1 - arr["request_start_share_of_timed_region"]))), 3),
+            # what keeps the speed-up below accepted-tokens x 1: the prompt's prefill + ingest (both sides pay it, the faster side feels it
+            # more), and the wide-bucket steps costing more than an 8-row step
+            "losses_ms": {"request_starts": round(sp["request_start_ms_each"] * n_requests, 1),
+                          "wide_buckets_over_8_row_steps": round(wide - narrow_cost, 1), "speculative_wall": sp["wall_ms"]},
+        }
+    out["north_star_target"] = ">= 2.5x over autoregressive on Spec-Bench summarization (BASELINE.json); the reference publishes 2.43x on an A6000 (README.md:53)"
+    out["quoted_profile"] = "readme_mat"
+    return out
+
+
 def variant_projection(variant, ar_tps, ms_per_step):
     """speed-up the measured step cost of a plugin variant would give at the mean accepted tokens the reference publishes for it"""
     mat = {"token_recycle": 3.03, "eagle2": 4.62}.get(variant)
@@ -646,6 +797,10 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from profiles/walk_pmc.json instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--no-long-run", action="store_true", help="skip the untimed continuation of the request stream (context for short --steps)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--workload", choices=["headline", "summarization"], default="headline",
+                    help="the timed region and `value` are ALWAYS the headline (configs[1]); 'summarization' runs the `summarization` object's leg "
+                         "(long prompts, prompt-copy continuations, AR incl. prefill) over 24 requests per profile instead of the default 6")
+    ap.add_argument("--summ-requests", type=int, default=None, help="requests per profile of the summarization leg (0 = skip it)")
     ap.add_argument("--launch-selftest", action="store_true", help="CPU check of the N-rank plumbing (gloo): spawn, rendezvous, reduce, relay; no GPU work")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 outside a launcher: print the child command as JSON and exit")
     args = ap.parse_args()
@@ -888,6 +1043,11 @@ def main():
         torch.cuda.synchronize()
         ar_tps = ar_tokens / (time.perf_counter() - ta)
 
+        summ = None
+        n_summ = args.summ_requests if args.summ_requests is not None else (24 if args.workload == "summarization" else 6)
+        if args.variant == "sam_only" and args.acceptance == "scripted" and world == 1 and n_summ > 0 and max_len >= 2048:
+            summ = summarization_leg(model, ar, lm, docs, breakdown, n_summ, max_len=max_len)
+
         named = None
         if args.variant == "sam_only":
             if args.acceptance == "scripted":
@@ -948,6 +1108,8 @@ def main():
                               if order1 else None,
             "projected_speedup_of_this_variant": variant_projection(args.variant, ar_tps, dt_max / args.steps * 1e3),
             "long_run": long_run, "timed_tokens": int(tokens_total), "session_kernel_phases": session_phases,
+            # the category the north star's target is quoted on, as a workload (outside the timed region; see summarization_leg)
+            "summarization": summ,
             "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
             "step_breakdown_by_rows": breakdown, "step_breakdown_named": named,
             # SURVEY.md 8(d) end-to-end proxy: speed-up = accepted tokens x T_AR / T_step with THIS run's measured step times
