@@ -78,6 +78,45 @@ def synth_corpus(n_tokens, vocab=VOCAB, seed=0, doc_len=256):
     return flat, off, docs
 
 
+def zipf_cdf(vocab, s=1.15, first=3):
+    """cumulative distribution of token ids first..vocab-1 with P(rank r) ~ 1 / r^s (id = first + rank - 1: low ids are the frequent ones)"""
+    w = 1.0 / np.arange(1, vocab - first + 1, dtype=np.float64) ** s
+    c = np.cumsum(w)
+    return c / c[-1]
+
+
+def synth_corpus_zipf(n_tokens, vocab=VOCAB, seed=0, doc_len=256, s=1.15, succ_s=1.2, max_succ=1024, noise=0.02):
+    """a corpus with a natural-language-like DEGREE profile (VERDICT r04 #3c; the headline's order-2 source has a uniform vocabulary and 4
+    successors per context, so 93 % of its states are non-branching and nothing below depth 1 is a hub): token frequencies follow
+    Zipf(s) over the vocabulary, and the successor of context (a, b) is the c-th of up to `max_succ` candidates with c ~ Zipf(succ_s), each
+    candidate itself a Zipf-distributed token (a fixed hash of (a, b, c) through the inverse CDF).  Frequent tokens then have thousands of
+    distinct successors (depth-1 hubs), frequent bigrams / trigrams hundreds (depth-2/3 hubs of degree 10^2-10^3), rare contexts one.
+    Same shape as synth_corpus: documents of `doc_len` tokens + every vocabulary id as a one-token document."""
+    rng = np.random.default_rng(seed)
+    n_docs = max(1, n_tokens // doc_len)
+    cdf = zipf_cdf(vocab, s)
+    wc = 1.0 / np.arange(1, max_succ + 1, dtype=np.float64) ** succ_s
+    wc /= wc.sum()
+
+    def ztok(u):                                        # uniform [0, 1) -> Zipf token id
+        return (3 + np.searchsorted(cdf, u, side="right")).astype(np.int32).clip(3, vocab - 1)
+    docs = np.empty((n_docs, doc_len), np.int32)
+    docs[:, :2] = ztok(rng.random((n_docs, 2)))
+    choice = rng.choice(max_succ, size=(n_docs, doc_len), p=wc).astype(np.uint64)
+    is_noise = rng.random((n_docs, doc_len)) < noise
+    noise_tok = ztok(rng.random((n_docs, doc_len)))
+    for i in range(2, doc_len):
+        a, b = docs[:, i - 2].astype(np.uint64), docs[:, i - 1].astype(np.uint64)
+        h = (a * np.uint64(1000003) + b * np.uint64(10007) + choice[:, i] * np.uint64(7919) + np.uint64(12345)) & np.uint64(0x7FFFFFFF)
+        h = (h * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+        h = (h ^ (h >> np.uint64(15))) * np.uint64(2246822519) & np.uint64(0xFFFFFFFF)
+        t = ztok(h.astype(np.float64) / 4294967296.0)
+        docs[:, i] = np.where(is_noise[:, i], noise_tok[:, i], t)
+    flat = np.concatenate([docs.reshape(-1), np.arange(vocab, dtype=np.int32)])
+    off = np.concatenate([np.arange(n_docs + 1, dtype=np.int64) * doc_len, n_docs * doc_len + 1 + np.arange(vocab, dtype=np.int64)])
+    return flat, off, docs
+
+
 def synth_request(rng, docs, vocab=VOCAB, prompt_len=512, total_len=2048, copy_mean=8.0, repeat_mean=8.0, noise_mean=3.0,
                   p_copy=0.47, p_repeat=0.15):
     """prompt + continuation of one request: a mix of copied corpus spans (geometric length, mean `copy_mean`), repeats
@@ -286,7 +325,7 @@ def walk_source_sha16():
 WALK_BIGRAM_SLOTS_PER_PAIR = 16       # the batched walk's table sparsity (profiles/r04_walk.md); the product default is 4 (include/samd_hip.h)
 
 
-def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=WALK_BIGRAM_SLOTS_PER_PAIR, vocab=VOCAB):
+def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=WALK_BIGRAM_SLOTS_PER_PAIR, vocab=VOCAB, noise_cdf=None):
     """the SAM traversal kernel in batched-streams form: B independent cursors x T tokens per launch.  The launch asks for the bigram
     table at `slots_per_pair` (samd_static_set_bigram_slots: a lock-step wave pays for any lane's collision; a request's one-cursor
     walks do not care, so the decode loop above ran on the 4-per-pair default) and the bytes that costs are reported with it."""
@@ -299,7 +338,11 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=W
     s = rng.integers(0, doc_len - T, B)
     toks = docs[d[None, :], (s[None, :] + np.arange(T)[:, None])]
     noise = rng.random((T, B)) < 0.10
-    toks = np.where(noise, rng.integers(3, vocab, (T, B)), toks).astype(np.int32)
+    if noise_cdf is None:
+        noise_tok = rng.integers(3, vocab, (T, B))
+    else:                                               # a Zipf corpus gets Zipf noise (a uniform draw would almost always be a rare token)
+        noise_tok = (3 + np.searchsorted(noise_cdf, rng.random((T, B)), side="right")).clip(3, vocab - 1)
+    toks = np.where(noise, noise_tok, toks).astype(np.int32)
     d_toks = torch.from_numpy(np.ascontiguousarray(toks)).cuda()
     cursors = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
     visited = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -351,7 +394,7 @@ def request_rate(roof):
     return roof
 
 
-def live_walk_traffic(corpus_tokens, B, T, timeout_s=90):
+def live_walk_traffic(corpus_tokens, B, T, timeout_s=90, dist="markov", slots_per_pair=None, counters=("FETCH_SIZE", "WRITE_SIZE"), detail=None):
     """HBM bytes of ONE k_static_walk launch measured in this bench run: scripts/walk_probe.py (the same corpus, streams and kernel)
     as a CHILD process under `rocprofv3 --kernel-trace --pmc <counter>`, FETCH_SIZE and WRITE_SIZE in separate passes as
     MI355X_MICROARCH.md prescribes (FETCH_SIZE is exact for this scattered 16-byte pattern: profiles/r01_hbm_probe.md).  Returns
@@ -370,10 +413,11 @@ def live_walk_traffic(corpus_tokens, B, T, timeout_s=90):
         return None, "this process is itself being profiled"
     per_launch = {}
     deadline = time.monotonic() + timeout_s
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in counters:
         out = tempfile.mkdtemp(prefix="samd_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "w", "--",
-               sys.executable, os.path.join(ROOT, "scripts", "walk_probe.py"), str(corpus_tokens), str(B), str(T), "3"]
+               sys.executable, os.path.join(ROOT, "scripts", "walk_probe.py"), str(corpus_tokens), str(B), str(T), "3", dist,
+               str(slots_per_pair if slots_per_pair is not None else WALK_BIGRAM_SLOTS_PER_PAIR)]
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                  start_new_session=True)
@@ -391,6 +435,8 @@ def live_walk_traffic(corpus_tokens, B, T, timeout_s=90):
             if not vals:
                 return None, f"no {counter} rows for k_static_walk (rocprofv3 exit code {p.returncode})"
             per_launch[counter] = vals[-1] * 1024.0          # KiB per dispatch; the last launch runs on warm caches like the timed ones
+            if detail is not None:
+                detail[counter] = per_launch[counter]
         except OSError as e:
             return None, f"{type(e).__name__}: {e}"
         finally:

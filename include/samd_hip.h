@@ -87,6 +87,14 @@ int samd_static_build(const int32_t *h_tokens, const int64_t *h_doc_offsets, int
 int samd_static_from_tables(int32_t kind, int64_t n_states, const int32_t *h_link, const int32_t *h_length,
                             const int32_t *h_aux, const int32_t *h_deg, const int32_t *h_edge_tok,
                             const int32_t *h_edge_dst, const int32_t *h_text, int64_t n_text, samd_static_t **out);
+/* load_sam of a pickle WRITTEN BY THE REFERENCE's dump_sam -- SO/sam/utils.py:20-39, S/sam/utils.py (pickle.dump of the StaticSAM object
+ * graph: `states` = list of SAMState {next, link, length, cnt_endpos | min_endpos}, `input_ids` for the samd variant).  A streaming reader
+ * of the pickle opcode subset that graph uses (protocols 2-5): states go straight into flat tables and on into the node image, nothing of
+ * the stream is executed, peak memory ~ the image (CPython's unpickler keeps three objects per state alive: tens of GB for the published
+ * 20-35 M-state automata).  kind = SAMD_KIND_COUNT (samd_sam_only) or SAMD_KIND_ENDPOS (samd).  out_params (optional, 8 doubles):
+ * max_predicts, alpha, K, n_predicts, cur_index, cur_length, last, max_length as pickled (-1 = absent).  SAMD_E_IO: not such a pickle /
+ * an opcode outside the subset (samd_last_error names it) -- the caller may then fall back to pickle.load. */
+int samd_static_from_pickle(const char *path, int32_t kind, double out_params[8], samd_static_t **out);
 /* dump_sam / load_sam  -- SO/sam/utils.py:20-39 (flat binary image instead of a pickle) */
 int samd_static_save(const samd_static_t *sam, const char *path);
 int samd_static_load(const char *path, samd_static_t **out);

@@ -165,9 +165,11 @@ int layout(int32_t kind, int64_t n_states, const int32_t *link, const int32_t *l
     int64_t n_edges = 0, n_spill = 0;
     int32_t max_root_tok = -1;
     for (int64_t i = 0; i < n_states; i++) {
+        if (deg[i] < 0) { free(s); samd_set_error("negative degree"); return SAMD_E_INVALID; }
         if (deg[i] > SAMD_INLINE_EDGES) n_spill += SAMD_SPILL_HEAD + samd_spill_slots(deg[i]);
         n_edges += deg[i];
     }
+    if (n_edges > 0 && (!edge_tok || !edge_dst)) { free(s); samd_set_error("edge arrays missing"); return SAMD_E_INVALID; }
     for (int32_t j = 0; j < deg[0]; j++) max_root_tok = std::max(max_root_tok, edge_tok[j]);
     s->n_edges = n_edges; s->n_spill = n_spill; s->vocab = (int64_t)max_root_tok + 1;
     if (n_spill >= (1ll << 31)) { free(s); samd_set_error("spill region too large"); return SAMD_E_CAPACITY; }
@@ -229,6 +231,8 @@ struct FileHeader { char magic[8]; int64_t version, kind, n_states, n_edges, n_s
 
 }  // namespace
 
+static bool image_is_sane(const samd_static_t *s, const char **why);
+
 extern "C" {
 
 int samd_static_build(const int32_t *h_tokens, const int64_t *h_doc_offsets, int64_t n_docs, int32_t eos_token,
@@ -263,7 +267,12 @@ int samd_static_from_tables(int32_t kind, int64_t n_states, const int32_t *h_lin
         samd_set_error("samd_static_from_tables: invalid argument"); return SAMD_E_INVALID;
     }
     try {
-        return layout(kind, n_states, h_link, h_length, h_aux, h_deg, h_edge_tok, h_edge_dst, h_text, n_text, out);
+        const int rc = layout(kind, n_states, h_link, h_length, h_aux, h_deg, h_edge_tok, h_edge_dst, h_text, n_text, out);
+        if (rc != SAMD_OK) return rc;
+        // tables come from outside the builder (a reference pickle, a converter): the same structural check a loaded image gets
+        const char *why = "";
+        if (!image_is_sane(*out, &why)) { samd_static_free(*out); *out = nullptr; samd_set_error("samd_static_from_tables: inconsistent tables (%s)", why); return SAMD_E_INVALID; }
+        return SAMD_OK;
     } catch (const std::exception &e) {
         samd_set_error("samd_static_from_tables: %s", e.what());
         return SAMD_E_CAPACITY;

@@ -75,6 +75,7 @@ _PROTOS = {
     "samd_static_free": (None, [_VP]),
     "samd_static_upload": (C.c_int, [_VP]),
     "samd_static_info": (C.c_int, [_VP, _VP]),
+    "samd_static_from_pickle": (C.c_int, [C.c_char_p, _I32, _VP, _VP]),
     "samd_static_derived_info": (C.c_int, [_VP, _VP]),
     "samd_static_set_bigram_slots": (C.c_int, [_VP, _I32, _VP]),
     "samd_static_export": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -286,6 +287,17 @@ class StaticAutomaton:
         check(lib().samd_static_from_tables(kind, len(arrs[0]), *[_ptr(a) for a in arrs], _ptr(t), 0 if t is None else len(t),
                                             C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def from_reference_pickle(cls, path, kind=KIND_COUNT):
+        """a pickle written by the reference's dump_sam, read by the native streaming reader (include/samd_hip.h samd_static_from_pickle).
+        -> (automaton, {max_predicts, alpha, K, n_predicts, cur_index, cur_length, last, max_length} as pickled); raises SamdError when the
+        file is not such a pickle"""
+        h = C.c_void_p()
+        params = (C.c_double * 8)()
+        check(lib().samd_static_from_pickle(os.fsencode(path), int(kind), params, C.byref(h)))
+        names = ("max_predicts", "alpha", "K", "n_predicts", "cur_index", "cur_length", "last", "max_length")
+        return cls(h), {n: (None if v == -1.0 else v) for n, v in zip(names, params)}
 
     @classmethod
     def load(cls, path):

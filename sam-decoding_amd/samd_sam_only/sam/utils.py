@@ -31,11 +31,31 @@ def load_image_or_pickle(path: str, cls):
     if is_image:
         sam = cls._from_automaton(samd_hip.StaticAutomaton.load(path))
     else:
+        sam = load_reference_pickle(path, cls)
+        sam.init_topk_next()
+    print("loading ended in {} seconds.".format(time.perf_counter() - start))
+    return sam
+
+
+def load_reference_pickle(path: str, cls):
+    """a pickle written by the reference's dump_sam (SO/sam/utils.py:20-22).  First the native streaming reader
+    (samd_static_from_pickle: the states go straight into flat tables, peak memory ~ the node image, nothing in the stream is executed --
+    the published 20-35 M-state automata would otherwise become ~10^8 live Python objects); a pickle outside its opcode subset falls back to
+    pickle.load + cls.__setstate__ (small files, odd protocols), with a warning that says why."""
+    try:
+        auto, pickled = samd_hip.StaticAutomaton.from_reference_pickle(path, cls.KIND)
+    except samd_hip.SamdError as e:
+        import warnings
+        warnings.warn(f"native pickle reader declined {path} ({e}); falling back to pickle.load", RuntimeWarning)
         with open(path, "rb") as f:
             sam = pickle.load(f)
         assert type(sam) is cls
-        sam.init_topk_next()
-    print("loading ended in {} seconds.".format(time.perf_counter() - start))
+        return sam
+    sam = cls._from_automaton(auto)
+    for key in ("max_predicts", "alpha", "K", "n_predicts"):            # utils.py:29-33 copies the pickled attributes a fresh object also has
+        v = pickled.get(key)
+        if v is not None and hasattr(sam, key):
+            setattr(sam, key, type(getattr(sam, key))(v))
     return sam
 
 

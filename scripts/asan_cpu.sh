@@ -3,7 +3,7 @@
 #   * the native static-automaton builder, the SAMDHIP1 image parser + structural check, export / host-image entry points
 #     (sam-decoding_amd/csrc/sam_build.cpp and the host halves of the other sources), and
 #   * the CPU oracle (oracle/sam_oracle.c),
-# under tests/test_builder_cpu.py, test_gen_sam_cpu.py, test_oracle_golden.py and the loader fuzz tests/test_image_fuzz_cpu.py.
+# under tests/test_builder_cpu.py, test_gen_sam_cpu.py, test_oracle_golden.py, the loader fuzz tests/test_image_fuzz_cpu.py and the pickle reader tests/test_pickle_import_cpu.py.
 #
 # The library is the REAL one: every source compiled by hipcc with the sanitizers on the HOST pass only (-Xarch_host; the gfx950 code
 # objects are the usual ones -- GPU sanitizers do not exist on this pool), so the tests load it through the ordinary binding
@@ -22,7 +22,7 @@ SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-fram
 XSAN=""
 for f in $SAN; do XSAN="$XSAN -Xarch_host $f"; done
 CSRC="$ROOT/sam-decoding_amd/csrc"
-SRCS="sam_build.cpp sam_kernels.hip verify_kernels.hip attn_kernels.hip eagle_kernels.hip lm_kernels.hip gemm_kernels.hip"
+SRCS="sam_build.cpp sam_pickle.cpp sam_kernels.hip verify_kernels.hip attn_kernels.hip eagle_kernels.hip lm_kernels.hip gemm_kernels.hip"
 LIB="$OUT/libsamd_hip.so"
 newest=$(ls -t "$CSRC"/*.cpp "$CSRC"/*.hip "$CSRC"/*.h "$ROOT"/include/*.h | head -1)
 if [ ! -f "$LIB" ] || [ "$newest" -nt "$LIB" ]; then
@@ -51,7 +51,7 @@ if [ "${1:-}" = "--run" ]; then          # any command under the sanitizer envir
   exec "$@"
 fi
 if [ $# -eq 0 ]; then
-  set -- tests/test_builder_cpu.py tests/test_gen_sam_cpu.py tests/test_oracle_golden.py tests/test_image_fuzz_cpu.py -x -q -p no:cacheprovider
+  set -- tests/test_builder_cpu.py tests/test_gen_sam_cpu.py tests/test_oracle_golden.py tests/test_image_fuzz_cpu.py tests/test_pickle_import_cpu.py -x -q -p no:cacheprovider
 fi
 echo "[asan] python -m pytest $*"
 exec python -m pytest "$@"

@@ -214,33 +214,71 @@ def verify_against_hf(lm, runner, prompt_len, n, vocab, tol, seed=1, decide_gap=
                   attention_mask=tree_mask_4d(anc, L, n), past_key_values=cache, use_cache=True).logits[0]
     err_tree = (got - want).abs().max().item()
     top2 = want.topk(2, dim=-1).values
-    decided = (top2[:, 0] - top2[:, 1]) > (decide_gap or 4 * tol)      # rows whose fp32 arg-max is not a near-tie
+    decided = (top2[:, 0] - top2[:, 1]) > (decide_gap or 4 * (tol or 0.0))      # rows whose fp32 arg-max is not a near-tie
     agree = (b["argmax"][:n].long() == want.argmax(-1))
     print(f"prefill-last |dlogit| {err_prefill:.4f}, tree |dlogit| {err_tree:.4f} (|logit| max {want.abs().max().item():.2f}); arg-max agreement "
           f"{agree.float().mean().item():.3f} over {n} nodes, {int(decided.sum())} decided rows")
-    assert err_prefill < tol and err_tree < tol
-    assert bool(agree[decided].all())
+    if tol is not None:
+        assert err_prefill < tol and err_tree < tol
+        assert bool(agree[decided].all())
+    verify_against_hf.last = dict(argmax=b["argmax"][:n].long().clone(), want=want, ref_last=ref_last.float(), prompt=prompt, toks=toks, anc=anc, depth=depth)
     return err_prefill, err_tree
+
+
+def hf_low_precision_twin(lm, dtype):
+    """the reference's own arithmetic: the same HF module cast to the serving dtype (what SO/samd_model.py:134-138 runs), rotary
+    frequencies kept in fp32 as from_pretrained(dtype=...) keeps them"""
+    import copy
+    lm16 = copy.deepcopy(lm).to(dtype)
+    lm16.model.rotary_emb.inv_freq = lm.model.rotary_emb.inv_freq.clone()
+    if hasattr(lm16.model.rotary_emb, "original_inv_freq"):
+        lm16.model.rotary_emb.original_inv_freq = lm.model.rotary_emb.inv_freq.clone()
+    return lm16
+
+
+def check_against_reference_arithmetic(lm, lm16, runner, prompt_len, n, vocab, seed, label):
+    """OUR forward against fp32 HuggingFace, with the yardstick the reference itself sets: the same model run by HF in the serving dtype.
+    Asserts err(ours, fp32) <= 1.5 x err(HF-low, fp32) (+ 0.02) after the prefill and on the tree rows, and arg-max agreement with
+    HF-LOW-PRECISION -- the tokens the reference would emit -- on every node whose fp32 top-2 gap exceeds twice that error."""
+    from transformers import DynamicCache
+    e_pre, e_tree = verify_against_hf(lm, runner, prompt_len, n, vocab, tol=None, seed=seed)
+    c = verify_against_hf.last
+    ids = torch.tensor([c["prompt"]], device="cuda")
+    with torch.no_grad():
+        cache = DynamicCache()
+        last16 = lm16(input_ids=ids, past_key_values=cache, use_cache=True, logits_to_keep=1).logits[0, -1].float()
+        mask = tree_mask_4d(c["anc"], prompt_len, n).to(next(lm16.parameters()).dtype)
+        tree16 = lm16(input_ids=torch.tensor([c["toks"]], device="cuda"), position_ids=torch.tensor([[prompt_len + x for x in c["depth"]]], device="cuda"),
+                      attention_mask=mask, past_key_values=cache, use_cache=True).logits[0].float()
+    hf_pre = (c["ref_last"] - last16).abs().max().item()
+    hf_tree = (c["want"] - tree16).abs().max().item()
+    print(f"{label}, L={prompt_len}, n={n}: ours vs fp32 {e_pre:.4f} / {e_tree:.4f}; HF low-precision vs fp32 {hf_pre:.4f} / {hf_tree:.4f}")
+    assert e_pre <= 1.5 * hf_pre + 0.02 and e_tree <= 1.5 * hf_tree + 0.02, (e_pre, hf_pre, e_tree, hf_tree)
+    top2 = c["want"].topk(2, dim=-1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 2 * max(e_tree, hf_tree)
+    assert int(decided.sum()) >= n // 2                                        # the criterion must bite on most nodes
+    assert bool((c["argmax"] == tree16.argmax(-1))[decided].all())
+    return e_pre, e_tree, hf_pre, hf_tree
 
 
 def test_vicuna_7b_shape_forward_matches_hf_fp32():
     """The forward bench.py times -- 32 layers, hidden 4096, 32 heads, inter 11008, vocab 32000, fp16 -- against a random-init
     transformers LlamaForCausalLM of the same shape in fp32 (27 GB) on the same GPU: last-position logits after a 1000-token
     prefill, then a 60-node tree verify over the cached prompt with the reference's 4-D additive tree mask
-    (samd_sam_only/model_patch/llama.py:82-96).  Tolerance 0.15 absolute on logits whose magnitude reaches ~6.5, i.e. 2.3 % of the
-    logit range (measured on MI355X: 0.070 after the prefill, 0.081 on the tree rows -- fp16 activations rounded ~250 times on the way
-    through 32 layers, each 5e-4 relative, against fp32); the arg-max must agree on every node whose fp32 top-2 gap exceeds 4x
-    that (measured: 93 % of all 60 nodes agree, all of the decided ones)."""
+    (samd_sam_only/model_patch/llama.py:82-96), then a 13-node tree on the 16-row bucket (the norm-fold forward).  Round 5:
+    no absolute tolerance any more -- the yardstick is the reference's OWN arithmetic, the same HF model cast to fp16 (what
+    SO/samd_model.py:134-138 runs on Vicuna): our error against fp32 must stay within 1.5x of HF-fp16's error against fp32, and our
+    arg-max must equal HF-fp16's on every node whose fp32 top-2 gap exceeds twice that error (check_against_reference_arithmetic; the
+    bf16 Llama-3 test below uses the same criterion).  Measured on MI355X: ours 0.070 / 0.081 on logits of magnitude ~6.5."""
     from samd_hip.llama import LlamaRunner
     cfg = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=32,
                vocab_size=32000, max_position_embeddings=2048, rms_norm_eps=1e-6)
     lm = hf_llama(cfg, seed=0)
-    runner = LlamaRunner.from_hf(lm, max_cache_len=2048, dtype=torch.float16)
-    verify_against_hf(lm, runner, 1000, 60, 32000, tol=0.15)
-    # a 13-node tree runs the 16-row bucket: the norm-fold forward (RMSNorm applied by the consuming projections, residual adds by the
-    # producing ones; LlamaRunner._forward_rows_fold) against the same fp32 model
+    runner = LlamaRunner.from_hf(lm, max_cache_len=2048, dtype=torch.float16, share_weights=False)
     assert runner.norm_fold
-    verify_against_hf(lm, runner, 700, 13, 32000, tol=0.15, seed=2)
+    lm16 = hf_low_precision_twin(lm, torch.float16)
+    check_against_reference_arithmetic(lm, lm16, runner, 1000, 60, 32000, seed=1, label="vicuna-7b fp16, 64-row bucket")
+    check_against_reference_arithmetic(lm, lm16, runner, 700, 13, 32000, seed=2, label="vicuna-7b fp16, 16-row bucket (norm-fold)")
 
 
 def test_norm_fold_forward_equals_the_eight_launch_forward(monkeypatch):
