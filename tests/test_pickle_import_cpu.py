@@ -202,6 +202,7 @@ print(json.dumps({"how": how, "seconds": dt, "peak_rss_delta": hwm() - base, "n_
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "samd_sam_only")), reason="needs the reference checkout (dev container only)")
+@pytest.mark.skipif(bool(os.environ.get("SAMD_HIP_LIB")), reason="a timing / memory measurement: not under the sanitizer build")
 def test_a_pickle_of_2_to_the_20_tokens_written_by_the_reference(tmp_path):
     """the reference builds (StaticSAM.build), pickles (dump_sam) -- this process only orchestrates; the import runs in a child so that its
     peak memory is its own.  Bars: state table == the oracle's; native peak RSS <= 3 x the image; reported beside the pickle.load route."""
