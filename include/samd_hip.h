@@ -107,8 +107,10 @@ int samd_static_info(const samd_static_t *sam, int64_t out[8]);
 /* what the upload DERIVES on the device next to the image (csrc/samd_common.h): out[0] = bytes of the chain words, out[1] = bytes of the
  * bigram table with its root entries and child bitmap, out[2] = bytes of the top-k count table, out[3] = slots of the bigram table
  * (a power of two, >= 4 x the number of root-child edges by default: SAMD_BIGRAM_SLOTS_PER_PAIR / samd_static_set_bigram_slots); zeros for
- * what was not derived.  These bytes are resident per GPU replica NEXT to samd_static_info's device bytes (the image). */
-int samd_static_derived_info(const samd_static_t *sam, int64_t out[4]);
+ * what was not derived; out[4] = bytes, out[5] = slots of the EDGE TABLE of the branching states (round 5: one probe per transition out of a
+ * state of degree >= 2, csrc/samd_common.h; sized like the bigram table).  These bytes are resident per GPU replica NEXT to
+ * samd_static_info's device bytes (the image). */
+int samd_static_derived_info(const samd_static_t *sam, int64_t out[6]);
 /* re-size the bigram table of an uploaded automaton: slots_per_pair in 2 .. 64 (0 = the default, 4).  A tuning entry with no reference
  * counterpart: a sparser table only helps the BATCHED walk (samd_static_walk* / samd_static_lookup_batch: 64 cursors in lock-step pay a
  * second probe round when any collides -- 16 per pair measured best, profiles/r04_walk.md); one-cursor walks of a session are

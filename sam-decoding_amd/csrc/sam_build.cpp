@@ -293,6 +293,7 @@ void samd_static_free(samd_static_t *s) {
     if (s->d_d1hash) (void)hipFree(s->d_d1hash);
     if (s->d_rc_bits) (void)hipFree(s->d_rc_bits);
     if (s->d_topk_cnt) (void)hipFree(s->d_topk_cnt);
+    if (s->d_ehash) (void)hipFree(s->d_ehash);
     free(s);
 }
 
@@ -304,8 +305,10 @@ int samd_static_info(const samd_static_t *s, int64_t out[8]) {
     return SAMD_OK;
 }
 
-int samd_static_derived_info(const samd_static_t *s, int64_t out[4]) {
+int samd_static_derived_info(const samd_static_t *s, int64_t out[6]) {
     if (!s || !out) return SAMD_E_INVALID;
+    out[4] = s->d_ehash ? s->n_ehash * 16 : 0;
+    out[5] = s->d_ehash ? s->n_ehash : 0;
     out[0] = s->d_chain ? s->n_states * 16 : 0;
     out[1] = s->d_d1hash ? s->n_d1hash * 16 + s->vocab * 16 + ((s->vocab + 31) / 32) * 4 : 0;
     out[2] = s->d_topk_cnt ? s->n_states * (int64_t)SAMD_TOPK * 4 : 0;

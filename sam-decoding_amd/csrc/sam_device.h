@@ -87,15 +87,17 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
 // used = tokens of this word already consumed; (nlo, nhi) = the NEXT word of the run when have_next: requested while the last entry of
 // this one is still unused, so that a cursor deep in a run never waits for a word (a wave otherwise stalls at the top of every token
 // for the lanes -- one in eight -- that used up a word at the previous one)
-struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next; };
-__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = c.nlo = c.nhi = ~0ull; c.used = 0; c.have_next = 0; return c; }
+// hub (round 5) = the cursor's state is BRANCHING and therefore in the edge table (samd_common.h): known from the table entry that led to it;
+// its next transition probes the table without looking at the node
+struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next, hub; };
+__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = c.nlo = c.nhi = ~0ull; c.used = 0; c.have_next = 0; c.hub = 0; return c; }
 __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
     const uint4 c = S.chain[state];
     ChainWord w;
     w.lo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
     w.hi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
     w.nlo = w.nhi = ~0ull;
-    w.used = 0; w.have_next = 0;
+    w.used = 0; w.have_next = 0; w.hub = 0;
     return w;
 }
 // the first half of a state's chain word, as the root-child hash stores it beside the edge that leads there (samd_common.h): it serves
@@ -105,7 +107,7 @@ __device__ __forceinline__ ChainWord chain_half(unsigned lo, unsigned hi) {
     ChainWord w;
     w.lo = (unsigned long long)lo | ((unsigned long long)hi << 32);
     w.hi = w.nlo = w.nhi = ~0ull;
-    w.used = W / 2; w.have_next = 0;
+    w.used = W / 2; w.have_next = 0; w.hub = 0;
     return w;
 }
 // the FIRST entry of a state's chain word (the bigram table's entries of large vocabularies have room for one): one transition, then the
@@ -115,8 +117,27 @@ __device__ __forceinline__ ChainWord chain_first(unsigned first) {
     ChainWord w;
     w.lo = (unsigned long long)first | (W == 8 ? 0xFFFFFFFFFFFF0000ull : 0xFFFFFFFF00000000ull);
     w.hi = w.nlo = w.nhi = ~0ull;
-    w.used = W - 1; w.have_next = 0;
+    w.used = W - 1; w.have_next = 0; w.hub = 0;
     return w;
+}
+// what an EDGE TABLE entry carries of chain[dst]: its first 32 bits -- two entries (W = 8) or one (W = 4)
+template <int W>
+__device__ __forceinline__ ChainWord chain_from_edge(unsigned x) {
+    if (W != 8) return chain_first<W>(x);
+    ChainWord w;
+    w.lo = (unsigned long long)x | 0xFFFFFFFF00000000ull;
+    w.hi = w.nlo = w.nhi = ~0ull;
+    w.used = W - 2; w.have_next = 0; w.hub = 0;
+    return w;
+}
+// is (state, tok) in the edge table?  e = the slot already loaded at h; linear probing
+__device__ __forceinline__ bool edge_find(const StaticDev &S, int state, int tok, uint32_t h, uint4 &e) {
+    for (uint32_t probes = 0; probes <= S.edge_mask; probes++) {
+        if (e.x == (unsigned)state && e.y == (unsigned)tok) return true;
+        if (e.x == 0xFFFFFFFFu) return false;
+        h = (h + 1) & S.edge_mask; e = S.ehash[h];
+    }
+    return false;
 }
 
 // A cursor that sits on the root child of token a is carried as idx = -2 - a (samd_common.h, BIGRAM TABLE) and resolved where an index is
@@ -142,7 +163,7 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint3
     const unsigned ent = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
     const bool is_tok = (ent & LOW) != LOW;                  // a chain token (the end marker is all-ones)
     if (is_tok && (ent & LOW) == (unsigned)tok) {            // register path
-        idx += 1; len += 1;
+        idx += 1; len += 1; cw.hub = 0;
         if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
         else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
         // a FULL word used up: the run may go on -- its next word was requested one token ago (below); without it (a word that came
@@ -164,6 +185,8 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint3
     // flagged entry: idx has one edge, and it is not `tok`; its suffix link is the root child of ptok.  transfer_state visits idx, hops
     // (length <- states[link].length) and looks for `tok` there -- in the bigram table under (ptok, tok)
     const bool climbing = is_tok && !(ent & HI) && ptok >= 0 && have_table;
+    const bool have_edges = S.ehash != nullptr;
+    const bool at_hub = cw.hub && have_edges && idx > 0;
     cw = chain_none();
     int visited = climbing ? 1 : 0;
     const bool probing = climbing || st_on_child(idx);
@@ -176,8 +199,8 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint3
     // pays per token is the number of dependent PHASES, not of loads: with the kinds in separate branches a token cost their sum
     // (profiles/r04_walk.md).
     const int a = climbing ? ptok : -2 - idx;
-    uint32_t h = probing ? samd_bigram_hash(a, tok) & S.bigram_mask : 0u;
-    const uint4 *addr = probing ? S.bigram + h : reinterpret_cast<const uint4 *>(S.nodes + idx);
+    uint32_t h = probing ? samd_bigram_hash(a, tok) & S.bigram_mask : (at_hub ? samd_edge_hash(idx, tok) & S.edge_mask : 0u);
+    const uint4 *addr = probing ? S.bigram + h : (at_hub ? S.ehash + h : reinterpret_cast<const uint4 *>(S.nodes + idx));
     const uint4 first = *addr;
     if (probing) {
         uint4 e = first;
@@ -194,13 +217,62 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint3
                 len = lb < 3 ? (int)lb + 1 : (int)S.root16[a].w;
             }
             len += 1;
-            if (W == 8) { idx = (int)e.y; cw = chain_half<W>(e.z, e.w); }
-            else { idx = (int)e.z; cw = chain_first<W>(e.w); }
+            if (W == 8) { idx = (int)(e.y & 0x7FFFFFFFu); cw = chain_half<W>(e.z, e.w); cw.hub = (int)(e.y >> 31); }
+            else { idx = (int)(e.z & 0x7FFFFFFFu); cw = chain_first<W>(e.w); cw.hub = (int)(e.z >> 31); }
             return visited + 1;
         }
         // no edge in the table = that state visited too, then the hop to ITS suffix link, the root
         st_from_root(S, bits, tok, idx, len);
         return visited + 2;
+    }
+    if (have_edges) {
+        // ---- with the EDGE TABLE: a branching state answers in one probe; a climb issues a hop's node word 0 and its probe together ----------
+        auto follow = [&](const uint4 &e) {
+            idx = (int)(e.z & 0x7FFFFFFFu); len += 1;
+            cw = chain_from_edge<W>(e.w); cw.hub = (int)(e.z >> 31);
+        };
+        auto from_root = [&]() {
+            if (have_table) st_from_root(S, bits, tok, idx, len);
+            else { const int nx = tok < S.vocab ? S.root_next[tok] : -1; if (nx >= 0) { idx = nx; len += 1; } else { idx = 0; len = 0; } }
+        };
+        visited++;
+        if (idx == 0) { from_root(); return visited; }
+        int link;
+        if (at_hub) {                                         // the cursor's own state, known to branch: the probe decides; its node only on a miss
+            uint4 e = first;
+            if (edge_find(S, idx, tok, h, e)) { follow(e); return visited; }
+            link = S.nodes[idx].link;
+        } else {
+            const int4 w0 = make_int4((int)first.x, (int)first.y, (int)first.z, (int)first.w);
+            if (w0.z == tok) {                                // rank-0 edge
+                idx = w0.w; len += 1;
+                if (w0.y & SAMD_RUN) cw = chain_load(S, idx);
+                return visited;
+            }
+            if (!(w0.y & SAMD_SINGLE)) {                      // more edges: all of them are in the table
+                uint32_t h2 = samd_edge_hash(idx, tok) & S.edge_mask;
+                uint4 e = S.ehash[h2];
+                if (edge_find(S, idx, tok, h2, e)) { follow(e); return visited; }
+            }
+            link = w0.x;
+        }
+        idx = link;
+        for (;;) {                                            // the climb (static_sam.py:99-101)
+            visited++;
+            if (idx == 0) { len = 0; from_root(); return visited; }
+            const uint32_t h2 = samd_edge_hash(idx, tok) & S.edge_mask;
+            const int4 w0 = reinterpret_cast<const int4 *>(S.nodes + idx)[0];       // two independent loads: one round per hop
+            uint4 e = S.ehash[h2];
+            len = w0.y & SAMD_LEN_MASK;                       // length <- states[link].length
+            if (w0.y & SAMD_SINGLE) {
+                if (w0.z == tok) {
+                    idx = w0.w; len += 1;
+                    if (w0.y & SAMD_RUN) cw = chain_load(S, idx);
+                    return visited;
+                }
+            } else if (edge_find(S, idx, tok, h2, e)) { follow(e); return visited; }
+            idx = w0.x;
+        }
     }
     bool hopped = false, use_first = true;
     for (;;) {

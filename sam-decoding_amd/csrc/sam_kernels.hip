@@ -19,6 +19,7 @@ static inline StaticDev static_view(const samd_static_t *s) {
     v.chain = (const uint4 *)s->d_chain; v.chain_w = s->vocab <= 32767 ? 8 : 4;
     v.root16 = (const uint4 *)s->d_root16; v.bigram = (const uint4 *)s->d_d1hash; v.bigram_mask = s->n_d1hash > 0 ? (uint32_t)(s->n_d1hash - 1) : 0u;
     v.rc_bits = (const uint32_t *)s->d_rc_bits;
+    v.ehash = (const uint4 *)s->d_ehash; v.edge_mask = s->n_ehash > 0 ? (uint32_t)(s->n_ehash - 1) : 0u;
     v.topk_cnt = (const int32_t *)s->d_topk_cnt;
     return v;
 }
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(256) void k_bg_count(const SamNode *__restrict__ no
 }
 __global__ __launch_bounds__(256) void k_bg_fill(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, const int32_t *__restrict__ root_next,
                                                  int vocab, const uint4 *__restrict__ chain, uint4 *__restrict__ root16, uint4 *__restrict__ table, uint32_t mask,
-                                                 uint32_t *__restrict__ rc_bits, int W) {
+                                                 uint32_t *__restrict__ rc_bits, int W, int with_hub) {
     const int tok = blockIdx.x * blockDim.x + threadIdx.x;
     if (tok >= vocab) return;
     const int dst = root_next[tok];
@@ -452,12 +453,13 @@ __global__ __launch_bounds__(256) void k_bg_fill(const SamNode *__restrict__ nod
         if (t < 0) return;
         uint32_t h = samd_bigram_hash(tok, t) & mask;
         const uint4 c = d > 0 ? chain[d] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        const unsigned hub = (with_hub && d > 0 && !(nodes[d].length & SAMD_SINGLE)) ? 0x80000000u : 0u;     // dst is branching: it is in the edge table
         if (W == 8) {
             const unsigned key = (unsigned)tok | ((unsigned)t << 15) | (lb << 30);
             for (;;) {
                 unsigned *kp = reinterpret_cast<unsigned *>(table + h);
                 const unsigned old = atomicCAS(kp, 0xFFFFFFFFu, key);
-                if (old == 0xFFFFFFFFu) { kp[1] = (unsigned)d; kp[2] = c.x; kp[3] = c.y; return; }
+                if (old == 0xFFFFFFFFu) { kp[1] = (unsigned)d | hub; kp[2] = c.x; kp[3] = c.y; return; }
                 if (old == key) return;                                                                   // (the spill head repeats ranks 5..7)
                 h = (h + 1) & mask;
             }
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256) void k_bg_fill(const SamNode *__restrict__ nod
             for (;;) {
                 unsigned long long *kp = reinterpret_cast<unsigned long long *>(table + h);
                 const unsigned long long old = atomicCAS(kp, ~0ull, key);
-                if (old == ~0ull) { unsigned *wp = reinterpret_cast<unsigned *>(kp); wp[2] = (unsigned)d; wp[3] = c.x; return; }
+                if (old == ~0ull) { unsigned *wp = reinterpret_cast<unsigned *>(kp); wp[2] = (unsigned)d | hub; wp[3] = c.x; return; }
                 if (old == key) return;
                 h = (h + 1) & mask;
             }
@@ -491,6 +493,95 @@ __global__ __launch_bounds__(256) void k_topk_counts(const SamNode *__restrict__
     int dst = -1;
     if (k < w[5]) dst = k < SAMD_INLINE_EDGES ? w[SAMD_EDGE_WORD(k) + 1] : spill[w[14] + k - SAMD_INLINE_EDGES].dst;
     out[i] = dst >= 0 ? nodes[dst].aux : 0;
+}
+
+// edge table (samd_common.h, EDGE TABLE): count the edges of the branching states, then fill.  One thread per state.
+__global__ __launch_bounds__(256) void k_eh_count(const SamNode *__restrict__ nodes, long long n, unsigned long long *__restrict__ total) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long d = 0;
+    if (s >= 1 && s < n) { const int deg = nodes[s].deg; if (deg >= 2) d = (unsigned long long)deg; }
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(total, d);
+}
+__global__ __launch_bounds__(256) void k_eh_fill(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, long long n, const uint4 *__restrict__ chain,
+                                                 uint4 *__restrict__ table, uint32_t mask) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < 1 || s >= n) return;
+    const int *w = reinterpret_cast<const int *>(nodes + s);
+    const int deg = w[5];
+    if (deg < 2) return;
+    auto put = [&](int t, int d) {
+        if (t < 0 || d < 0) return;
+        uint32_t h = samd_edge_hash((int)s, t) & mask;
+        const unsigned hub = !(nodes[d].length & SAMD_SINGLE) ? 0x80000000u : 0u;
+        const unsigned long long key = (unsigned long long)(unsigned)s | ((unsigned long long)(unsigned)t << 32);
+        for (;;) {
+            unsigned long long *kp = reinterpret_cast<unsigned long long *>(table + h);
+            const unsigned long long old = atomicCAS(kp, ~0ull, key);
+            if (old == ~0ull) { unsigned *wp = reinterpret_cast<unsigned *>(kp); wp[2] = (unsigned)d | hub; wp[3] = chain[d].x; return; }
+            if (old == key) return;                                                                      // (the spill head repeats ranks 5..7)
+            h = (h + 1) & mask;
+        }
+    };
+    for (int k = 0; k < SAMD_INLINE_EDGES; k++) put(w[SAMD_EDGE_WORD(k)], w[SAMD_EDGE_WORD(k) + 1]);
+    if (deg > SAMD_INLINE_EDGES) {
+        const SamEdge *sp = spill + w[14];
+        const uint32_t slots = samd_spill_slots(deg);
+        for (uint32_t k = 0; k < SAMD_SPILL_HEAD + slots; k++) put(sp[k].tok, sp[k].dst);
+    }
+}
+
+static long long table_budget_bytes() {
+    long long budget = 8ll << 30;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { if ((long long)(free_b / 8) < budget) budget = (long long)(free_b / 8); } else (void)hipGetLastError();
+    return budget;
+}
+static int table_slots_per_entry(int arg) {
+    static const int per_env = [] { const char *e = getenv("SAMD_BIGRAM_SLOTS_PER_PAIR"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : (v > 64 ? 64 : v); }();
+    return arg > 0 ? (arg < 2 ? 2 : (arg > 64 ? 64 : arg)) : per_env;
+}
+
+// the edge table of the branching states; sized and budgeted like the bigram table (slots per entry: the same knob).  An accelerator: when
+// the device cannot spare it the walks go through the nodes as before.  SAMD_EDGE_TABLE=0 switches it off (A/B).
+static int derive_edge_hash(samd_static_t *s, hipStream_t st, int per_arg) {
+    const char *env = getenv("SAMD_EDGE_TABLE");                      // read at every derivation: tests upload the same automaton both ways
+    const bool enabled = !(env && env[0] == '0');
+    if (s->d_ehash) { (void)hipFree(s->d_ehash); s->d_ehash = nullptr; }
+    s->n_ehash = 0;
+    if (!enabled || !s->d_chain || s->n_states < 2) return SAMD_OK;
+    const long long n = (long long)s->n_states;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    unsigned long long *d_total = nullptr, total = 0;
+    if (hipMalloc((void **)&d_total, 8) != hipSuccess) { (void)hipGetLastError(); return SAMD_OK; }
+    int rc = SAMD_OK;
+    if (hipMemsetAsync(d_total, 0, 8, st) != hipSuccess) rc = SAMD_E_HIP;
+    if (rc == SAMD_OK) {
+        hipLaunchKernelGGL(k_eh_count, dim3(blocks), dim3(256), 0, st, s->d_nodes, n, d_total);
+        if (hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
+    }
+    (void)hipFree(d_total);
+    if (rc != SAMD_OK) { samd_set_error("edge table derivation failed"); return rc; }
+    if (total == 0) return SAMD_OK;
+    const int per = table_slots_per_entry(per_arg);
+    const long long budget = table_budget_bytes();
+    long long slots = 1024;
+    while (slots < per * (long long)total) slots <<= 1;
+    while (slots * 16 > budget && slots >= 4 * (long long)total) slots >>= 1;
+    if (slots > (1ll << 31) || slots * 16 > budget) return SAMD_OK;                     // does not fit: go without
+    while (hipMalloc(&s->d_ehash, (size_t)slots * 16) != hipSuccess) {
+        s->d_ehash = nullptr; (void)hipGetLastError();
+        if (slots < 4 * (long long)total || slots <= 1024) return SAMD_OK;
+        slots >>= 1;
+    }
+    if (hipMemsetAsync(s->d_ehash, 0xFF, (size_t)slots * 16, st) != hipSuccess) rc = SAMD_E_HIP;
+    if (rc == SAMD_OK) {
+        hipLaunchKernelGGL(k_eh_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, n, (const uint4 *)s->d_chain, (uint4 *)s->d_ehash, (uint32_t)(slots - 1));
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
+    }
+    if (rc != SAMD_OK) { (void)hipFree(s->d_ehash); s->d_ehash = nullptr; samd_set_error("edge table derivation failed"); return rc; }
+    s->n_ehash = slots;
+    return SAMD_OK;
 }
 
 static int derive_topk_counts(samd_static_t *s, hipStream_t st) {
@@ -548,7 +639,7 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg =
         if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)slots * 16, st) != hipSuccess || hipMemsetAsync(s->d_rc_bits, 0, bit_bytes, st) != hipSuccess)) rc = SAMD_E_HIP;
         if (rc == SAMD_OK) {
             hipLaunchKernelGGL(k_bg_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, (const uint4 *)s->d_chain, (uint4 *)s->d_root16,
-                               (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, vocab <= 32767 ? 8 : 4);
+                               (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, vocab <= 32767 ? 8 : 4, s->d_ehash ? 1 : 0);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
         }
         if (rc == SAMD_OK) s->n_d1hash = slots;
@@ -571,15 +662,17 @@ int samd_static_derive_chain(samd_static_t *s, void *stream) {
     else hipLaunchKernelGGL(k_build_chain<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
     LAUNCHCHK();
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { samd_set_error("chain-word derivation failed"); return SAMD_E_HIP; }
-    const int rc = derive_root_hash(s, (hipStream_t)stream);
+    int rc = derive_edge_hash(s, (hipStream_t)stream, 0);
+    if (rc == SAMD_OK) rc = derive_root_hash(s, (hipStream_t)stream);
     return rc != SAMD_OK ? rc : derive_topk_counts(s, (hipStream_t)stream);
 }
 
 int samd_static_set_bigram_slots(samd_static_t *s, int32_t slots_per_pair, void *stream) {
     if (!s || !s->uploaded || !s->d_nodes || slots_per_pair < 0) { samd_set_error("samd_static_set_bigram_slots: invalid argument"); return SAMD_E_INVALID; }
     if (!s->d_chain) return SAMD_OK;                                           // no derived tables on this handle: nothing to re-size
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SAMD_E_HIP;      // nothing may still read the table that is replaced
-    return derive_root_hash(s, (hipStream_t)stream, slots_per_pair);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SAMD_E_HIP;      // nothing may still read the tables that are replaced
+    const int rc = derive_edge_hash(s, (hipStream_t)stream, slots_per_pair);             // (both tables follow the same knob)
+    return rc != SAMD_OK ? rc : derive_root_hash(s, (hipStream_t)stream, slots_per_pair);
 }
 
 int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,

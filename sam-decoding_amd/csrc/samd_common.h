@@ -61,6 +61,12 @@ SAMD_HD static inline uint32_t samd_bigram_hash(int32_t a, int32_t b) {
     h ^= h >> 15; h *= 0x2C1B3C6Du;
     return h ^ (h >> 13);
 }
+// slot of the edge (state, tok) in the edge table (StaticDev), before masking
+SAMD_HD static inline uint32_t samd_edge_hash(int32_t state, int32_t tok) {
+    uint32_t h = (uint32_t)state * 0x85EBCA77u ^ ((uint32_t)tok * 0x9E3779B1u + 0x7F4A7C15u);
+    h ^= h >> 16; h *= 0x2C1B3C6Du;
+    return h ^ (h >> 15);
+}
 SAMD_HD static inline uint32_t samd_spill_hash(int32_t tok, uint32_t slots) {
     return (((uint32_t)tok * 0x9E3779B1u) >> 7) & (slots - 1);
 }
@@ -91,6 +97,17 @@ struct StaticDev {
     const uint4 *bigram;
     uint32_t bigram_mask;
     const uint32_t *rc_bits;
+    // EDGE TABLE (device-only, derived at upload; may be null; round 5).  The bigram table generalised to every BRANCHING state (degree >= 2,
+    // any depth; the root excepted): one open-addressing table keyed by (state, token) holds every edge of every such state,
+    //   entry {state, token, dst | hub(dst) << 31, first entries of chain[dst]}   (16 B; empty = all-ones; slot = samd_edge_hash & edge_mask)
+    // so a transition out of a branching state is ONE probe -- hit or conclusive miss -- where the node costs word 0, then words 1-3, then a
+    // spill probe (three dependent rounds for a hub).  On a natural-language-like corpus (Zipfian vocabulary: hubs of degree 10^2-10^3 at
+    // depth 1-3, 16 % of the states branching) that is where a walk spends its time: every restart climbs through 3-5 short contexts, and a
+    // lock-step wave pays the slowest lane's rounds at every token (profiles/r05_walk_sweep.md).  hub(dst) = dst is itself branching: the
+    // cursor then probes here again next time without looking at dst's node at all.  A climb issues a hop's node word 0 (length, link, the
+    // only edge of a non-branching state) and its probe together: one round per hop.  The bigram table's entries carry the same hub bit.
+    const uint4 *ehash;
+    uint32_t edge_mask;
     // TOP-K COUNTS (device-only, derived at upload; may be null): topk_cnt[8 s + k] = cnt_endpos of state s's rank-k successor, the
     // numerators of the best-first tree's child probabilities (static_sam.py:205-210).  Without it an expansion is two dependent round
     // trips (the parent's node for the edges, then the children's nodes for their counts); with it one.
@@ -169,6 +186,8 @@ struct samd_static {
     void *d_rc_bits;            // which tokens have a root child (StaticDev); owned by the handle
     void *d_topk_cnt;           // top-k counts (StaticDev), KIND_COUNT only; owned by the handle
     int64_t n_d1hash;           // the bigram table's slots (a power of two)
+    void *d_ehash;              // the edge table of the branching states (StaticDev); owned by the handle
+    int64_t n_ehash;            // its slots (a power of two)
 };
 
 // sam_kernels.hip: (re)derive the chain words from the device image; called by upload / adopt and lazily by the walks

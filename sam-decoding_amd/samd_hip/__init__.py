@@ -326,10 +326,10 @@ class StaticAutomaton:
     def derived_info(self):
         """what upload() derived on the device next to the image: bytes of the chain words, of the bigram table (+ root entries, child
         bitmap) and of the top-k counts, and the bigram table's slots (include/samd_hip.h samd_static_derived_info)"""
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 6)()
         check(lib().samd_static_derived_info(self._h, out))
-        d = dict(zip(("chain_bytes", "bigram_bytes", "topk_count_bytes", "bigram_slots"), list(out)))
-        d["resident_bytes"] = self.info()["device_bytes"] + d["chain_bytes"] + d["bigram_bytes"] + d["topk_count_bytes"]      # image + derived, per replica
+        d = dict(zip(("chain_bytes", "bigram_bytes", "topk_count_bytes", "bigram_slots", "edge_table_bytes", "edge_table_slots"), list(out)))
+        d["resident_bytes"] = self.info()["device_bytes"] + d["chain_bytes"] + d["bigram_bytes"] + d["topk_count_bytes"] + d["edge_table_bytes"]      # image + derived, per replica
         return d
 
     def set_bigram_slots(self, slots_per_pair=0):

@@ -371,7 +371,7 @@ def test_bigram_table_size_changes_nothing_but_bytes(vocab):
             assert info["bigram_slots"] * 2 == pairs_x4 or info["bigram_slots"] == 1024
         else:
             assert info["bigram_slots"] == pairs_x4 * per_pair // 4
-        assert info["resident_bytes"] == prod.info()["device_bytes"] + info["chain_bytes"] + info["bigram_bytes"] + info["topk_count_bytes"]
+        assert info["resident_bytes"] == prod.info()["device_bytes"] + info["chain_bytes"] + info["bigram_bytes"] + info["topk_count_bytes"] + info["edge_table_bytes"]
         res = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
         v = torch.zeros(1, dtype=torch.int64, device="cuda")
         prod.lookup_batch(root, d_toks, res, visited=v)
@@ -384,6 +384,80 @@ def test_bigram_table_size_changes_nothing_but_bytes(vocab):
         for t in range(T):
             i, l = ora.transfer_state(i, l, int(toks[t, b]))
         assert tuple(want[b].tolist()) == (i, l)
+
+
+@pytest.mark.parametrize("vocab,n_tok", [(300, 1 << 14), (2000, 1 << 16), (70000, 1 << 15)])
+def test_static_walk_zipf_corpus_with_deep_hubs(vocab, n_tok, monkeypatch):
+    """a natural-language-like corpus (bench.synth_corpus_zipf: Zipfian vocabulary, hubs of degree >> 5 at depth 1-4): the EDGE TABLE path of
+    the walk (round 5: one probe per transition out of a branching state, node word 0 + probe together on every hop of a climb) against the
+    oracle -- every (index, length) of every stream, the visited-state count state for state, cursors carried over a second pass -- and
+    against the same automaton uploaded WITHOUT the table (SAMD_EDGE_TABLE=0)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    flat, off, docs2d = bench.synth_corpus_zipf(n_tok, vocab=vocab, doc_len=128, max_succ=256)
+    docs = [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
+    ora = O.StaticSAM.build(docs, 2)
+    prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    info = prod.derived_info()
+    assert info["edge_table_slots"] >= 1024 and info["edge_table_bytes"] == 16 * info["edge_table_slots"]
+    e = ora.export()
+    assert int(((e["deg"] > 5) & (e["length"] >= 2)).sum()) > 20                    # hubs below the root children exist
+    rng = np.random.default_rng(vocab)
+    B, T = 3000, 32
+    cdf = bench.zipf_cdf(vocab)
+    d = rng.integers(0, docs2d.shape[0], B); s0 = rng.integers(0, docs2d.shape[1] - T, B)
+    toks = docs2d[d[None, :], s0[None, :] + np.arange(T)[:, None]]
+    noise = rng.random((T, B)) < 0.12
+    ntok = (3 + np.searchsorted(cdf, rng.random((T, B)), side="right")).clip(3, vocab + 3)      # incl. out-of-vocabulary ids
+    toks = np.ascontiguousarray(np.where(noise, ntok, toks).astype(np.int32))
+    cur = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    trace = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    visited = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.walk(cur, dev(toks), commit=True, trace=trace)
+    res = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    prod.lookup_batch(torch.zeros((B, 2), dtype=torch.int32, device="cuda"), dev(toks), res, visited=visited)
+    assert torch.equal(res, cur)
+    sub = toks[:, :700]
+    assert int(visited.item()) >= B * T
+    v2 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prod.lookup_batch(torch.zeros((700, 2), dtype=torch.int32, device="cuda"), dev(np.ascontiguousarray(sub)), torch.zeros((700, 2), dtype=torch.int32, device="cuda"), visited=v2)
+    assert int(v2.item()) == walk_visited(e, sub)
+    got = trace.cpu().numpy()
+    for b in range(0, B, 25):
+        i, l = 0, 0
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[t, b]))
+            assert (int(got[t, b, 0]), int(got[t, b, 1])) == (i, l), (b, t)
+    # a second pass from the cursors the first one left (deep states, hubs, root children)
+    rev = dev(np.ascontiguousarray(toks[::-1]))
+    cur2 = cur.clone()
+    trace2 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    prod.walk(cur2, rev, commit=True, trace=trace2)
+    got2 = trace2.cpu().numpy()
+    start = cur.cpu().numpy()
+    for b in range(0, B, 40):
+        i, l = int(start[b, 0]), int(start[b, 1])
+        for t in range(T):
+            i, l = ora.transfer_state(i, l, int(toks[T - 1 - t, b]))
+            assert (int(got2[t, b, 0]), int(got2[t, b, 1])) == (i, l), (b, t)
+    # the single-cursor kernels (a session's committed walk) take the same path
+    sess = samd_hip.Session(64)
+    out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for b in range(0, B, 300):
+        sess.reset()
+        sess.static_walk(prod, dev(toks[:, b].copy()), T, commit=True, d_out=out)
+        assert out.cpu().tolist() == [int(got[T - 1, b, 0]), int(got[T - 1, b, 1])]
+    # and without the table: identical traces and counts
+    monkeypatch.setenv("SAMD_EDGE_TABLE", "0")
+    plain = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+    assert plain.derived_info()["edge_table_slots"] == 0
+    cur3 = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+    trace3 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    v3 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    plain.walk(cur3, dev(toks), commit=True, trace=trace3)
+    plain.lookup_batch(torch.zeros((B, 2), dtype=torch.int32, device="cuda"), dev(toks), res, visited=v3)
+    assert torch.equal(trace3, trace) and torch.equal(cur3, cur) and int(v3.item()) == int(visited.item())
 
 
 def test_static_walk_empty_and_ragged():
