@@ -1148,7 +1148,11 @@ def main():
             # so the token-keyed [V, 8] table learns what the reference's learns on natural text (token_recycle.py:40-48) and the tree
             # steps' accept length is a MEASUREMENT of the method on that source (draft_steps.tree.mean_accept), not a priced path.
             # (Rounds 1-3 ran it on the headline's order-2 source, where a token-keyed table accepts ~1.06.)
-            "tree_steps_priced_not_predictive": False,
+            # computed, not a constant: a random-init draft head (eagle / eagle2 without the plant) or --acceptance natural prices the path
+            "tree_steps_priced_not_predictive": bool((args.variant in ("eagle2", "eagle") and not planted) or (args.variant != "sam_only" and args.acceptance != "scripted")),
+            # the plugin variants' request source is BUILT to fit the method (order-1 text for a token-keyed table; a draft head planted with exactly
+            # the source's distribution): their accept lengths and speed-ups are UPPER BOUNDS on such a source, not measurements on natural text
+            "oracle_draft_source": bool(order1),
             "variant_source": ("order-1 source over %d hot ids, rank probabilities %s, mixed with corpus copies / repeats / noise (bench.synth_request_order1)"
                                % (TR_HOT_VOCAB, list(TR_RANK_P))) + ("; draft head planted with exactly that distribution (plant_order1_head)" if planted else "")
                               if order1 else None,

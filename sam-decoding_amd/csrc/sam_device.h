@@ -89,8 +89,10 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
 // for the lanes -- one in eight -- that used up a word at the previous one)
 // hub (round 5) = the cursor's state is BRANCHING and therefore in the edge table (samd_common.h): known from the table entry that led to it;
 // its next transition probes the table without looking at the node
-struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next, hub; };
-__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = c.nlo = c.nhi = ~0ull; c.used = 0; c.have_next = 0; c.hub = 0; return c; }
+// ptok = the token of the transition that brought the cursor to its state (-1: unknown): what the flagged climb keys the bigram table with.  It
+// lives IN the cursor's word so that it cannot go stale: st_transfer_chain sets it after every transition, a fresh cursor (chain_none) has none.
+struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next, hub, ptok; };
+__device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = c.nlo = c.nhi = ~0ull; c.used = 0; c.have_next = 0; c.hub = 0; c.ptok = -1; return c; }
 __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
     const uint4 c = S.chain[state];
     ChainWord w;
@@ -154,10 +156,18 @@ __device__ __forceinline__ void st_from_root(const StaticDev &S, const uint32_t 
     if (st_has_child(S, bits, tok)) { idx = st_child_of(tok); len = 1; } else { idx = 0; len = 0; }
 }
 
-// ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown.
+// ptok = the token of the previous transition of this cursor (the one that brought it to idx), or -1 when unknown (cw.ptok, see ChainWord).
 // `bits`: see st_has_child.  With the bigram table (S.bigram) the function may leave idx in the unresolved form (st_on_child).
 template <int W>
-__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw) {
+__device__ __forceinline__ int st_transfer_chain_impl(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw);
+template <int W>
+__device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, ChainWord &cw) {
+    const int visited = st_transfer_chain_impl<W>(S, bits, idx, len, tok, cw.ptok, cw);
+    cw.ptok = tok;                                           // (the word may have been replaced inside: set last)
+    return visited;
+}
+template <int W>
+__device__ __forceinline__ int st_transfer_chain_impl(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw) {
     constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
     if (tok < 0) { idx = 0; len = 0; cw = chain_none(); return 1; }
     const unsigned ent = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
@@ -320,11 +330,11 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint3
 __device__ __forceinline__ void st_transfer_tokens(const StaticDev &S, int &idx, int &len, const int *toks, int n) {
     if (S.chain && S.chain_w == 8) {
         ChainWord cw = chain_none();
-        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, S.rc_bits, idx, len, toks[i], i ? toks[i - 1] : -1, cw);
+        for (int i = 0; i < n; i++) st_transfer_chain<8>(S, S.rc_bits, idx, len, toks[i], cw);
         idx = st_resolve(S, idx);
     } else if (S.chain) {
         ChainWord cw = chain_none();
-        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, S.rc_bits, idx, len, toks[i], i ? toks[i - 1] : -1, cw);
+        for (int i = 0; i < n; i++) st_transfer_chain<4>(S, S.rc_bits, idx, len, toks[i], cw);
         idx = st_resolve(S, idx);
     } else {
         for (int i = 0; i < n; i++) st_transfer(S, idx, len, toks[i]);

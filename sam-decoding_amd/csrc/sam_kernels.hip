@@ -16,7 +16,7 @@ static inline StaticDev static_view(const samd_static_t *s) {
     if (!s) { memset(&v, 0, sizeof(v)); return v; }
     v.nodes = s->d_nodes; v.root_next = s->d_root; v.spill = s->d_spill; v.text = s->d_text;
     v.n_states = (int32_t)s->n_states; v.vocab = (int32_t)s->vocab; v.n_text = (int32_t)s->n_text; v.kind = s->kind;
-    v.chain = (const uint4 *)s->d_chain; v.chain_w = s->vocab <= 32767 ? 8 : 4;
+    v.chain = (const uint4 *)s->d_chain; v.chain_w = samd_chain_w(s->vocab);
     v.root16 = (const uint4 *)s->d_root16; v.bigram = (const uint4 *)s->d_d1hash; v.bigram_mask = s->n_d1hash > 0 ? (uint32_t)(s->n_d1hash - 1) : 0u;
     v.rc_bits = (const uint32_t *)s->d_rc_bits;
     v.ehash = (const uint4 *)s->d_ehash; v.edge_mask = s->n_ehash > 0 ? (uint32_t)(s->n_ehash - 1) : 0u;
@@ -54,13 +54,12 @@ __global__ __launch_bounds__(256) void k_static_walk(StaticDev S, const int32_t 
         int idx = c.x, len = c.y;
         int tok = tokens[b];
         ChainWord cw = chain_none();
-        int ptok = -1;
         for (int t = 0; t < T; t++) {
             const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;
-            if (CHAIN) visited += st_transfer_chain<W>(S, bits, idx, len, tok, ptok, cw);
+            if (CHAIN) visited += st_transfer_chain<W>(S, bits, idx, len, tok, cw);
             else visited += st_transfer(S, idx, len, tok);
             if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(CHAIN ? st_resolve(S, idx) : idx, len);
-            ptok = tok; tok = nxt;
+            tok = nxt;
         }
         // the result of the walk: the final (index, length) of every stream -- in place (transfer_tokens), into a separate array (lookup:
         // the reference RETURNS the pair and leaves cur_index / cur_length alone, static_sam.py:122-125), or nowhere (cursors_out null)
@@ -639,7 +638,7 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg =
         if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)slots * 16, st) != hipSuccess || hipMemsetAsync(s->d_rc_bits, 0, bit_bytes, st) != hipSuccess)) rc = SAMD_E_HIP;
         if (rc == SAMD_OK) {
             hipLaunchKernelGGL(k_bg_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, (const uint4 *)s->d_chain, (uint4 *)s->d_root16,
-                               (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, vocab <= 32767 ? 8 : 4, s->d_ehash ? 1 : 0);
+                               (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, samd_chain_w(vocab), s->d_ehash ? 1 : 0);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
         }
         if (rc == SAMD_OK) s->n_d1hash = slots;
@@ -658,7 +657,7 @@ int samd_static_derive_chain(samd_static_t *s, void *stream) {
     if (!s || !s->uploaded || !s->d_nodes) return SAMD_E_INVALID;
     if (!s->d_chain && hipMalloc(&s->d_chain, (size_t)s->n_states * 16) != hipSuccess) { s->d_chain = nullptr; samd_set_error("hipMalloc(chain words) failed"); return SAMD_E_HIP; }
     const unsigned blocks = (unsigned)((s->n_states + 255) / 256);
-    if (s->vocab <= 32767) hipLaunchKernelGGL(k_build_chain<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
+    if (samd_chain_w(s->vocab) == 8) hipLaunchKernelGGL(k_build_chain<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
     else hipLaunchKernelGGL(k_build_chain<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
     LAUNCHCHK();
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { samd_set_error("chain-word derivation failed"); return SAMD_E_HIP; }
@@ -779,7 +778,11 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
     D.push_seq = (int32_t *)(base + o_seq); D.h_report = nullptr;
     if (hipMemset(s->arena, 0, off) != hipSuccess) { (void)hipFree(s->arena); free(s); return SAMD_E_HIP; }
     *out = s;
-    int rc = samd_session_reset(s, nullptr);
+    // the report target exists from the start: SessionDev travels BY VALUE into every launch (and into every captured graph), so a target
+    // created later would be missing from the steps captured before it (they would never push)
+    int32_t *target = nullptr;
+    int rc = samd_session_report_target(s, &target);
+    if (rc == SAMD_OK) rc = samd_session_reset(s, nullptr);
     if (rc == SAMD_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = SAMD_E_HIP;
     if (rc) { samd_session_free(s); *out = nullptr; }
     return rc;

@@ -55,6 +55,9 @@ SAMD_HD static inline uint32_t samd_spill_slots(int32_t deg) {
     while (m < need && m < 0x80000000u) m <<= 1;          // (a degree from a damaged image must not turn this into an endless loop)
     return m;
 }
+// tokens per chain word: 8 x 15-bit entries while every token id fits 15 bits (the all-ones entry is the terminator), else 4 x 31-bit; the ONE
+// place this rule lives (StaticDev::chain_w, the chain-word builder, the bigram and edge table entry forms all follow it)
+SAMD_HD static inline int samd_chain_w(int64_t vocab) { return vocab <= 32767 ? 8 : 4; }
 // slot of the token pair (a, b) in the bigram table (StaticDev), before masking
 SAMD_HD static inline uint32_t samd_bigram_hash(int32_t a, int32_t b) {
     uint32_t h = (uint32_t)a * 0x9E3779B1u + (uint32_t)b * 0x85EBCA77u;

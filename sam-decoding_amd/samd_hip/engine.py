@@ -288,6 +288,12 @@ class DecodeEngine:
             g.replay()
         if push is not None:
             from . import lib
+            # the pushed report needs no stream synchronisation, so a device fault AFTER the step kernel (cache compaction, the next forward)
+            # would surface at some unrelated later call: every 64 steps ask the stream (hipStreamQuery: not-ready is fine, an error raises here)
+            self._steps_since_query = getattr(self, "_steps_since_query", 0) + 1
+            if self._steps_since_query >= 64:
+                self._steps_since_query = 0
+                torch.cuda.current_stream().query()
             if lib().samd_report_wait(push[1], last, 5_000_000) != 0:
                 torch.cuda.current_stream().synchronize()            # surfaces a device fault; a healthy step has pushed by now
                 if int(push[0][REPORT_INTS]) == last:
