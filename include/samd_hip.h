@@ -31,23 +31,23 @@ extern "C" {
 #define SAMD_E_IO (-4)        /* file could not be read / written / has a bad header */
 #define SAMD_E_NODEVICE (-5)  /* no gfx950 device visible */
 
-/* A draft (sequence or tree) holds at most 64 nodes: one wavefront builds and verifies it, one u64 mask row per node, one 64-row GEMM
- * tile.  The reference takes any max_predicts / n_predicts (samd_sam_only/sam/static_sam.py:183); its shipped configurations use 40-63.
- * The C ABI refuses samd_params_t values above 64 (SAMD_E_INVALID); the Python packages above it cap larger requests at 64 with a
- * RuntimeWarning (samd_sam_only/sam/_common.py): decoding stays lossless, only the accept lengths of very long matches differ.
- * INTEGRATION.md section A. */
-#define SAMD_MAX_DRAFT 64
+/* A draft (sequence or tree) holds at most 128 nodes (round 5; 64 before): one wavefront builds it two nodes per lane, its ancestor mask is
+ * two u64 words per node (mask / mask_hi), the verify forward runs it as two 64-row tiles.  The reference takes any max_predicts /
+ * n_predicts (samd_sam_only/sam/static_sam.py:183, samd/sam/dyn_sam.py:107-113); its shipped configurations use 40-63.  The C ABI refuses
+ * samd_params_t values above 128 (SAMD_E_INVALID); the Python packages above it cap larger requests at 128 with a RuntimeWarning
+ * (samd_sam_only/sam/_common.py): decoding stays lossless, only the accept lengths of very long matches differ.  INTEGRATION.md section A. */
+#define SAMD_MAX_DRAFT 128
 #define SAMD_TOPK 8           /* SO/sam/static_sam.py:137 keeps 8 successors per state */
 
 /* per-step report block (int32 words) copied to the host by samd_session_report_async:
  * what SamdModel.decode/update_state/generate read back per step (SO/samd_model.py:158-174, :216-235) */
 #define SAMD_REP_DMETA 0      /* [16] type, n, n_leaves, max_depth, index_dyn, match_dyn, index_static, match_static, ... */
 #define SAMD_REP_VERDICT 16   /* [8]  best, accept, next_node, next_token, kv_start, is_tree */
-#define SAMD_REP_TOKENS 24    /* [64] candidate_tokens[best][:accept] */
-#define SAMD_REP_KVINDEX 88   /* [64] retrieve[best][:accept] */
-#define SAMD_REP_COUNTERS 152 /* [8]  steps, tokens, sequence steps, tree steps */
-#define SAMD_REP_META 160     /* [16] n_states, n_edges, n_text, last, max_length, cursors, error flag */
-#define SAMD_REPORT_INTS 176
+#define SAMD_REP_TOKENS 24    /* [128] candidate_tokens[best][:accept] */
+#define SAMD_REP_KVINDEX 152  /* [128] retrieve[best][:accept] */
+#define SAMD_REP_COUNTERS 280 /* [8]  steps, tokens, sequence steps, tree steps */
+#define SAMD_REP_META 288     /* [16] n_states, n_edges, n_text, last, max_length, cursors, error flag */
+#define SAMD_REPORT_INTS 304
 
 /* automaton flavours */
 #define SAMD_KIND_COUNT 0     /* samd_sam_only StaticSAM: cnt_endpos + top-k (SO/sam/static_sam.py:24-29) */
@@ -188,7 +188,8 @@ typedef struct samd_draft_host {
     int32_t tokens[SAMD_MAX_DRAFT];
     int32_t parent[SAMD_MAX_DRAFT];         /* anc_tree; sequence: i-1 */
     int32_t position[SAMD_MAX_DRAFT];       /* tree_position_ids / seq_position_ids */
-    uint64_t mask[SAMD_MAX_DRAFT];          /* row i: bit j set iff node i attends node j (tree_attn_mask) */
+    uint64_t mask[SAMD_MAX_DRAFT];          /* row i: bit j set iff node i attends node j < 64 (tree_attn_mask) */
+    uint64_t mask_hi[SAMD_MAX_DRAFT];       /* row i: bit j set iff node i attends node 64 + j */
     int32_t retrieve[SAMD_MAX_DRAFT * SAMD_MAX_DRAFT];  /* [n_leaves][max_depth], -1 padded */
 } samd_draft_host_t;
 

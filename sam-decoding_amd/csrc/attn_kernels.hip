@@ -378,7 +378,7 @@ int samd_attention_block(const void *d_qkv, int32_t n_partials, int64_t partial_
                          const uint64_t *d_mask, const int32_t *d_write_pos, const int32_t *d_visible_len, const int32_t *d_n, float scale,
                          void *stream) {
     if (!d_qkv || !d_cs || !d_k_cache || !d_vt_cache || !d_out || !d_mask || !d_write_pos || !d_n) { samd_set_error("samd_attention_block: null pointer"); return SAMD_E_INVALID; }
-    if (head_dim != AB_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || n_partials < 0 ||
+    if (head_dim != AB_D || n_q_pad < 1 || n_q_pad > 64 || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || n_partials < 0 ||
         max_len < 8 || max_len % 8 != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
         samd_set_error("samd_attention_block: unsupported shape (head_dim must be 128, n_q_pad <= 64, max_len a multiple of 8, f16/bf16)");
         return SAMD_E_INVALID;

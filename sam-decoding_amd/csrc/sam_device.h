@@ -504,11 +504,11 @@ struct StepShared {
     int tokens[SAMD_MAX_DRAFT];
     int parent[SAMD_MAX_DRAFT];
     int position[SAMD_MAX_DRAFT];
-    unsigned long long mask[SAMD_MAX_DRAFT];
+    unsigned long long mask[SAMD_MAX_DRAFT], mask_hi[SAMD_MAX_DRAFT];   // ancestors among nodes 0..63 / 64..127
     unsigned char path[SAMD_MAX_DRAFT][SAMD_MAX_DRAFT];   // retrieve rows, PATH_PAD padded
     int node_argmax[SAMD_MAX_DRAFT];
     int accepted[SAMD_MAX_DRAFT];
-    unsigned long long child_mask;
+    unsigned long long child_mask[2];
     int red[4];
     // best-first search heap (static_sam.py:184-214): <= 1 + 8*(n-1) live items
     double h_prob[8 * SAMD_MAX_DRAFT + 8];
@@ -523,16 +523,14 @@ __device__ __forceinline__ int seq_draft_var(StepShared &sh, const int *text, in
     const int lo = endpos + 1;
     int hi = endpos + n; hi = hi > n_text ? n_text : hi;
     const int m = 1 + (hi > lo ? hi - lo : 0);
-    const int i = lane_id();
-    if (i < m) { sh.tokens[i] = (i == 0) ? start : text[endpos + i]; sh.parent[i] = i - 1; }
+    for (int i = lane_id(); i < m; i += WAVE) { sh.tokens[i] = (i == 0) ? start : text[endpos + i]; sh.parent[i] = i - 1; }   // (two nodes per lane above 64)
     __syncthreads();
     return m;
 }
 
 // fixed-length, zero padded (samd/sam/dyn_sam.py:107-113, samd/sam/static_sam.py:119-125)
 __device__ __forceinline__ int seq_draft_fixed(StepShared &sh, const int *text, int n_text, int endpos, int n_predicts, int start) {
-    const int i = lane_id();
-    if (i < n_predicts) {
+    for (int i = lane_id(); i < n_predicts; i += WAVE) {
         int v = 0;
         if (i == 0) v = start; else if (endpos + i < n_text) v = text[endpos + i];
         sh.tokens[i] = v; sh.parent[i] = i - 1;
@@ -579,8 +577,9 @@ __device__ __forceinline__ void hq_pop(StepShared &sh, int &hn, double &p, int &
 __device__ __forceinline__ int tree_draft(StepShared &sh, const StaticDev &S, int index, int n, int K, int start) {
     const int lane = lane_id();
     int hn = 0, m = 0;
-    if (lane <= SAMD_MAX_DRAFT) sh.dep_cnt[lane] = 0;
-    if (lane == 0) { sh.dep_cnt[SAMD_MAX_DRAFT + 1] = 0; hq_push(sh, hn, -1.0, start, index, -1, 0); }
+    for (int k = lane; k < SAMD_MAX_DRAFT + 2; k += WAVE) sh.dep_cnt[k] = 0;
+    __syncthreads();
+    if (lane == 0) hq_push(sh, hn, -1.0, start, index, -1, 0);
     __syncthreads();
     while (m != n) {
         if (lane == 0) {
@@ -631,34 +630,38 @@ __device__ __forceinline__ int tree_draft(StepShared &sh, const StaticDev &S, in
 // gen_buffers (static_sam.py:148-180): depth, ancestor mask, root->leaf rows.  One lane per node.
 // reverse = Token-Recycle row order (samd/tree_model/token_recycle/utils.py:88).
 __device__ __forceinline__ void build_buffers(StepShared &sh, int n, int reverse, int &n_leaves, int &max_depth) {
-    const int i = lane_id();
-    if (i == 0) sh.child_mask = 0ull;
+    const int lane = lane_id();
+    if (lane == 0) { sh.child_mask[0] = 0ull; sh.child_mask[1] = 0ull; }
     __syncthreads();
     // a well-formed parent array has parent[0] == -1 and 0 <= parent[i] < i; anything else (an externally supplied draft
     // with a missing ancestor) is re-attached to the root so that the ancestor walks below always terminate
-    if (i < n) {
+    for (int i = lane; i < n; i += WAVE) {
         const int p = sh.parent[i];
         if (i == 0) sh.parent[0] = -1;
         else if (p < 0 || p >= i) sh.parent[i] = 0;
     }
     __syncthreads();
-    int depth = 0; unsigned long long m = 0ull;
-    if (i < n) {
-        for (int j = i; j != -1; j = sh.parent[j]) { m |= 1ull << j; depth++; }
+    int md = 0;
+    for (int i = lane; i < n; i += WAVE) {                    // one lane per node, two rounds above 64 nodes
+        int depth = 0; unsigned long long m = 0ull, mh = 0ull;
+        for (int j = i; j != -1; j = sh.parent[j]) { if (j < 64) m |= 1ull << j; else mh |= 1ull << (j - 64); depth++; }
         depth -= 1;
-        sh.position[i] = depth; sh.mask[i] = m;
-        if (i > 0) atomicOr(&sh.child_mask, 1ull << sh.parent[i]);
+        sh.position[i] = depth; sh.mask[i] = m; sh.mask_hi[i] = mh;
+        if (i > 0) { const int p = sh.parent[i]; atomicOr(&sh.child_mask[p >> 6], 1ull << (p & 63)); }
+        md = depth + 1 > md ? depth + 1 : md;
     }
-    int md = depth + 1;
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(md, o); md = v > md ? v : md; }
     __syncthreads();
-    const unsigned long long valid = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    const unsigned long long leaf = valid & ~sh.child_mask;
-    const int nl = __popcll(leaf);
-    for (int k = i; k < SAMD_MAX_DRAFT * SAMD_MAX_DRAFT; k += WAVE) (&sh.path[0][0])[k] = PATH_PAD;
+    const int n0 = n < 64 ? n : 64, n1 = n > 64 ? n - 64 : 0;
+    const unsigned long long valid0 = n0 >= 64 ? ~0ull : ((1ull << n0) - 1ull), valid1 = n1 >= 64 ? ~0ull : ((1ull << n1) - 1ull);
+    const unsigned long long leaf0 = valid0 & ~sh.child_mask[0], leaf1 = valid1 & ~sh.child_mask[1];
+    const int nl0 = __popcll(leaf0), nl = nl0 + __popcll(leaf1);
+    for (int k = lane; k < SAMD_MAX_DRAFT * SAMD_MAX_DRAFT; k += WAVE) (&sh.path[0][0])[k] = PATH_PAD;
     __syncthreads();
-    if (i < n && ((leaf >> i) & 1ull)) {
-        int r = __popcll(leaf & ((1ull << i) - 1ull));
+    for (int i = lane; i < n; i += WAVE) {
+        const bool is_leaf = i < 64 ? ((leaf0 >> i) & 1ull) : ((leaf1 >> (i - 64)) & 1ull);
+        if (!is_leaf) continue;
+        int r = i < 64 ? __popcll(leaf0 & ((1ull << i) - 1ull)) : nl0 + __popcll(leaf1 & ((1ull << (i - 64)) - 1ull));      // leaves in increasing node index
         if (reverse) r = nl - 1 - r;
         for (int j = i; j != -1; j = sh.parent[j]) sh.path[r][sh.position[j]] = (unsigned char)j;
     }
@@ -669,8 +672,10 @@ __device__ __forceinline__ void build_buffers(StepShared &sh, int n, int reverse
 __device__ __forceinline__ void store_draft(const SessionDev &D, StepShared &sh, int type, int n, int n_leaves, int max_depth,
                                             int idx_dyn, int m_dyn, int idx_st, int m_st, int reverse) {
     const int i = lane_id();
-    if (i < n) { D.tokens[i] = sh.tokens[i]; D.parent[i] = sh.parent[i]; D.position[i] = sh.position[i]; D.mask[i] = sh.mask[i]; }
-    else { D.tokens[i] = 0; D.parent[i] = i - 1; D.position[i] = 0; D.mask[i] = 0ull; }   // padded rows attend nothing
+    for (int k = i; k < SAMD_MAX_DRAFT; k += WAVE) {
+        if (k < n) { D.tokens[k] = sh.tokens[k]; D.parent[k] = sh.parent[k]; D.position[k] = sh.position[k]; D.mask[k] = sh.mask[k]; D.mask_hi[k] = sh.mask_hi[k]; }
+        else { D.tokens[k] = 0; D.parent[k] = k - 1; D.position[k] = 0; D.mask[k] = 0ull; D.mask_hi[k] = 0ull; }   // padded rows attend nothing
+    }
     for (int k = i; k < n_leaves * max_depth; k += WAVE) {
         const unsigned char v = sh.path[k / max_depth][k % max_depth];
         D.retrieve[k] = v == PATH_PAD ? -1 : (int)v;
@@ -731,30 +736,31 @@ __device__ __forceinline__ void do_draft(const SessionDev &D, const StaticDev &S
 __device__ __forceinline__ void do_accept(const SessionDev &D, StepShared &sh, const int *node_argmax, int type, int n,
                                           int n_leaves, int max_depth, int &accept_out, int &next_token_out) {
     const int i = lane_id();
-    if (i < n) sh.node_argmax[i] = node_argmax[i];
+    for (int k = i; k < n; k += WAVE) sh.node_argmax[k] = node_argmax[k];
     __syncthreads();
-    int acc = -1;
-    if (i < n_leaves) {
-        acc = 0;
+    // one lane per candidate row (two rounds above 64 leaves); first maximum over rows: key = acc * 128 + (127 - row)
+    int key = -1;
+    for (int row = i; row < n_leaves; row += WAVE) {
+        int acc = 0;
         for (int j = 1; j < max_depth; j++) {
-            const int cj = sh.path[i][j], pj = sh.path[i][j - 1];
+            const int cj = sh.path[row][j], pj = sh.path[row][j - 1];
             const int cand = cj == PATH_PAD ? 0 : sh.tokens[cj];              // pad token 0 (utils.py:95-96)
             const int am = sh.node_argmax[pj == PATH_PAD ? n - 1 : pj];       // logits[-1] = last node (samd_model.py:144)
             if (cand != am) break;
             acc++;
         }
+        const int kk = acc * SAMD_MAX_DRAFT + (SAMD_MAX_DRAFT - 1 - row);
+        key = kk > key ? kk : key;
     }
-    // first maximum over rows: key = acc * 64 + (63 - row)
-    int key = acc < 0 ? -1 : acc * WAVE + (WAVE - 1 - i);
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(key, o); key = v > key ? v : key; }
-    const int best_acc = key / WAVE, best = WAVE - 1 - (key % WAVE);
+    const int best_acc = key / SAMD_MAX_DRAFT, best = SAMD_MAX_DRAFT - 1 - (key % SAMD_MAX_DRAFT);
     const int a = best_acc + 1;
-    if (i < a) {
-        const int node = sh.path[best][i];
+    for (int k = i; k < a; k += WAVE) {
+        const int node = sh.path[best][k];
         const int tk = node == PATH_PAD ? 0 : sh.tokens[node];
-        sh.accepted[i] = tk;
-        D.acc_tokens[i] = tk;
-        D.kv_index[i] = node == PATH_PAD ? -1 : node;
+        sh.accepted[k] = tk;
+        D.acc_tokens[k] = tk;
+        D.kv_index[k] = node == PATH_PAD ? -1 : node;
     }
     const int nn_raw = sh.path[best][best_acc];
     const int nn = nn_raw == PATH_PAD ? n - 1 : nn_raw;
@@ -781,12 +787,12 @@ __device__ __forceinline__ void do_accept_given(const SessionDev &D, StepShared 
     int best = given[0], a = given[1];
     best = best < 0 ? 0 : (best >= n_leaves ? (n_leaves > 0 ? n_leaves - 1 : 0) : best);
     a = a < 1 ? 1 : (a > max_depth ? max_depth : a);
-    if (i < a) {
-        const int node = sh.path[best][i];
+    for (int k = i; k < a; k += WAVE) {
+        const int node = sh.path[best][k];
         const int tk = node == PATH_PAD ? 0 : sh.tokens[node];
-        sh.accepted[i] = tk;
-        D.acc_tokens[i] = tk;
-        D.kv_index[i] = node == PATH_PAD ? -1 : node;
+        sh.accepted[k] = tk;
+        D.acc_tokens[k] = tk;
+        D.kv_index[k] = node == PATH_PAD ? -1 : node;
     }
     const int nn_raw = sh.path[best][a - 1];
     const int nn = nn_raw == PATH_PAD ? n - 1 : nn_raw;

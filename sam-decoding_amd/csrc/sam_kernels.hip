@@ -126,7 +126,7 @@ struct StepArgs {
 __device__ __forceinline__ void load_draft(const SessionDev &D, StepShared &sh, int &type, int &n, int &nl, int &md) {
     const int i = lane_id();
     type = D.dmeta[D_TYPE]; n = D.dmeta[D_N]; nl = D.dmeta[D_NLEAVES]; md = D.dmeta[D_MAXDEPTH];
-    if (i < n) { sh.tokens[i] = D.tokens[i]; sh.parent[i] = D.parent[i]; }
+    for (int k = i; k < n; k += WAVE) { sh.tokens[k] = D.tokens[k]; sh.parent[k] = D.parent[k]; }
     for (int k = i; k < SAMD_MAX_DRAFT * SAMD_MAX_DRAFT; k += WAVE) (&sh.path[0][0])[k] = PATH_PAD;
     __syncthreads();
     for (int k = i; k < nl * md; k += WAVE) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
     if (A.ops & OP_COMMIT) {
         // DraftModel.update(accepted tokens) (draft.py:62-67)
         const int a = D.verdict[V_ACCEPT];
-        if (lane < a) sh.accepted[lane] = D.acc_tokens[lane];
+        for (int k = lane; k < a; k += WAVE) sh.accepted[k] = D.acc_tokens[k];
         __syncthreads();
         dyn_add_tokens(D, sh.accepted, a);
         wave_mem_sync();
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void k_session(SessionDev D, StaticDev S, samd_
         store_draft(D, sh, 0, n, nl, mxd, A.index, 0, A.index, 0, 0);
     }
     if ((A.ops & OP_SET_DRAFT) && !(A.only_if_deferred && D.dmeta[D_TYPE] != 2)) {
-        if (lane < A.n) { sh.tokens[lane] = A.tokens[lane]; sh.parent[lane] = A.parents[lane]; }
+        for (int k = lane; k < A.n; k += WAVE) { sh.tokens[k] = A.tokens[k]; sh.parent[k] = A.parents[k]; }
         __syncthreads();
         int nl, mxd; build_buffers(sh, A.n, A.reverse, nl, mxd);
         store_draft(D, sh, A.type, A.n, nl, mxd, 0, 0, 0, 0, A.reverse);
@@ -273,13 +273,13 @@ __global__ __launch_bounds__(64) void k_tree_buffers(const int32_t *parent, int 
                                                      uint8_t *mask_bool, int32_t *retrieve, int32_t *shape) {
     __shared__ StepShared sh;
     const int i = lane_id();
-    if (i < n) sh.parent[i] = parent[i];
+    for (int k = i; k < n; k += WAVE) sh.parent[k] = parent[k];
     __syncthreads();
     int nl, md; build_buffers(sh, n, reverse, nl, md);
-    if (i < n) {
-        if (position) position[i] = sh.position[i];
-        if (mask) mask[i] = sh.mask[i];
-        if (mask_bool) for (int j = 0; j < n; j++) mask_bool[(size_t)i * n + j] = (uint8_t)((sh.mask[i] >> j) & 1ull);
+    for (int k = i; k < n; k += WAVE) {
+        if (position) position[k] = sh.position[k];
+        if (mask) { mask[k] = sh.mask[k]; if (n > 64) mask[n + k] = sh.mask_hi[k]; }      // n > 64: the n high words follow the n low words
+        if (mask_bool) for (int j = 0; j < n; j++) mask_bool[(size_t)k * n + j] = (uint8_t)(((j < 64 ? sh.mask[k] >> j : sh.mask_hi[k] >> (j - 64))) & 1ull);
     }
     if (retrieve) for (int k = i; k < nl * md; k += WAVE) { const unsigned char v = sh.path[k / md][k % md]; retrieve[k] = v == PATH_PAD ? -1 : (int)v; }
     if (shape && i == 0) { shape[0] = nl; shape[1] = md; }
@@ -295,30 +295,32 @@ __global__ __launch_bounds__(64) void k_scripted_argmax(SessionDev D, const int3
     const int n = D.dmeta[D_N];
     const int nc = D.meta[M_NTEXT] - 1;                       // committed tokens (text[0] is the sentinel)
     const int32_t *hist = D.text + 1;
-    if (i < n) { tok[i] = D.tokens[i]; par[i] = D.parent[i]; }
+    for (int k = i; k < n; k += WAVE) { tok[k] = D.tokens[k]; par[k] = D.parent[k]; }
     __syncthreads();
     // is the committed history a prefix of target?
     int bad = 0;
     for (int k = i; k < nc; k += WAVE) bad |= (k >= n_target || hist[k] != target[k]);
     const bool hist_ok = __ballot(bad != 0) == 0ull;
-    int res = 0;
-    if (i < n) {
-        int path[SAMD_MAX_DRAFT]; int d = 0;
-        for (int j = i; j != -1; j = par[j]) path[d++] = tok[j];   // leaf -> root
-        bool ok = hist_ok;
-        for (int k = 0; k < d && ok; k++) { const int pos = nc + k; ok = pos < n_target && path[d - 1 - k] == target[pos]; }
-        const int len = nc + d;
-        if (ok && len < n_target) res = target[len];
-        else {
-            long long h = 1469598103ll;
-            for (int k = (len >= 3 ? len - 3 : 0); k < len; k++) {
-                const int t = k < nc ? hist[k] : path[d - 1 - (k - nc)];
-                h = (h * 1000003ll + t + 7) % 2147483647ll;
+    for (int node = i; node < SAMD_MAX_DRAFT; node += WAVE) {         // one lane per node, two rounds above 64 nodes
+        int res = 0;
+        if (node < n) {
+            int path[SAMD_MAX_DRAFT]; int d = 0;
+            for (int j = node; j != -1; j = par[j]) path[d++] = tok[j];   // leaf -> root
+            bool ok = hist_ok;
+            for (int k = 0; k < d && ok; k++) { const int pos = nc + k; ok = pos < n_target && path[d - 1 - k] == target[pos]; }
+            const int len = nc + d;
+            if (ok && len < n_target) res = target[len];
+            else {
+                long long h = 1469598103ll;
+                for (int k = (len >= 3 ? len - 3 : 0); k < len; k++) {
+                    const int t = k < nc ? hist[k] : path[d - 1 - (k - nc)];
+                    h = (h * 1000003ll + t + 7) % 2147483647ll;
+                }
+                res = 3 + (int)(h % (vocab - 3));
             }
-            res = 3 + (int)(h % (vocab - 3));
         }
+        out[node] = res;
     }
-    out[i] = res;
 }
 
 // stream-major entry points: d_tokens int32 [B][T] (what a caller that holds B token sequences has), d_trace int32 [B][T][2].  The walk
@@ -761,7 +763,8 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
     const size_t o_link = carve(4ull * D.cap_states), o_len = carve(4ull * D.cap_states), o_me = carve(4ull * D.cap_states),
                  o_head = carve(4ull * D.cap_states), o_tail = carve(4ull * D.cap_states), o_hk = carve(8ull * H),
                  o_hd = carve(4ull * H), o_hn = carve(4ull * H), o_text = carve(4ull * D.cap_text),
-                 o_tok = carve(4 * 64), o_par = carve(4 * 64), o_pos = carve(4 * 64), o_mask = carve(8 * 64), o_ret = carve(4 * 64 * 64),
+                 o_tok = carve(4 * SAMD_MAX_DRAFT), o_par = carve(4 * SAMD_MAX_DRAFT), o_pos = carve(4 * SAMD_MAX_DRAFT), o_mask = carve(8 * 2 * SAMD_MAX_DRAFT),
+                 o_ret = carve(4 * SAMD_MAX_DRAFT * SAMD_MAX_DRAFT),
                  o_rep = carve(4 * SAMD_REPORT_INTS), o_st = carve(4), o_cl = carve(4), o_seq = carve(4);
     s->arena_bytes = off;
     if (hipMalloc(&s->arena, off) != hipSuccess) { free(s); samd_set_error("hipMalloc(session arena) failed"); return SAMD_E_HIP; }
@@ -770,7 +773,7 @@ int samd_session_create(int32_t max_tokens, samd_session_t **out) {
     D.head = (int32_t *)(base + o_head); D.tail = (int32_t *)(base + o_tail); D.hkey = (uint64_t *)(base + o_hk);
     D.hdst = (int32_t *)(base + o_hd); D.hnext = (int32_t *)(base + o_hn); D.text = (int32_t *)(base + o_text);
     D.tokens = (int32_t *)(base + o_tok); D.parent = (int32_t *)(base + o_par);
-    D.position = (int32_t *)(base + o_pos); D.mask = (uint64_t *)(base + o_mask); D.retrieve = (int32_t *)(base + o_ret);
+    D.position = (int32_t *)(base + o_pos); D.mask = (uint64_t *)(base + o_mask); D.mask_hi = D.mask + SAMD_MAX_DRAFT; D.retrieve = (int32_t *)(base + o_ret);
     int32_t *rep = (int32_t *)(base + o_rep);
     D.dmeta = rep + SAMD_REP_DMETA; D.verdict = rep + SAMD_REP_VERDICT; D.acc_tokens = rep + SAMD_REP_TOKENS;
     D.kv_index = rep + SAMD_REP_KVINDEX; D.counters = rep + SAMD_REP_COUNTERS; D.meta = rep + SAMD_REP_META;
@@ -970,8 +973,8 @@ int samd_session_read_draft(samd_session_t *s, samd_draft_host_t *out, void *str
     const SessionDev &D = s->dev;
     int32_t dm[D_COUNT];
     D2H(dm, D.dmeta, sizeof(dm));
-    D2H(out->tokens, D.tokens, 4 * 64); D2H(out->parent, D.parent, 4 * 64); D2H(out->position, D.position, 4 * 64);
-    D2H(out->mask, D.mask, 8 * 64); D2H(out->retrieve, D.retrieve, 4 * 64 * 64);
+    D2H(out->tokens, D.tokens, 4 * SAMD_MAX_DRAFT); D2H(out->parent, D.parent, 4 * SAMD_MAX_DRAFT); D2H(out->position, D.position, 4 * SAMD_MAX_DRAFT);
+    D2H(out->mask, D.mask, 8 * SAMD_MAX_DRAFT); D2H(out->mask_hi, D.mask_hi, 8 * SAMD_MAX_DRAFT); D2H(out->retrieve, D.retrieve, 4 * SAMD_MAX_DRAFT * SAMD_MAX_DRAFT);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     out->type = dm[D_TYPE]; out->n = dm[D_N]; out->n_leaves = dm[D_NLEAVES]; out->max_depth = dm[D_MAXDEPTH];
     out->index_dyn = dm[D_IDX_DYN]; out->match_dyn = dm[D_MATCH_DYN]; out->index_static = dm[D_IDX_ST]; out->match_static = dm[D_MATCH_ST];
@@ -982,7 +985,7 @@ int samd_session_read_verdict(samd_session_t *s, samd_verdict_host_t *out, void 
     if (!s || !out) return SAMD_E_INVALID;
     const SessionDev &D = s->dev;
     int32_t v[V_COUNT];
-    D2H(v, D.verdict, sizeof(v)); D2H(out->tokens, D.acc_tokens, 4 * 64); D2H(out->kv_index, D.kv_index, 4 * 64);
+    D2H(v, D.verdict, sizeof(v)); D2H(out->tokens, D.acc_tokens, 4 * SAMD_MAX_DRAFT); D2H(out->kv_index, D.kv_index, 4 * SAMD_MAX_DRAFT);
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     out->best = v[V_BEST]; out->accept = v[V_ACCEPT]; out->next_node = v[V_NEXT_NODE]; out->next_token = v[V_NEXT_TOKEN];
     return SAMD_OK;
@@ -1067,7 +1070,7 @@ int samd_scripted_logits_order1(samd_session_t *s, const int32_t *d_argmax, void
 
 int samd_tree_buffers(const int32_t *d_parent, int32_t n, int32_t reverse_leaves, int32_t *d_position, uint64_t *d_mask,
                       uint8_t *d_mask_bool, int32_t *d_retrieve, int32_t *d_shape, void *stream) {
-    if (!d_parent || n < 1 || n > SAMD_MAX_DRAFT) { samd_set_error("samd_tree_buffers: n must be in [1,64]"); return SAMD_E_INVALID; }
+    if (!d_parent || n < 1 || n > SAMD_MAX_DRAFT) { samd_set_error("samd_tree_buffers: n must be in [1,128]"); return SAMD_E_INVALID; }
     hipLaunchKernelGGL(k_tree_buffers, dim3(1), dim3(WAVE), 0, (hipStream_t)stream, d_parent, n, reverse_leaves, d_position, d_mask,
                        d_mask_bool, d_retrieve, d_shape);
     LAUNCHCHK();

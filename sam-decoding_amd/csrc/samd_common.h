@@ -144,8 +144,9 @@ struct SessionDev {
     int32_t *meta;              // M_*
     // draft + verdict block
     int32_t *tokens, *parent, *position;
-    uint64_t *mask;
-    int32_t *retrieve;          // [64][64]
+    uint64_t *mask;             // [2][SAMD_MAX_DRAFT]: row i's ancestors among nodes 0..63, then (mask_hi = mask + SAMD_MAX_DRAFT) among 64..127
+    uint64_t *mask_hi;
+    int32_t *retrieve;          // [SAMD_MAX_DRAFT][SAMD_MAX_DRAFT]
     int32_t *dmeta;             // D_*
     int32_t *verdict;           // V_*
     int32_t *acc_tokens, *kv_index;

@@ -154,12 +154,15 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 
     const int h = att_head_of_block(blockIdx.x, n_heads), split = blockIdx.y;
     if (split >= ATT_SPLITS) {               // warm workgroups: the head of the output projection's weight stream -> this XCD's L2 (warm_device.h)
+        if (blockIdx.z != 0) return;
         const unsigned a = warm_next_projection(warm, (split - ATT_SPLITS) * n_heads + h);
         if (a == 0x9E3779B9u && n_q_pad < 0) ws[0] = 0.f;         // never true: keeps the loads alive
         return;
     }
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lg = l >> 4;
-    const int row_base = 16 * w;
+    // blockIdx.z = the 64-row tile of the draft (round 5: drafts of up to 128 nodes are two tiles; row i's ancestor mask is two u64 words,
+    // the high words -- nodes 64..127 -- stored SAMD_MAX_DRAFT entries behind the low ones; a draft of <= 64 nodes has one tile, low words only)
+    const int row_base = 64 * (int)blockIdx.z + 16 * w;
     // loads that do not depend on L / n go out first (Q fragments, mask rows), together with the two scalars
     V8 qa[4];
     {
@@ -172,9 +175,12 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
             qa[kk] = __builtin_bit_cast(V8, raw);
         }
     }
-    unsigned long long mrow[4];
+    unsigned long long mrow[4], mrow_hi[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) mrow[r] = mask[row_base + 4 * lg + r];       // mask holds 64 rows; rows >= n are zeroed below
+    for (int r = 0; r < 4; r++) {                                             // the mask holds n_q_pad rows (<= 64: low words only); rows >= n are zeroed below
+        mrow[r] = mask[row_base + 4 * lg + r];
+        mrow_hi[r] = n_q_pad > 64 ? mask[SAMD_MAX_DRAFT + row_base + 4 * lg + r] : 0ull;
+    }
     // Split s owns the key tiles s, s + ATT_SPLITS, s + 2 ATT_SPLITS, ...: the FIRST tile of a workgroup is known from its
     // block index alone, so its K fragments and V rows are requested here, in the same memory round trip as the two scalars
     // (L, n) instead of after them.  Keys are clamped to the cache; what lies beyond L + n is masked (K) / zeroed (V) below.
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     if (split >= ntiles) return;                       // no keys for this split: k_attn_combine only reads the splits in use
     const bool active = row_base < n;
 #pragma unroll
-    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) mrow[r] = 0ull;
+    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) { mrow[r] = 0ull; mrow_hi[r] = 0ull; }
 
     float m_run[4], l_run[4];
     floatx4 o[8];
@@ -263,7 +269,8 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
                 const int key = key0 + 16 * st + lr;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const bool ok = key < L || (key < total && ((mrow[r] >> (key - L)) & 1ull));
+                    const int rel = key - L;                                   // index of a NEW key among the draft's nodes
+                    const bool ok = key < L || (key < total && (((rel < 64 ? mrow[r] >> rel : mrow_hi[r] >> (rel - 64))) & 1ull));
                     const float v = ok ? s[st][r] * scale_log2 : -INFINITY;
                     s[st][r] = v;
                     tmax[r] = fmaxf(tmax[r], v);
@@ -829,18 +836,17 @@ __global__ __launch_bounds__(64) void k_recycle_draft(const int *__restrict__ ta
                                                       int n_nodes, int n_levels, const int *__restrict__ start, int *__restrict__ out) {
     __shared__ int tok[SAMD_MAX_DRAFT];
     const int lane = threadIdx.x;
-    if (lane < n_nodes) tok[lane] = lane == 0 ? start[0] : 0;
+    for (int k = lane; k < n_nodes; k += 64) tok[k] = k == 0 ? start[0] : 0;
     __syncthreads();
     for (int lv = 0; lv < n_levels; lv++) {
-        const int k = level_off[lv] + lane;
-        if (k < level_off[lv + 1]) {
+        for (int k = level_off[lv] + lane; k < level_off[lv + 1]; k += 64) {
             const int node = level_nodes[k], t = tok[node];
             if (t >= 0 && t < vocab && present[t])
                 for (int c = child_off[node]; c < child_off[node + 1]; c++) tok[children[c]] = table[(size_t)t * 8 + (c - child_off[node])];
         }
         __syncthreads();
     }
-    if (lane < n_nodes) out[lane] = tok[lane];
+    for (int k = lane; k < n_nodes; k += 64) out[k] = tok[k];
 }
 
 // ================================================================================================
@@ -861,7 +867,7 @@ template <typename T>
 __global__ __launch_bounds__(1024) void k_posterior_sampled(const T *__restrict__ probs, const long long *__restrict__ cand, int C, int D, long long V,
                                                             const double *__restrict__ uniforms, int n_uniforms, T *__restrict__ work, int *__restrict__ out,
                                                             const int *__restrict__ rowmap, int n_rows) {
-    __shared__ long long prefix[64];
+    __shared__ long long prefix[SAMD_MAX_DRAFT];
     __shared__ int seen[1024];
     __shared__ int s_action, s_tok, s_row, s_anchor;
     __shared__ float red[16];
@@ -988,9 +994,9 @@ int samd_posterior_sampled(const void *d_probs, int32_t dtype, const int64_t *d_
 
 int samd_posterior_sampled_nodes(const void *d_probs, int32_t dtype, const int32_t *d_rowmap, int32_t n_rows, const int64_t *d_candidates, int32_t n_candidates,
                                  int32_t depth, int64_t vocab, const double *d_uniforms, int32_t n_uniforms, void *d_work, int32_t *d_out, void *stream) {
-    if (!d_probs || !d_candidates || n_candidates < 1 || depth < 1 || depth > 64 || vocab < 1 || !d_uniforms || n_uniforms < 0 || !d_work || !d_out ||
+    if (!d_probs || !d_candidates || n_candidates < 1 || depth < 1 || depth > SAMD_MAX_DRAFT || vocab < 1 || !d_uniforms || n_uniforms < 0 || !d_work || !d_out ||
         (d_rowmap && n_rows < 1)) {
-        samd_set_error("samd_posterior_sampled: invalid argument (depth <= 64)"); return SAMD_E_INVALID;
+        samd_set_error("samd_posterior_sampled: invalid argument (depth <= 128)"); return SAMD_E_INVALID;
     }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SAMD_F32) hipLaunchKernelGGL(k_posterior_sampled<float>, dim3(1), dim3(1024), 0, st, (const float *)d_probs, (const long long *)d_candidates, n_candidates, depth,
@@ -1056,19 +1062,20 @@ static int tree_attention_impl(const void *d_q, const void *d_k_cache, const voi
     if (!d_q || !d_k_cache || !d_v_cache || !d_out || !d_mask || !d_cache_length || !d_n || !d_workspace) { samd_set_error("samd_tree_attention: null pointer"); return SAMD_E_INVALID; }
     if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 ||
         (dtype != SAMD_F16 && dtype != SAMD_BF16) || workspace_bytes < samd_tree_attention_workspace(n_q_pad, n_heads, head_dim)) {
-        samd_set_error("samd_tree_attention: unsupported shape (head_dim must be 128, n_q_pad <= 64, f16/bf16) or workspace too small");
+        samd_set_error("samd_tree_attention: unsupported shape (head_dim must be 128, n_q_pad <= 128, f16/bf16) or workspace too small");
         return SAMD_E_INVALID;
     }
+    const int row_tiles = (n_q_pad + 63) / 64;                 // > 64 rows: d_mask holds [2][SAMD_MAX_DRAFT] words (low, high)
     hipStream_t st = (hipStream_t)stream;
     const float scale_log2 = scale * 1.4426950408889634f;
     float *ws = (float *)d_workspace;
     if (dtype == SAMD_F16) {
-        hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
+        hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
                            (const _Float16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
         hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     } else {
-        hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS + warm_splits), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
+        hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
                            (const __bf16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
         hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
@@ -1106,7 +1113,7 @@ int samd_tree_attention_rope(const void *d_qkv, int32_t n_partials, int64_t part
                              const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace,
                              int64_t workspace_bytes, void *stream) {
     if (!d_qkv || !d_cs || !d_k_cache || !d_v_cache || !d_out || !d_mask || !d_cache_length || !d_n || !d_workspace) { samd_set_error("samd_tree_attention_rope: null pointer"); return SAMD_E_INVALID; }
-    if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > SAMD_MAX_DRAFT || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || n_partials < 0 ||
+    if (head_dim != ATT_D || n_q_pad < 1 || n_q_pad > 64 || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 || n_partials < 0 ||
         (dtype != SAMD_F16 && dtype != SAMD_BF16) || workspace_bytes < samd_tree_attention_rope_workspace(n_q_pad, n_heads, head_dim)) {
         samd_set_error("samd_tree_attention_rope: unsupported shape (head_dim must be 128, n_q_pad <= 64, f16/bf16) or workspace too small");
         return SAMD_E_INVALID;

@@ -12,10 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SAMD_HIP_LIB: another build of the SAME library (scripts/asan_cpu.sh points the CPU tests at a host-sanitizer build); it must
 # export every entry point like the default one, and a missing file fails just as loudly
 LIB_PATH = os.environ.get("SAMD_HIP_LIB") or os.path.join(_HERE, "libsamd_hip.so")
-MAX_DRAFT = 64
+MAX_DRAFT = 128             # nodes of a draft (include/samd_hip.h SAMD_MAX_DRAFT; 64 until round 5)
+TILE_ROWS = 64              # rows of one verify tile: the streaming GEMM's largest row tile, one u64 mask word, a prefill chunk
 TOPK = 8
 # report block layout (include/samd_hip.h SAMD_REP_*)
-REP_DMETA, REP_VERDICT, REP_TOKENS, REP_KVINDEX, REP_COUNTERS, REP_META, REPORT_INTS = 0, 16, 24, 88, 152, 160, 176
+REP_DMETA, REP_VERDICT, REP_TOKENS, REP_KVINDEX, REP_COUNTERS, REP_META, REPORT_INTS = 0, 16, 24, 152, 280, 288, 304
 KIND_COUNT, KIND_ENDPOS = 0, 1
 F16, BF16, F32 = 0, 1, 2
 
@@ -38,7 +39,7 @@ class DraftHost(C.Structure):
     _fields_ = [("type", C.c_int32), ("n", C.c_int32), ("n_leaves", C.c_int32), ("max_depth", C.c_int32),
                 ("index_dyn", C.c_int32), ("match_dyn", C.c_int32), ("index_static", C.c_int32),
                 ("match_static", C.c_int32), ("tokens", C.c_int32 * MAX_DRAFT), ("parent", C.c_int32 * MAX_DRAFT),
-                ("position", C.c_int32 * MAX_DRAFT), ("mask", C.c_uint64 * MAX_DRAFT),
+                ("position", C.c_int32 * MAX_DRAFT), ("mask", C.c_uint64 * MAX_DRAFT), ("mask_hi", C.c_uint64 * MAX_DRAFT),
                 ("retrieve", C.c_int32 * (MAX_DRAFT * MAX_DRAFT))]
 
 

@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import (F16, BF16, MAX_DRAFT, SamdError, Session, Warm, _ptr, check, current_stream, lib, require_gpu,
+from . import (F16, BF16, MAX_DRAFT, TILE_ROWS, SamdError, Session, Warm, _ptr, check, current_stream, lib, require_gpu,
                torch_dtype_code)
 
 
@@ -76,7 +76,10 @@ class LlamaRunner:
 
     # row buckets of a decode step (one hipGraph each).  The streaming GEMM's cost goes by 16-row tiles (1 / 8 / 16 rows share the
     # 16-row tile), so the buckets above 16 follow its tiles: a 33..48-node draft (match length 8..11 at alpha 4) does not pay for 64 rows
-    BUCKETS = (1, 8, 16, 32, 48, 64)
+    # 128 (round 5): drafts of 65..128 nodes (max_predicts / n_predicts above 64, which the reference accepts: SO/sam/static_sam.py:183) run as
+    # two 64-row tiles of the attention kernel; their projections go to the library GEMM (the streaming kernels' largest row tile is 64, and a
+    # 128-row product is no longer a weight stream with a little MFMA attached), so this bucket needs the row-major matrices
+    BUCKETS = (1, 8, 16, 32, 48, 64, 128)
 
     def __init__(self, shape, weights, max_cache_len, dtype=torch.float16, device="cuda", kv=None, native_gemm=True, packed_lm_head=None,
                  attention=None):
@@ -200,8 +203,9 @@ class LlamaRunner:
         (meta tensors).  SAMD_RELEASE_ROW_MAJOR=1 does this at construction."""
         if self.row_major_released or not self.wp:
             return self.row_major_released
-        if self.native_gemm_max_rows < self.BUCKETS[-1]:
-            return False                                   # (a row bucket would fall back to the library GEMM, which reads the row-major matrices)
+        if self.native_gemm_max_rows < TILE_ROWS:
+            return False                                   # (a row bucket would fall back to the library GEMM, which reads the row-major matrices;
+                                                           #  the 128-row bucket always does: drafts above 64 nodes then raise, see forward_rows)
         need = ("wo", "wdown", "wgu")
         if self.wp["lm_head"] is None or any(l.get(k) is None for l in self.wp["layers"] for k in need) or \
                 any(l.get("wqkv") is None and l.get("wqkv64") is None for l in self.wp["layers"]):
@@ -234,11 +238,13 @@ class LlamaRunner:
         if hasattr(self, "_buf"):
             return                                            # row buffers and prefill staging do not depend on the length
         self._buf = {}
-        # prefill staging (chunks of MAX_DRAFT rows with a causal chain mask)
+        # prefill staging (chunks of TILE_ROWS rows with a causal chain mask); the mask doubles as the SEQUENCE-draft mask of the granular
+        # decode(): row i attends rows 0..i -- low words (nodes 0..63) of all MAX_DRAFT rows, then the high words (nodes 64..127)
         self.pf_tokens = torch.zeros(MAX_DRAFT, dtype=torch.int32, device=self.device)
         self.pf_relpos = torch.arange(MAX_DRAFT, dtype=torch.int32, device=self.device)
-        rows = [(1 << (i + 1)) - 1 for i in range(MAX_DRAFT)]
-        self.pf_mask = torch.tensor([r - (1 << 64) if r >= (1 << 63) else r for r in rows], dtype=torch.int64, device=self.device)
+        lo = [(1 << (min(i, 63) + 1)) - 1 for i in range(MAX_DRAFT)]
+        hi = [0 if i < 64 else (1 << (i - 63)) - 1 for i in range(MAX_DRAFT)]
+        self.pf_mask = torch.tensor([r - (1 << 64) if r >= (1 << 63) else r for r in lo + hi], dtype=torch.int64, device=self.device)
         self.pf_n = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def resize_cache(self, max_cache_len, storage=None):
@@ -354,7 +360,8 @@ class LlamaRunner:
             if self.native_gemm:
                 qkv_out = (s.heads + 2 * s.kv_heads) * s.head_dim
                 for n, k in ((qkv_out, s.hidden), (s.hidden, s.heads * s.head_dim), (2 * s.inter, s.hidden), (s.hidden, s.inter)):
-                    part_elems = max(part_elems, lib().samd_gemm_splits(n, k, RP) * RP * n)
+                    if RP <= self.native_gemm_max_rows:          # (above it every projection is a library GEMM: no split-K partials)
+                        part_elems = max(part_elems, lib().samd_gemm_splits(n, k, RP) * RP * n)
             self._buf[R] = dict(x=z(R, s.hidden), h=z(R, s.hidden), qkv=z(R, (s.heads + 2 * s.kv_heads) * s.head_dim),
                                 q=z(R, s.heads, s.head_dim), attn=z(R, s.heads, s.head_dim), o=z(R, s.hidden),
                                 gu=z(R, 2 * s.inter), act=z(R, s.inter), d=z(R, s.hidden), logits=z(R, s.vocab),
@@ -378,6 +385,9 @@ class LlamaRunner:
         layer 0 has no input norm and lm_head reads the residual stream itself (b["x"] = the head's output states)."""
         L, s, b, dt, st = lib(), self.shape, self._buffers(R), self.dt, current_stream()
         RP, part = b["rows_pad"], b["part"]
+        if RP > self.native_gemm_max_rows and self.row_major_released:
+            raise SamdError(f"a {R}-row forward needs the row-major projection matrices (released: SAMD_RELEASE_ROW_MAJOR / release_row_major()); "
+                            f"drafts above {self.native_gemm_max_rows} nodes and the library-GEMM path are unavailable on this runner")
         if (self.norm_fold and RP == 16 and x_in is None and d_vis is None and not getattr(self, "draft_head", False)
                 and RP <= self.native_gemm_max_rows):
             return self._forward_rows_fold(R, b, d_tokens, d_relpos, d_mask, d_L, d_n)
@@ -519,22 +529,22 @@ class LlamaRunner:
         N = ids.numel()
         if N < 1 or N > self.max_len:
             raise SamdError(f"prompt of {N} tokens does not fit max_cache_len {self.max_len}")
-        if N >= 2 * MAX_DRAFT and os.environ.get("SAMD_PREFILL", "wide") != "chunked" and not self.row_major_released:
+        if N >= 2 * TILE_ROWS and os.environ.get("SAMD_PREFILL", "wide") != "chunked" and not self.row_major_released:
             return self._prefill_wide(session, ids, on_chunk)
         v = session.device_views()
         b = None
-        for c0 in range(0, N, MAX_DRAFT):
-            n = min(MAX_DRAFT, N - c0)
+        for c0 in range(0, N, TILE_ROWS):
+            n = min(TILE_ROWS, N - c0)
             self.pf_tokens.zero_()
             self.pf_tokens[:n] = ids[c0:c0 + n]
             self.pf_n.fill_(n)
             session.set_cache_length(c0)
-            b = self.forward_rows(MAX_DRAFT, self.pf_tokens, self.pf_relpos, self.pf_mask, v["cache_length"], self.pf_n)
+            b = self.forward_rows(TILE_ROWS, self.pf_tokens, self.pf_relpos, self.pf_mask, v["cache_length"], self.pf_n)
             if on_chunk is not None:
                 on_chunk(self.pf_tokens, b["logits"], n, b["h"])
         session.set_cache_length(N)
-        session.set_start_token(b["argmax"][(N - 1) % MAX_DRAFT:])
-        return b["logits"][(N - 1) % MAX_DRAFT]
+        session.set_start_token(b["argmax"][(N - 1) % TILE_ROWS:])
+        return b["logits"][(N - 1) % TILE_ROWS]
 
     def _prefill_wide(self, session: Session, ids, on_chunk=None):
         """the whole prompt in one pass: compute-bound, so the GEMMs go to the library (N x K x N_out at full MFMA rate) and
@@ -581,8 +591,8 @@ class LlamaRunner:
             torch.mm(h[N - 1:N], self.w["lm_head"].t(), out=b["logits"][:1])
         else:
             logits = torch.mm(h, self.w["lm_head"].t())
-            for c0 in range(0, N, MAX_DRAFT):
-                n = min(MAX_DRAFT, N - c0)
+            for c0 in range(0, N, TILE_ROWS):
+                n = min(TILE_ROWS, N - c0)
                 on_chunk(ids[c0:c0 + n], logits[c0:c0 + n], n, h[c0:c0 + n])
             b["logits"][:1].copy_(logits[N - 1:N])
         check(L.samd_argmax_rows(_ptr(b["logits"]), dt, 1, s.vocab, s.vocab, None, _ptr(b["argmax"]), st))

@@ -21,11 +21,14 @@ def tree_decode_mask(tree_attn_mask: torch.Tensor, cache_length: int, dtype=torc
 
 
 def mask_rows_u64(tree_attn_mask: torch.Tensor) -> torch.Tensor:
-    """bool/float [.., n, n] mask -> int64[64] whose bit pattern is the u64 row mask the kernel reads."""
+    """bool/float [.., n, n] mask -> int64[2 * MAX_DRAFT] whose bit patterns are the u64 row masks the kernel reads: the low words (nodes
+    0..63) of all rows, then -- MAX_DRAFT entries further -- the high words (nodes 64..127; read only when more than 64 rows are verified)."""
     n = tree_attn_mask.shape[-1]
     bits = (tree_attn_mask.reshape(n, n) != 0).to(torch.int64).cpu()
-    rows = [sum(int(bits[i, j]) << j for j in range(n)) for i in range(n)] + [0] * (samd_hip.MAX_DRAFT - n)
-    rows = [r - (1 << 64) if r >= (1 << 63) else r for r in rows]
+    M = samd_hip.MAX_DRAFT
+    lo = [sum(int(bits[i, j]) << j for j in range(min(n, 64))) for i in range(n)] + [0] * (M - n)
+    hi = [sum(int(bits[i, j]) << (j - 64) for j in range(64, n)) for i in range(n)] + [0] * (M - n)
+    rows = [r - (1 << 64) if r >= (1 << 63) else r for r in lo + hi]
     return torch.tensor(rows, dtype=torch.int64, device="cuda")
 
 
@@ -68,7 +71,7 @@ def hf_attention_forward(self, hidden_states, position_embeddings=None, attentio
         k, v = past_key_values.update(k, v, self.layer_idx)
     n, total = q.shape[2], k.shape[2]
     D = self.head_dim
-    usable = (q.shape[0] == 1 and n <= samd_hip.MAX_DRAFT and D == 128 and q.dtype in (torch.float16, torch.bfloat16) and q.is_cuda
+    usable = (q.shape[0] == 1 and n <= samd_hip.TILE_ROWS and D == 128 and q.dtype in (torch.float16, torch.bfloat16) and q.is_cuda
               and attention_mask is not None and attention_mask.dim() == 4 and attention_mask.shape[-1] >= total
               and (attention_mask.dtype.is_floating_point or attention_mask.dtype == torch.bool)
               and k.stride(3) == 1 and k.stride(2) == D and v.stride(3) == 1 and v.stride(2) == D and k.stride(1) == v.stride(1)

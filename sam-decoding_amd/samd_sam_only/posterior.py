@@ -132,7 +132,7 @@ def _sampled_nodes(node_logits, retrieve, candidates, config):
 def eval_posterior_nodes(node_logits, retrieve, candidates, config):
     """eval_posterior for callers that still hold the verify forward's per-node rows and the retrieve table (SamdModel.decode): the
     gather logits[retrieve] of samd_model.py:144 is not materialised.  Same results as eval_posterior(node_logits[retrieve], ...)."""
-    usable = (not config.greedy and node_logits.is_cuda and candidates.shape[1] <= 64
+    usable = (not config.greedy and node_logits.is_cuda and candidates.shape[1] <= samd_hip.MAX_DRAFT
               and node_logits.dtype in (torch.float16, torch.bfloat16, torch.float32))
     if usable:
         return _sampled_nodes(node_logits, retrieve, candidates, config)
@@ -175,6 +175,6 @@ def eval_posterior(logits: torch.Tensor, candidates: torch.Tensor, config):
     tensors runs in the library's kernel; on host tensors (tools, fixtures) in the plain restatement above."""
     if config.greedy:
         return _greedy(logits, candidates)
-    if logits.is_cuda and candidates.shape[1] <= 64 and logits.dtype in (torch.float16, torch.bfloat16, torch.float32):
+    if logits.is_cuda and candidates.shape[1] <= samd_hip.MAX_DRAFT and logits.dtype in (torch.float16, torch.bfloat16, torch.float32):
         return _sampled_device(logits, candidates, config)
     return _sampled(logits, candidates, config)

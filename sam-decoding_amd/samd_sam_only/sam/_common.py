@@ -11,9 +11,9 @@ def dev_i32(values, device="cuda"):
 
 
 def so_params(max_predicts=60, alpha=4.0, K=8, len_bias=0):
-    """device parameters of the SAM-only variant.  A draft holds at most samd_hip.MAX_DRAFT (64) nodes -- one wavefront, one 64-bit
-    mask row per node (include/samd_hip.h SAMD_MAX_DRAFT); larger max_predicts are served with 64-node drafts (decoding stays lossless,
-    only the accept lengths of very long matches differ from the reference's)."""
+    """device parameters of the SAM-only variant.  A draft holds at most samd_hip.MAX_DRAFT (128) nodes -- one wavefront builds it two
+    nodes per lane, two 64-bit mask words per node, two 64-row verify tiles (include/samd_hip.h SAMD_MAX_DRAFT); larger max_predicts are
+    served with 128-node drafts (decoding stays lossless, only the accept lengths of very long matches differ from the reference's)."""
     p = samd_hip.Params()
     p.variant, p.max_predicts, p.alpha, p.K, p.len_bias = 0, min(int(max_predicts), samd_hip.MAX_DRAFT), float(alpha), int(K), int(len_bias)
     p.n_predicts, p.len_threshold, p.static_null = 0, 0, 0
@@ -32,7 +32,10 @@ def tree_buffers_from_draft(d, device):
     int64 depths [1,n], int64 retrieve [leaves, max_depth] padded with -1."""
     n = d.n
     rows = np.frombuffer(d.mask, dtype=np.uint64, count=n)
-    bits = ((rows[:, None] >> np.arange(n, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+    bits = ((rows[:, None] >> np.arange(min(n, 64), dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)
+    if n > 64:                                           # nodes 64..127: the high mask words
+        hi = np.frombuffer(d.mask_hi, dtype=np.uint64, count=n)
+        bits = np.concatenate([bits, ((hi[:, None] >> np.arange(n - 64, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(bool)], axis=1)
     pos = np.asarray(d.position[:n], dtype=np.int64)
     ret = np.asarray(d.retrieve[:d.n_leaves * d.max_depth], dtype=np.int64).reshape(d.n_leaves, d.max_depth)
     return {

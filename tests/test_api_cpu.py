@@ -27,22 +27,23 @@ def test_so_surface_and_defaults():
     assert list(inspect.signature(StaticSAM.__init__).parameters)[1:] == ["max_predicts", "alpha", "K", "device"]
     from samd_sam_only.samd_config import ForwardType
     assert [e.value for e in ForwardType] == ["prefill", "seq_decode", "tree_decode"]
-    with pytest.warns(RuntimeWarning, match="capped at 64"):
-        SO.SamdConfig(max_predicts=65)                     # one wavefront verifies one draft: capped, not refused
+    with pytest.warns(RuntimeWarning, match="capped at 128"):
+        SO.SamdConfig(max_predicts=129)                    # one wavefront builds one draft, two nodes per lane: capped, not refused
 
 
 def test_draft_size_limit_is_a_warning_not_an_error():
-    """max_predicts / n_predicts above 64: the reference accepts any value; this implementation caps drafts at 64 nodes (the value itself
-    is kept: the cache guard of generate() uses it as the reference does) and says so once per config"""
+    """max_predicts / n_predicts up to 128 are served as the reference serves them (round 5; 64 before); above that -- the reference accepts
+    any value -- this implementation caps drafts at 128 nodes (the value itself is kept: the cache guard of generate() uses it as the
+    reference does) and says so once per config"""
     import warnings
     import samd_sam_only as SO
     import samd as S
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        assert SO.SamdConfig(max_predicts=128).max_predicts == 128
-        assert S.SamdConfig(n_predicts=70).n_predicts == 70
-        assert SO.SamdConfig(max_predicts=64).max_predicts == 64
-    assert len(w) == 2 and all("capped at 64" in str(x.message) for x in w)
+        assert SO.SamdConfig(max_predicts=200).max_predicts == 200
+        assert S.SamdConfig(n_predicts=130).n_predicts == 130
+        assert SO.SamdConfig(max_predicts=128).max_predicts == 128 and S.SamdConfig(n_predicts=100).n_predicts == 100      # no warning: served exactly
+    assert len(w) == 2 and all("capped at 128" in str(x.message) for x in w)
     with pytest.raises(ValueError):
         SO.SamdConfig(max_predicts=0)
 

@@ -43,18 +43,19 @@ def test_generate_so_matches_reference_trace(golden, use_graphs):
         assert model.lookup_stats["tree"][0] == 2 * kinds.count("tree")
 
 
-def test_max_predicts_above_64_is_capped_not_refused(golden):
-    """the reference takes any max_predicts (samd_sam_only/sam/static_sam.py:183); here a draft holds at most 64 nodes, so a larger
-    value is served with 64-node drafts: a warning, the same output tokens as max_predicts = 64 step for step, and the same tokens as the
-    recorded reference run (speculative decoding is lossless: only accept lengths could differ, and only on matches longer than 15)."""
+def test_max_predicts_above_128_is_capped_not_refused(golden):
+    """the reference takes any max_predicts (samd_sam_only/sam/static_sam.py:183); here a draft holds at most 128 nodes (round 5; 64 before),
+    so a larger value is served with 128-node drafts: a warning, the same output tokens as max_predicts = 128 step for step, and the same
+    tokens as the recorded reference run (speculative decoding is lossless: only accept lengths could differ, and only on matches longer
+    than 31).  Values up to 128 are served exactly: tests/test_gpu_wide_drafts.py follows the reference's recorded traces at 80 / 100 / 128."""
     import samd_sam_only as SO
     import samd as S
     case = golden("loop_so.json.gz")[0]
     outs = []
-    for mp in (64, 100):
+    for mp in (128, 200):
         c = dict(case, max_predicts=mp)
-        if mp > 64:
-            with pytest.warns(RuntimeWarning, match="capped at 64"):
+        if mp > 128:
+            with pytest.warns(RuntimeWarning, match="capped at 128"):
                 _, model = so_model(c)
         else:
             _, model = so_model(c)
@@ -62,12 +63,12 @@ def test_max_predicts_above_64_is_capped_not_refused(golden):
         model.set_cache(gcfg)
         out = model.generate(torch.tensor([case["prompt"]], dtype=torch.long, device="cuda"), generation_config=gcfg)
         outs.append((out.output_ids, out.accepet_length_per_step))
-        assert max(out.accepet_length_per_step) <= 64
+        assert max(out.accepet_length_per_step) <= 128
     assert outs[0] == outs[1]
     assert outs[1][0] == [case["output_ids"]]                                     # the reference's tokens
-    with pytest.warns(RuntimeWarning, match="capped at 64"):
-        cfg = S.SamdConfig(n_predicts=90)
-    assert cfg.n_predicts == 90
+    with pytest.warns(RuntimeWarning, match="capped at 128"):
+        cfg = S.SamdConfig(n_predicts=190)
+    assert cfg.n_predicts == 190
     with pytest.raises(ValueError):
         SO.SamdConfig(max_predicts=0)
 
