@@ -281,15 +281,16 @@ int samd_report_wait(const int32_t *h_report, int32_t last_seq, int64_t timeout_
 int samd_session_report_async(samd_session_t *s, int32_t *h_dst, void *stream);
 
 /* device view of the session's draft/verdict block (fixed layout, see samd_session_block_t in DESIGN.md):
- * out[0]=tokens int32[64] out[1]=parent int32[64] out[2]=position int32[64] out[3]=mask u64[64]
- * out[4]=retrieve int32[64*64] out[5]=meta int32[16] {type,n,n_leaves,max_depth,...}
- * out[6]=verdict int32[8] {best,accept,next_node,next_token,...} out[7]=accepted tokens int32[64]
- * out[8]=kv_index int32[64] out[9]=start_token int32[1] out[10]=cache_length int32[1]
+ * out[0]=tokens int32[128] out[1]=parent int32[128] out[2]=position int32[128] out[3]=mask u64[2][128] (low words of all rows, then the
+ * high words: what samd_tree_attention reads for n_q_pad > 64) out[4]=retrieve int32[128*128] out[5]=meta int32[16] {type,n,n_leaves,max_depth,...}
+ * out[6]=verdict int32[8] {best,accept,next_node,next_token,...} out[7]=accepted tokens int32[128]
+ * out[8]=kv_index int32[128] out[9]=start_token int32[1] out[10]=cache_length int32[1]
  * out[11]=history int32[max_tokens] (all committed tokens) out[12]=counters int32[8] */
 int samd_session_device_views(samd_session_t *s, void *out[16]);
 
 /* gen_buffers(anc_tree) standalone  -- SO/sam/static_sam.py:148-180.  d_parent int32[n] ->
- * d_position int32[n], d_mask u64[n], d_mask_bool u8[n*n] (optional), d_retrieve int32[n*n] (optional),
+ * d_position int32[n], d_mask u64[n] (n > 64: u64[2 n], the n high words -- nodes 64..127 -- behind the n low words),
+ * d_mask_bool u8[n*n] (optional), d_retrieve int32[n*n] (optional),
  * d_shape int32[2] = {n_leaves, max_depth}. reverse_leaves=1 gives Token-Recycle's row order
  * (S/tree_model/token_recycle/utils.py:88). */
 int samd_tree_buffers(const int32_t *d_parent, int32_t n, int32_t reverse_leaves, int32_t *d_position, uint64_t *d_mask,
@@ -376,7 +377,9 @@ typedef struct samd_warm {
 /* tree-mask attention of the n draft tokens over L cached + n new keys
  * -- SO/model_patch/llama.py:82-96 (mask semantics) + the SDPA call it feeds.
  * q [n_q_pad][H][D], k_cache/v_cache [H_kv][max_len][D] (new rows already written at [L, L+n)),
- * out [n_q_pad][H][D] (rows >= n are zeroed); mask u64[n] row i bit j; L and n are read from device
+ * out [n_q_pad][H][D] (rows >= n are zeroed); mask u64[n_q_pad] row i bit j = node i attends node j; n_q_pad <= 128 (round 5), run as
+ * 64-row tiles: for n_q_pad > 64 the mask is u64[2][SAMD_MAX_DRAFT] -- the low words (nodes 0..63) of all rows, then, SAMD_MAX_DRAFT
+ * entries further, the high words (nodes 64..127).  L and n are read from device
  * memory (d_cache_length, d_n).  head_dim must be 128, dtype f16 or bf16.  d_workspace: scratch of
  * samd_tree_attention_workspace() bytes (split-KV partials). */
 int64_t samd_tree_attention_workspace(int32_t n_q_pad, int32_t n_heads, int32_t head_dim);

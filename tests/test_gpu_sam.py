@@ -551,11 +551,11 @@ def test_tree_buffers(golden):
     g = golden("buffers.json.gz")
     rng = np.random.default_rng(1)
     cases = [(c["anc"], 0) for c in g["so"]]
-    cases += [(random_parents(rng, n, s), r) for n in (1, 5, 40, 64) for s in ("chain", "star", "bushy", "random") for r in (0, 1)]
+    cases += [(random_parents(rng, n, s), r) for n in (1, 5, 40, 64, 65, 111, 128) for s in ("chain", "star", "bushy", "random") for r in (0, 1)]
     for anc, rev in cases:
         n = len(anc)
         pos = torch.zeros(n, dtype=torch.int32, device="cuda")
-        mask = torch.zeros(n, dtype=torch.int64, device="cuda")
+        mask = torch.zeros(n if n <= 64 else 2 * n, dtype=torch.int64, device="cuda")      # n > 64: the n high words follow the n low words
         mb = torch.zeros((n, n), dtype=torch.uint8, device="cuda")
         ret = torch.full((n * n,), -7, dtype=torch.int32, device="cuda")
         shape = torch.zeros(2, dtype=torch.int32, device="cuda")
@@ -567,7 +567,8 @@ def test_tree_buffers(golden):
         assert pos.cpu().tolist() == want["tree_position_ids"][0].tolist()
         assert mb.cpu().numpy().astype(bool).tolist() == want["tree_attn_mask"][0, 0].tolist()
         m64 = mask.cpu().numpy().astype(np.uint64)
-        assert [[int(m64[i] >> np.uint64(j)) & 1 for j in range(n)] for i in range(n)] == want["tree_attn_mask"][0, 0].astype(int).tolist()
+        bit = lambda i, j: int(m64[i] >> np.uint64(j)) & 1 if j < 64 else int(m64[n + i] >> np.uint64(j - 64)) & 1
+        assert [[bit(i, j) for j in range(n)] for i in range(n)] == want["tree_attn_mask"][0, 0].astype(int).tolist()
         wr = want["tree_retrieve_indices"]
         got = ret[:nl * md].reshape(nl, md).cpu().numpy()
         assert got.tolist() == (wr[::-1] if rev else wr).tolist()
@@ -595,6 +596,7 @@ def test_drafts_golden(golden):
             sess.draft_fixed(None, p, 0, c["index"], c["start"])
             assert draft_tuple(sess.read_draft())[1] == c["seq"]
     corp_s = {c["name"]: c for c in golden("sam_traces.json.gz")["static_s"]}
+    corp_s.update(g.get("corpora", {}))
     for case in g["static_s"]:
         sam = samd_hip.StaticAutomaton.build(corp_s[case["name"]]["docs"], corp_s[case["name"]]["eos"], 1).upload()
         sess = samd_hip.Session(64)
@@ -603,6 +605,7 @@ def test_drafts_golden(golden):
             sess.draft_fixed(sam, p, 1, c["index"], c["start"])
             assert draft_tuple(sess.read_draft())[1] == c["seq"]
     corp = {c["name"]: c for c in golden("sam_traces.json.gz")["static_so"]}
+    corp.update(g.get("corpora", {}))
     n_tree = 0
     for case in g["tree"]:
         sam = samd_hip.StaticAutomaton.build(corp[case["name"]]["docs"], corp[case["name"]]["eos"], 0).upload()

@@ -90,6 +90,7 @@ def test_dyn_drafts(golden):
 def test_static_s_drafts(golden):
     g = golden("drafts.json.gz")
     corp = {c["name"]: c for c in golden("sam_traces.json.gz")["static_s"]}
+    corp.update(g.get("corpora", {}))                        # (the wide fixtures carry their corpora inline)
     for case in g["static_s"]:
         sam = O.StaticSAMFull.build(corp[case["name"]]["docs"], corp[case["name"]]["eos"])
         sam.n_predicts = case["n_predicts"]
@@ -103,6 +104,7 @@ def test_static_s_drafts(golden):
 def test_tree_drafts(golden):
     g = golden("drafts.json.gz")
     corp = {c["name"]: c for c in golden("sam_traces.json.gz")["static_so"]}
+    corp.update(g.get("corpora", {}))
     ncases = 0
     for case in g["tree"]:
         sam = O.StaticSAM.build(corp[case["name"]]["docs"], corp[case["name"]]["eos"])
