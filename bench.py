@@ -378,6 +378,21 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=W
                 request_ceiling_per_s=HBM_REQUESTS_PER_S), toks
 
 
+def corpus_sweep(current_sha16):
+    """the traversal kernel over BASELINE.md section 3's corpus sizes and over a Zipfian corpus (scripts/walk_sweep.py on an MI355X; committed
+    as profiles/walk_sweep.json, stamped with the kernel sources' hash): [{tokens, dist, slots_per_pair, frac, req_per_visit, derived_bytes}].
+    The headline `roofline` is measured live in this run; the sweep is attached from the committed file when it belongs to THESE sources."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "walk_sweep.json")))
+    except (OSError, ValueError):
+        return None
+    rows = [{"tokens": r["tokens"], "dist": r["dist"], "slots_per_pair": r["slots_per_pair_asked"], "launch_ms": r["launch_ms"], "frac": r["frac"],
+             "req_per_visit": r.get("req_per_visit"), "frac_of_request_ceiling": r.get("frac_of_request_ceiling"), "derived_bytes": r["derived_bytes"],
+             "states": r["states"]} for r in d.get("rows", [])]
+    return {"from": "profiles/walk_sweep.json (scripts/walk_sweep.py)", "kernel_source_sha16": d.get("kernel_source_sha16"),
+            "matches_this_tree": d.get("kernel_source_sha16") == current_sha16, "rows": rows}
+
+
 def request_rate(roof):
     """requests_per_s = HBM traffic of a launch / 64 B / launch time, against the probed ceiling of scattered requests; a launch may
     serve several visited states per request (chain words, hashed blocks), so this -- not bytes per visited state -- is the quantity
@@ -1109,6 +1124,7 @@ def main():
             if live is not None:
                 roof["traffic"] = live
         request_rate(roof)
+        roof["corpus_sweep"] = corpus_sweep(walk_source_sha16())
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(flat, off, docs, cfg, toks_walk)    # rank 0 at N = 1 only
 
         n_steps = sum(v[0] for v in stats.values())

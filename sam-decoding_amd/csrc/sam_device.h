@@ -505,7 +505,7 @@ struct StepShared {
     int parent[SAMD_MAX_DRAFT];
     int position[SAMD_MAX_DRAFT];
     unsigned long long mask[SAMD_MAX_DRAFT], mask_hi[SAMD_MAX_DRAFT];   // ancestors among nodes 0..63 / 64..127
-    unsigned char path[SAMD_MAX_DRAFT][SAMD_MAX_DRAFT];   // retrieve rows, PATH_PAD padded
+    __attribute__((aligned(16))) unsigned char path[SAMD_MAX_DRAFT][SAMD_MAX_DRAFT];   // retrieve rows, PATH_PAD padded
     int node_argmax[SAMD_MAX_DRAFT];
     int accepted[SAMD_MAX_DRAFT];
     unsigned long long child_mask[2];
@@ -517,6 +517,14 @@ struct StepShared {
     int c_tok[SAMD_TOPK], c_dst[SAMD_TOPK], c_cnt[SAMD_TOPK];
     int pop_ok, pop_tok, pop_idx, pop_anc, pop_dep; double pop_prob;
 };
+
+// PATH_PAD into the first `rows` retrieve rows (16-byte stores: the 16 KB table is never filled whole -- a draft has few leaf rows)
+__device__ __forceinline__ void path_fill(StepShared &sh, int rows) {
+    const uint4 pad = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    static_assert(PATH_PAD == 255 && SAMD_MAX_DRAFT % 16 == 0, "");
+    uint4 *p = reinterpret_cast<uint4 *>(&sh.path[0][0]);
+    for (int k = lane_id(); k < rows * (SAMD_MAX_DRAFT / 16); k += WAVE) p[k] = pad;
+}
 
 // sequence draft [start] + input_ids[e+1 : e+n] from `text` (dyn_sam.py:118-119); returns its length
 __device__ __forceinline__ int seq_draft_var(StepShared &sh, const int *text, int n_text, int endpos, int n, int start) {
@@ -656,7 +664,7 @@ __device__ __forceinline__ void build_buffers(StepShared &sh, int n, int reverse
     const unsigned long long valid0 = n0 >= 64 ? ~0ull : ((1ull << n0) - 1ull), valid1 = n1 >= 64 ? ~0ull : ((1ull << n1) - 1ull);
     const unsigned long long leaf0 = valid0 & ~sh.child_mask[0], leaf1 = valid1 & ~sh.child_mask[1];
     const int nl0 = __popcll(leaf0), nl = nl0 + __popcll(leaf1);
-    for (int k = lane; k < SAMD_MAX_DRAFT * SAMD_MAX_DRAFT; k += WAVE) (&sh.path[0][0])[k] = PATH_PAD;
+    path_fill(sh, nl);
     __syncthreads();
     for (int i = lane; i < n; i += WAVE) {
         const bool is_leaf = i < 64 ? ((leaf0 >> i) & 1ull) : ((leaf1 >> (i - 64)) & 1ull);

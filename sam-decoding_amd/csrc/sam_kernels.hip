@@ -127,7 +127,7 @@ __device__ __forceinline__ void load_draft(const SessionDev &D, StepShared &sh, 
     const int i = lane_id();
     type = D.dmeta[D_TYPE]; n = D.dmeta[D_N]; nl = D.dmeta[D_NLEAVES]; md = D.dmeta[D_MAXDEPTH];
     for (int k = i; k < n; k += WAVE) { sh.tokens[k] = D.tokens[k]; sh.parent[k] = D.parent[k]; }
-    for (int k = i; k < SAMD_MAX_DRAFT * SAMD_MAX_DRAFT; k += WAVE) (&sh.path[0][0])[k] = PATH_PAD;
+    path_fill(sh, nl < SAMD_MAX_DRAFT ? (nl < 1 ? 1 : nl) : SAMD_MAX_DRAFT);
     __syncthreads();
     for (int k = i; k < nl * md; k += WAVE) {
         const int v = D.retrieve[k];

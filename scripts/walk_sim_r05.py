@@ -1,6 +1,7 @@
-"""walk_sim_r05.py -- CPU replay of the batched-walk workload through the round-4/5 transition rule (st_transfer_chain: chain words,
-flagged entries, bigram table) on the Markov AND the Zipf corpus: dependent memory ROUNDS per (lane, token), what a lock-step wave of 64
-lanes pays (the max over its lanes, per token), and requests by kind.  Then the same workload under candidate rules (see `RULES`).
+"""walk_sim_r05.py -- CPU replay of the batched-walk workload through the round-4 transition rule (st_transfer_chain: chain words,
+flagged entries, bigram table) and through round 5's EDGE TABLE rule on the Markov AND the Zipf corpus: dependent memory ROUNDS per
+(lane, token), what a lock-step wave of 64 lanes pays (the max over its lanes, per token), and requests by kind; then priced variants of the
+shipped rule (run_edge's docstring).  profiles/r05_walk_sweep.md quotes its numbers.
 usage: python scripts/walk_sim_r05.py [markov|zipf] [corpus_tokens] [cursors]"""
 import os, sys, collections
 import numpy as np
@@ -229,6 +230,7 @@ def run_edge(variant):
         print(f"    {kk:32s} {v / B:7.3f} per stream   {v / visited:.4f} per visit")
 
 print(dist, "states", n, "non-branching", sum(1 for d in deg if d <= 1) / n)
+run("r04")                                                   # the round-4 rule (no edge table)
 for v in ("shipped", "hubterm", "linkhub", "fail2"):
     run_edge(v)
 sys.exit(0)
