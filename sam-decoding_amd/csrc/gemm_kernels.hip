@@ -58,6 +58,13 @@ struct GBF16 { typedef __bf16 elem; typedef bf16x8 vec8;
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
+// Diagnostic build only (-DSAMD_GEMM_ABLATE, scripts/r05_ablate.sh; never in the shipped library): k_gemm_pairs_silu with parts switched off at
+// run time by SAMD_GEMM_ABL -- bit 0: no s_barrier per chunk (results wrong, timing only), bit 1: no LDS reads / MFMAs, bit 2: no A staging,
+// bit 3: A fetched from rows 0..15 only (L1 hits instead of L2 traffic) -- to see where the 64-row tile loses its time (profiles/r05_wide_tile.md)
+#ifdef SAMD_GEMM_ABLATE
+__device__ int samd_abl_flag;
+#endif
+
 // EPI 0: out / fp32 partials as they are.  EPI 1 (splits == 1 only): the matrix is the MLP's gate|up pair with its rows
 // interleaved in groups of 64 (tile t = gate columns 64t.. | up columns 64t..), and the epilogue writes
 // silu(gate) * up [rows][N/2] -- LlamaMLP's activation without a launch, a 2N-wide intermediate or its re-read.
@@ -539,6 +546,11 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     E (*xs)[R][GEMM_KC] = reinterpret_cast<E (*)[R][GEMM_KC]>(gemm_lds);
 
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, g = l >> 4;
+#ifdef SAMD_GEMM_ABLATE
+    const int abl = samd_abl_flag;
+#else
+    constexpr int abl = 0;
+#endif
     // this workgroup's pairs [p0, p1): an even deal of n_pairs over the grid
     const int p0 = (int)((long long)blockIdx.x * n_pairs / gridDim.x), p1 = (int)((long long)(blockIdx.x + 1) * n_pairs / gridDim.x);
     const bool active = w < 2 * (p1 - p0);                                       // wave-uniform
@@ -567,11 +579,11 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     u32x4 xr[NORM ? DEPTH : 1][NORM ? XV : 1], gr[NORM ? DEPTH : 1][NORM ? XV : 1];
     __shared__ float norm_part[NORM ? (NT / 16) * 16 : 1], norm_rs[NORM ? 16 : 1];
     auto stage_x = [&](int c, int buf, int d) {
-        if (!stager) return;
+        if (!stager || (abl & 4)) return;
 #pragma unroll
         for (int i = 0; i < XV; i++) {
             const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
-            const E *src = A + (size_t)row * K + (size_t)c * GEMM_KC + 8 * unit;
+            const E *src = A + (size_t)((abl & 8) ? (row & 15) : row) * K + (size_t)c * GEMM_KC + 8 * unit;
             if constexpr (NORM) {
                 const E *gsrc = reinterpret_cast<const E *>(na.g) + (size_t)c * GEMM_KC + 8 * unit;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[d][i]) : "v"(src) : "memory");
@@ -585,8 +597,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     };
     // a wave without a column group issues no weight loads, one that stages no rows no A loads: its counted waits leave those out
     auto landed = [&](int younger, int buf, int d) {
-        if (active) { if (stager) gemm_wait_younger<DEPTH, 8 + XL>(younger); else gemm_wait_younger<DEPTH, 8>(younger); }
-        else { if (stager) gemm_wait_younger<DEPTH, XL>(younger); else gemm_wait_younger<DEPTH, 0>(younger); }
+        const bool stg = stager && !(abl & 4);
+        if (active) { if (stg) gemm_wait_younger<DEPTH, 8 + XL>(younger); else gemm_wait_younger<DEPTH, 8>(younger); }
+        else { if (stg) gemm_wait_younger<DEPTH, XL>(younger); else gemm_wait_younger<DEPTH, 0>(younger); }
         if constexpr (NORM) {
             if (stager) {
 #pragma unroll
@@ -600,12 +613,12 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(abl & 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
     auto phase = [&](u32x4 (&cur)[4][2], int c, int buf, int d) {
         landed(n_chunks - 1 - c, buf, d);
-        if (active) {
+        if (active && !(abl & 2)) {
             const uint32_t xbase = lds_base + (uint32_t)buf * (R * GEMM_KC * 2) + (uint32_t)n * (GEMM_KC * 2);
 #pragma unroll
             for (int b = 0; b < 4; b++) {
@@ -1033,6 +1046,10 @@ int samd_gemm_pairs_silu(const void *d_A, const void *d_Wg, int32_t rows_pad, in
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     static const int depth_env = [] { const char *e = getenv("SAMD_PAIRS_DEPTH"); return e ? atoi(e) : 0; }();
+#ifdef SAMD_GEMM_ABLATE
+    static const int abl_set = [] { const char *e = getenv("SAMD_GEMM_ABL"); const int v = e ? atoi(e) : 0; return hipMemcpyToSymbol(HIP_SYMBOL(samd_abl_flag), &v, 4) == hipSuccess ? 1 : -1; }();
+    (void)abl_set;
+#endif
 #define ARGS st, grid, d_A, d_Wg, d_out, K, inter, n_pairs
 #define GO(TT) (rows_pad == 16 ? (depth_env == 2 ? pairs_silu_launch<TT, 1, 2>(ARGS) : depth_env == 4 ? pairs_silu_launch<TT, 1, 4>(ARGS) : pairs_silu_launch<TT, 1, 3>(ARGS)) \
                 : rows_pad == 32 ? (depth_env == 2 ? pairs_silu_launch<TT, 2, 2>(ARGS) : pairs_silu_launch<TT, 2, 3>(ARGS)) \
