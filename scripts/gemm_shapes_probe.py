@@ -1,10 +1,15 @@
 """gemm_shapes_probe.py -- what the LIBRARY GEMM (torch.mm -> hipBLASLt) reaches on the four projection shapes of a Vicuna-7B decoder
 layer at prefill row counts, and the other launches of the wide prefill (SDPA, our glue kernels): PFLOP/s per shape, ms per layer.
-usage: python3 scripts/gemm_shapes_probe.py [rows ...]"""
+usage: python3 scripts/gemm_shapes_probe.py [rows ...]
+SAMD_PROBE_TUNABLE=<csv>: PyTorch's TunableOp enabled and tuning (every hipBLASLt / rocBLAS solution timed per shape), results written to <csv>."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "sam-decoding_amd")]
 import torch
+if os.environ.get("SAMD_PROBE_TUNABLE"):
+    import torch.cuda.tunable as tun
+    tun.enable(True); tun.tuning_enable(True); tun.set_filename(os.environ["SAMD_PROBE_TUNABLE"])
+    tun.set_max_tuning_duration(20); tun.set_max_tuning_iterations(20)
 rows = [int(x) for x in sys.argv[1:]] or [512, 1024, 1280, 1536, 2048]
 H, I = 4096, 11008
 shapes = {"qkv": (3 * H, H), "o": (H, H), "gate|up": (2 * I, H), "down": (H, I)}
