@@ -746,6 +746,9 @@ def summarization_leg(model, ar, lm, docs, breakdown, n_requests, seed=2000, max
         }
     out["north_star_target"] = ">= 2.5x over autoregressive on Spec-Bench summarization (BASELINE.json); the reference publishes 2.43x on an A6000 (README.md:53)"
     out["quoted_profile"] = "readme_mat"
+    r = getattr(lm, "runner", lm)
+    if hasattr(r, "prefill_plan_summary"):
+        out["prefill"] = {"projection_row_splits": r.prefill_plan_summary(), "attention_rows_padded_to": getattr(r, "PF_ATTN_PAD", None)}
     return out
 
 
@@ -915,6 +918,7 @@ def main():
         mcfg["num_hidden_layers"] = args.layers
     max_len = mcfg["max_position_embeddings"]                 # 2048 (Vicuna) / 8192 (Llama-3): evaluation/inference_samd.py:152-163
     runner = LlamaRunner.random_init(mcfg, max_len, dtype, seed=0)
+    runner.tune_prefill(2048)                                 # setup: where the library's projections of a long prompt are split in two calls (llama.py)
     # Token Recycle learns from the top-8 of every verified row: its scripted model also ranks the source's continuations
     tr = args.variant == "token_recycle"
     planted = args.variant in ("eagle2", "eagle") and args.eagle_head == "planted" and args.acceptance == "scripted"

@@ -546,16 +546,92 @@ class LlamaRunner:
         session.set_start_token(b["argmax"][(N - 1) % TILE_ROWS:])
         return b["logits"][(N - 1) % TILE_ROWS]
 
+    # ---- the wide prefill's library calls, shaped for what the library does well on 256 CUs (profiles/r05_prefill.md) ----
+    PF_SPLIT_MIN_ROWS = 1024          # below this no projection of the prompt is worth splitting (and short prompts keep one code path)
+    PF_ATTN_PAD = 128                 # fused causal SDPA runs 40-45 % slower on row counts that are not a multiple of this (r05_gemm_rows.log)
+
+    def _time_mm(self, x, wt, out, reps=3):
+        best = float("inf")
+        torch.mm(x, wt, out=out)
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.mm(x, wt, out=out)
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
+
+    def tune_prefill(self, max_rows=None):
+        """Where does a projection of the prompt fall off a tile-quantisation cliff?  hipBLASLt's time over the prompt's rows is a staircase
+        (q|k|v and gate|up of a 7B layer: 103 / 196 us at 1280 rows, 153 / 298 at 1281-1536 -- a third round of tiles on 256 CUs), while the
+        remainder rows alone cost 34-62 us.  For every projection this measures the staircase once -- rows R = 256 k, R + 64, and the small
+        products 64..256 -- and keeps, per R, whether `mm(rows[:R]) + mm(rows[R:])` beats one call.  ~50 ms, once per runner (lazily on the
+        first prompt of >= PF_SPLIT_MIN_ROWS rows, or call it during warm-up); SAMD_PREFILL_SPLIT=0 disables the splits."""
+        self._pf_plan = {}
+        if os.environ.get("SAMD_PREFILL_SPLIT", "1") == "0" or self.row_major_released:
+            return self._pf_plan
+        max_rows = min(int(max_rows or self.max_len), 4096)          # longer prompts: one call per projection
+        w0 = self.w["layers"][0]
+        for key in ("wqkv", "wo", "wgu", "wdown"):
+            wt = w0[key].t()
+            K, N = wt.shape
+            x = torch.zeros((max_rows + 64, K), dtype=self.dtype, device=self.device)
+            out = torch.empty((max_rows + 64, N), dtype=self.dtype, device=self.device)
+            small = {r: self._time_mm(x[:r], wt, out[:r]) for r in (64, 128, 192, 256)}
+            plan = {}
+            for R in range(max(256, (self.PF_SPLIT_MIN_ROWS // 256) * 256), max_rows, 256):
+                t_at = self._time_mm(x[:R], wt, out[:R])
+                t_past = self._time_mm(x[:R + 64], wt, out[:R + 64])
+                # rows in (R, R + 256]: one call costs ~t_past whatever the count (the staircase is flat between steps); two calls t_at + small
+                plan[R] = {r: t_at + small[r] < 0.95 * t_past for r in small}
+            self._pf_plan[key] = plan
+            del x, out
+        return self._pf_plan
+
+    def prefill_plan_summary(self):
+        """{projection: [first-call row counts R at which a prompt of R + 1 .. R + 256 rows is split]} -- for logs"""
+        plan = getattr(self, "_pf_plan", None) or {}
+        return {k: [R for R, d in sorted(v.items()) if any(d.values())] for k, v in plan.items()}
+
+    def _pf_split(self, key, M):
+        """row count of the first of two library calls for projection `key` over M prompt rows, or 0 for one call"""
+        if M <= self.PF_SPLIT_MIN_ROWS:
+            return 0
+        if getattr(self, "_pf_plan", None) is None:
+            self.tune_prefill()
+        R = ((M - 1) // 256) * 256
+        rest = -(-(M - R) // 64) * 64
+        return R if self._pf_plan.get(key, {}).get(R, {}).get(rest, False) else 0
+
+    def _pf_mm(self, x, w, out, key):
+        R = self._pf_split(key, x.shape[0])
+        if R:
+            torch.mm(x[:R], w.t(), out=out[:R])
+            torch.mm(x[R:], w.t(), out=out[R:])
+        else:
+            torch.mm(x, w.t(), out=out)
+
     def _prefill_wide(self, session: Session, ids, on_chunk=None):
         """the whole prompt in one pass: compute-bound, so the GEMMs go to the library (N x K x N_out at full MFMA rate) and
         the causal attention to PyTorch's fused SDPA; norm / RoPE + K/V write / SiLU*up / arg-max stay our kernels.  A
         per-chunk consumer (Token Recycle: the prompt's logits, EAGLE: its last hidden states) gets them afterwards in
-        64-row slices of one [N, V] lm_head product."""
+        64-row slices of one [N, V] lm_head product.  Round 5: a projection whose row count sits just past a tile-quantisation step of
+        the library is issued as two calls (tune_prefill), and the attention runs on the row count padded to a multiple of 128 -- zero
+        query rows and zero K / V rows BEHIND the prompt, which causality keeps out of every real row (their own outputs are dropped)."""
         L, s, dt, st, N = lib(), self.shape, self.dt, current_stream(), ids.numel()
         dev, ty = self.device, self.dtype
         z = lambda *sz: torch.empty(sz, dtype=ty, device=dev)
         x, h, qkv = z(N, s.hidden), z(N, s.hidden), z(N, (s.heads + 2 * s.kv_heads) * s.head_dim)
-        q, o, gu, act, d = z(N, s.heads, s.head_dim), z(N, s.hidden), z(N, 2 * s.inter), z(N, s.inter), z(N, s.hidden)
+        Np = -(-N // self.PF_ATTN_PAD) * self.PF_ATTN_PAD
+        if self.v_transposed or Np > self.max_len:
+            Np = N
+        qp = z(Np, s.heads, s.head_dim)
+        q = qp[:N]
+        if Np > N:
+            qp[N:].zero_()
+            self.kv[:, :, :, N:Np].zero_()          # rows behind the prompt: free space of the cache (the first decode steps overwrite them)
+        o, gu, act, d = z(N, s.hidden), z(N, 2 * s.inter), z(N, s.inter), z(N, s.hidden)
         relpos = torch.arange(N, dtype=torch.int32, device=dev)
         d_L = torch.zeros(1, dtype=torch.int32, device=dev)
         d_n = torch.full((1,), N, dtype=torch.int32, device=dev)
@@ -563,7 +639,7 @@ class LlamaRunner:
         delta = None
         for li, w in enumerate(self.w["layers"]):
             check(L.samd_rmsnorm(_ptr(x), _ptr(delta), _ptr(w["ln1"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
-            torch.mm(h, w["wqkv"].t(), out=qkv)
+            self._pf_mm(h, w["wqkv"], qkv, "wqkv")
             if self.v_transposed:
                 check(L.samd_rope_kv_write_vt(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
                                               _ptr(self.kv[li, 0]), None, N, s.heads, s.kv_heads, s.head_dim, self.max_len,
@@ -574,16 +650,16 @@ class LlamaRunner:
                 check(L.samd_rope_kv_write(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
                                            _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), N, s.heads, s.kv_heads, s.head_dim, self.max_len,
                                            self.rope_rows, dt, 0, 0, st))
-                vv = self.kv[li, 1][:, :N]
-            kk = self.kv[li, 0][:, :N]
+                vv = self.kv[li, 1][:, :Np]
+            kk = self.kv[li, 0][:, :Np]
             if s.kv_heads != s.heads:
                 kk, vv = kk.repeat_interleave(s.heads // s.kv_heads, dim=0), vv.repeat_interleave(s.heads // s.kv_heads, dim=0)
-            att = torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1)[None], kk[None], vv[None], is_causal=True, scale=self.scale)
-            torch.mm(att[0].transpose(0, 1).reshape(N, -1), w["wo"].t(), out=o)
+            att = torch.nn.functional.scaled_dot_product_attention(qp.transpose(0, 1)[None], kk[None], vv[None], is_causal=True, scale=self.scale)
+            self._pf_mm(att[0, :, :N].transpose(0, 1).reshape(N, -1), w["wo"], o, "wo")
             check(L.samd_rmsnorm(_ptr(x), _ptr(o), _ptr(w["ln2"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
-            torch.mm(h, w["wgu"].t(), out=gu)
+            self._pf_mm(h, w["wgu"], gu, "wgu")
             check(L.samd_silu_mul(_ptr(gu), _ptr(act), N, s.inter, dt, 0, 0, st))
-            torch.mm(act, w["wdown"].t(), out=d)
+            self._pf_mm(act, w["wdown"], d, "wdown")
             delta = d
         check(L.samd_rmsnorm(_ptr(x), _ptr(delta), _ptr(self.w["norm"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
         b = self._buffers(1)

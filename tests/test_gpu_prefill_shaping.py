@@ -1,0 +1,62 @@
+"""The wide prefill's two library-shaping measures (round 5, samd_hip/llama.py `_prefill_wide`; profiles/r05_prefill.md section 2): the causal
+attention on the row count padded to a multiple of 128 (zero query rows and zero K / V rows behind the prompt) and a projection issued as two
+row slices where the library's time steps up.  Neither may change what the prompt's forward computes: last-position logits and the K / V
+rows against the plain form (one call per projection, attention on exactly N rows) and against fp32 HuggingFace."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import samd_hip
+from samd_hip.llama import LlamaRunner
+from test_gpu_wide_drafts import small_llama
+
+
+def all_splits(max_rows=2048):
+    return {k: {R: {r: True for r in (64, 128, 192, 256)} for R in range(256, max_rows, 256)} for k in ("wqkv", "wo", "wgu", "wdown")}
+
+
+@pytest.mark.parametrize("N", [1025, 1100, 1281, 1536, 1999])
+def test_padded_attention_and_split_projections_leave_the_prefill_unchanged(N, monkeypatch):
+    lm, cfg = small_llama(seed=5)
+    runner = LlamaRunner.from_hf(lm, max_cache_len=2048, dtype=torch.float16, share_weights=False)
+    sess = samd_hip.Session(2048)
+    ids = torch.tensor([np.random.default_rng(N).integers(3, cfg["vocab_size"], N).tolist()], device="cuda")
+
+    def run(plan, pad):
+        monkeypatch.setattr(LlamaRunner, "PF_ATTN_PAD", pad)
+        runner._pf_plan = plan
+        runner.kv.fill_(float("nan"))                     # whatever lies behind the prompt in the cache must not reach a real row
+        sess.reset()
+        logits = runner.prefill(sess, ids).float().clone()
+        torch.cuda.synchronize()
+        return logits, runner.kv[:, :, :, :N].float().clone()
+
+    plain_logits, plain_kv = run({}, 1)
+    shaped_logits, shaped_kv = run(all_splits(), 128)
+    assert runner._pf_split("wgu", N) == ((N - 1) // 256) * 256 and N > runner.PF_SPLIT_MIN_ROWS
+    assert torch.isfinite(shaped_logits).all() and torch.isfinite(shaped_kv).all()
+    scale = max(1.0, plain_logits.abs().max().item())
+    assert (shaped_logits - plain_logits).abs().max().item() < 0.01 * scale          # other tile shapes of the same products: fp16 roundings
+    assert (shaped_kv - plain_kv).abs().max().item() < 0.01 * max(1.0, plain_kv.abs().max().item())
+    with torch.no_grad():
+        want = lm(input_ids=ids, logits_to_keep=1).logits[0, -1].float()
+    err_plain, err_shaped = (plain_logits - want).abs().max().item(), (shaped_logits - want).abs().max().item()
+    print(f"N={N}: |d logit| vs fp32 HF plain {err_plain:.4f} shaped {err_shaped:.4f} of {want.abs().max().item():.2f}")
+    assert err_shaped < max(1.5 * err_plain, 0.02 * max(1.0, want.abs().max().item()))
+    assert int(shaped_logits.argmax()) == int(plain_logits.argmax()) or (want.topk(2).values[0] - want.topk(2).values[1]).item() < 4 * err_shaped
+
+
+def test_tune_prefill_measures_a_plan_and_short_prompts_never_split():
+    lm, cfg = small_llama(layers=1, seed=6)
+    runner = LlamaRunner.from_hf(lm, max_cache_len=2048, dtype=torch.float16, share_weights=False)
+    plan = runner.tune_prefill(2048)
+    assert set(plan) == {"wqkv", "wo", "wgu", "wdown"}
+    assert all(sorted(v) == [1024, 1280, 1536, 1792] for v in plan.values())
+    assert all(isinstance(b, bool) for v in plan.values() for d in v.values() for b in d.values())
+    assert set(runner.prefill_plan_summary()) == set(plan)
+    runner._pf_plan = all_splits()
+    assert runner._pf_split("wgu", 1024) == 0 and runner._pf_split("wgu", 300) == 0      # <= PF_SPLIT_MIN_ROWS: one code path for short prompts
+    assert runner._pf_split("wgu", 1025) == 1024 and runner._pf_split("wgu", 1280) == 1024 and runner._pf_split("wgu", 1281) == 1280
