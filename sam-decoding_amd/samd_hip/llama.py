@@ -622,15 +622,19 @@ class LlamaRunner:
         L, s, dt, st, N = lib(), self.shape, self.dt, current_stream(), ids.numel()
         dev, ty = self.device, self.dtype
         z = lambda *sz: torch.empty(sz, dtype=ty, device=dev)
-        x, h, qkv = z(N, s.hidden), z(N, s.hidden), z(N, (s.heads + 2 * s.kv_heads) * s.head_dim)
+        x, h = z(N, s.hidden), z(N, s.hidden)
         Np = -(-N // self.PF_ATTN_PAD) * self.PF_ATTN_PAD
-        if self.v_transposed or Np > self.max_len:
+        if Np > self.max_len:
             Np = N
-        qp = z(Np, s.heads, s.head_dim)
-        q = qp[:N]
+        qkv_p, qp = z(Np, (s.heads + 2 * s.kv_heads) * s.head_dim), z(Np, s.heads, s.head_dim)
+        qkv, q = qkv_p[:N], qp[:N]
         if Np > N:
             qp[N:].zero_()
-            self.kv[:, :, :, N:Np].zero_()          # rows behind the prompt: free space of the cache (the first decode steps overwrite them)
+            if self.v_transposed:
+                qkv_p[N:].zero_()                     # V comes straight from the projection in this mode: its rows behind the prompt
+                self.kv[:, 0, :, N:Np].zero_()
+            else:
+                self.kv[:, :, :, N:Np].zero_()        # rows behind the prompt: free space of the cache (the first decode steps overwrite them)
         o, gu, act, d = z(N, s.hidden), z(N, 2 * s.inter), z(N, s.inter), z(N, s.hidden)
         relpos = torch.arange(N, dtype=torch.int32, device=dev)
         d_L = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -644,8 +648,8 @@ class LlamaRunner:
                 check(L.samd_rope_kv_write_vt(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
                                               _ptr(self.kv[li, 0]), None, N, s.heads, s.kv_heads, s.head_dim, self.max_len,
                                               self.rope_rows, dt, 0, 0, st))                                         # q and K rows
-                vv = qkv[:, (s.heads + s.kv_heads) * s.head_dim:].view(N, s.kv_heads, s.head_dim).transpose(0, 1)  # V straight from the projection
-                self.kv[li, 1].view(s.kv_heads, s.head_dim, self.max_len)[:, :, :N].copy_(vv.transpose(1, 2))        # V^T columns of the cache
+                vv = qkv_p[:, (s.heads + s.kv_heads) * s.head_dim:].view(Np, s.kv_heads, s.head_dim).transpose(0, 1)  # V straight from the projection
+                self.kv[li, 1].view(s.kv_heads, s.head_dim, self.max_len)[:, :, :N].copy_(vv[:, :N].transpose(1, 2))     # V^T columns of the cache
             else:
                 check(L.samd_rope_kv_write(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
                                            _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), N, s.heads, s.kv_heads, s.head_dim, self.max_len,
