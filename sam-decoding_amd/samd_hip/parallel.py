@@ -13,12 +13,21 @@ import torch.distributed as dist
 from . import StaticAutomaton
 
 
-def shard_bounds(n_items, world, rank):
+def shard_bounds(n_items, world, rank, tail=None):
     """contiguous chunks as eval_vicuna.py:50-65 (chunk = n // world questions per worker, in question order).  The reference
     hands the remainder to one extra Ray task that runs after the others; with a fixed world that tail would double the last
-    rank's wall time (480 questions + 7 on 8 GPUs), so the n % world leftover questions are spread one each over the first
-    ranks: rank r gets chunk + 1 when r < n % world.  Still contiguous, still in order, sizes differ by at most one."""
+    rank's wall time (480 questions + 7 on 8 GPUs), so by default (tail "spread") the n % world leftover questions are spread one each
+    over the first ranks: rank r gets chunk + 1 when r < n % world.  Still contiguous, still in order, sizes differ by at most one.
+    tail "reference" (or SAMD_SHARD_TAIL=reference) keeps the reference's cut points instead -- `world` chunks of n // world questions
+    and the extra chunk of n % world, which the LAST rank takes after its own (Ray gives it to whichever actor frees up first; the
+    answers and their order in the gathered file are the same either way)."""
+    import os
+    tail = tail or os.environ.get("SAMD_SHARD_TAIL", "spread")
+    if tail not in ("spread", "reference"):
+        raise ValueError(f"shard tail '{tail}': 'spread' or 'reference'")
     chunk, rem = divmod(n_items, world)
+    if tail == "reference":
+        return rank * chunk, (n_items if rank == world - 1 else (rank + 1) * chunk)
     lo = rank * chunk + min(rank, rem)
     return lo, lo + chunk + (1 if rank < rem else 0)
 

@@ -156,3 +156,24 @@ def test_shard_bounds_cover_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)     # balanced, the extra ones first
+
+
+def test_shard_bounds_reference_tail_keeps_the_reference_cut_points(monkeypatch):
+    """eval_vicuna.py:50-65: range(0, n, n // world) -- `world` chunks of n // world and one extra chunk of the remainder"""
+    from samd_hip import parallel
+    for n in (7, 80, 481, 487):
+        for world in (1, 2, 4, 8):
+            if n // world == 0:
+                continue
+            chunk = n // world
+            ref = [(i, min(i + chunk, n)) for i in range(0, n, chunk)]                      # the reference's slices questions[i: i + chunk_size]
+            spans = [parallel.shard_bounds(n, world, r, tail="reference") for r in range(world)]
+            assert spans[:-1] == ref[:world - 1]
+            assert spans[-1] == (ref[world - 1][0], n)                                      # the last rank: its own chunk, then the extra one
+            assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    monkeypatch.setenv("SAMD_SHARD_TAIL", "reference")
+    assert parallel.shard_bounds(487, 8, 7) == (420, 487) and parallel.shard_bounds(487, 8, 0) == (0, 60)
+    monkeypatch.setenv("SAMD_SHARD_TAIL", "nonsense")
+    import pytest
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(10, 2, 0)
