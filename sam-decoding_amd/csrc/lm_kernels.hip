@@ -231,6 +231,41 @@ __global__ void k_rope_kv(const T *__restrict__ qkv, const int *__restrict__ rel
     dst[j] = o1; dst[j + half] = o2;
 }
 
+// The same for the prompt's rows (round 5: 33 -> ~15 us per layer at 1.3-1.5 k rows, profiles/r05_prefill.md): head_dim 128, dtype operands, position
+// tables; 8 elements of each half per lane (16-byte loads / stores) and 8 heads per 64-thread workgroup instead of one 2-byte element pair
+// per thread.  Same expressions, same roundings as k_rope_kv.  grid = (rows, ceil((H + 2 Hkv) / 8)).
+template <typename T>
+__global__ __launch_bounds__(64) void k_rope_kv_wide(const T *__restrict__ qkv, const int *__restrict__ rel_pos, const int *__restrict__ d_L,
+                                                     const int *__restrict__ d_n, const float *__restrict__ cos_t, const float *__restrict__ sin_t,
+                                                     T *__restrict__ q_out, T *__restrict__ k_cache, T *__restrict__ v_cache, int H, int Hkv,
+                                                     long long max_len, int max_pos) {
+    typedef T V8 __attribute__((ext_vector_type(8)));
+    const int r = blockIdx.x, hh = blockIdx.y * 8 + (threadIdx.x >> 3), j = (threadIdx.x & 7) * 8;
+    if (hh >= H + 2 * Hkv) return;
+    const int rel = rel_pos[r], n = d_n[0], L = d_L[0];
+    const size_t soff = ((size_t)r * (H + 2 * Hkv) + hh) * 128;
+    const V8 a = *reinterpret_cast<const V8 *>(qkv + soff + j), b = *reinterpret_cast<const V8 *>(qkv + soff + 64 + j);
+    if (r >= n || L + r >= max_len) return;
+    if (hh >= H + Hkv) {
+        if (!v_cache) return;
+        T *dst = v_cache + ((size_t)(hh - H - Hkv) * max_len + L + r) * 128;
+        *reinterpret_cast<V8 *>(dst + j) = a; *reinterpret_cast<V8 *>(dst + 64 + j) = b;
+        return;
+    }
+    int pos = L + rel; pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
+    const float4 c0 = *reinterpret_cast<const float4 *>(cos_t + (size_t)pos * 64 + j), c1 = *reinterpret_cast<const float4 *>(cos_t + (size_t)pos * 64 + j + 4);
+    const float4 s0 = *reinterpret_cast<const float4 *>(sin_t + (size_t)pos * 64 + j), s1 = *reinterpret_cast<const float4 *>(sin_t + (size_t)pos * 64 + j + 4);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    V8 o1, o2;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float x1 = (float)a[k], x2 = (float)b[k];
+        o1[k] = (T)(x1 * c[k] - x2 * sn[k]); o2[k] = (T)(x2 * c[k] + x1 * sn[k]);
+    }
+    T *dst = hh < H ? q_out + ((size_t)r * H + hh) * 128 : k_cache + ((size_t)(hh - H) * max_len + L + r) * 128;
+    *reinterpret_cast<V8 *>(dst + j) = o1; *reinterpret_cast<V8 *>(dst + 64 + j) = o2;
+}
+
 // out = silu(gate) * up, gate|up concatenated per row: gu[r] = [gate(I) | up(I)]
 template <typename T>
 __global__ __launch_bounds__(256) void k_silu_mul(const T *__restrict__ gu, T *__restrict__ out, int inter, int n_part, long long part_stride) {
@@ -328,6 +363,13 @@ static int rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int3
     if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || ((!d_cos || !d_sin) && !d_cs) || !d_q_out || !d_k_cache || (!d_v_cache && !v_transposed) || rows < 1 ||
         head_dim % 2 != 0 || head_dim > 2048) { samd_set_error("samd_rope_kv_write: invalid argument"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
+    if (rows >= 128 && head_dim == 128 && n_partials == 0 && !d_cs && d_cos && d_sin && (!v_transposed || !d_v_cache) && (dtype == SAMD_F16 || dtype == SAMD_BF16)) {
+        const dim3 wgrid(rows, (n_heads + 2 * n_kv_heads + 7) / 8);                    // the prompt's rows: 16-byte lanes
+        if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv_wide<_Float16>, wgrid, dim3(64), 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, (long long)max_len, max_pos);
+        else hipLaunchKernelGGL(k_rope_kv_wide<__bf16>, wgrid, dim3(64), 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, (long long)max_len, max_pos);
+        LAUNCHCHK();
+        return SAMD_OK;
+    }
     const dim3 grid(rows, n_heads + 2 * n_kv_heads), block(head_dim / 2);
     if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv<_Float16>, grid, block, 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed, d_cs);
     else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_rope_kv<__bf16>, grid, block, 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, head_dim, (long long)max_len, max_pos, n_partials, (long long)partial_stride, v_transposed, d_cs);

@@ -60,3 +60,45 @@ def test_tune_prefill_measures_a_plan_and_short_prompts_never_split():
     runner._pf_plan = all_splits()
     assert runner._pf_split("wgu", 1024) == 0 and runner._pf_split("wgu", 300) == 0      # <= PF_SPLIT_MIN_ROWS: one code path for short prompts
     assert runner._pf_split("wgu", 1025) == 1024 and runner._pf_split("wgu", 1280) == 1024 and runner._pf_split("wgu", 1281) == 1280
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,Hkv,rows,L", [(32, 32, 200, 0), (32, 8, 1333, 5), (8, 2, 128, 700)])
+def test_rope_kv_write_of_the_prompt_rows_is_the_narrow_kernel_bit_for_bit(dtype, H, Hkv, rows, L):
+    """samd_rope_kv_write picks k_rope_kv_wide (16-byte lanes, 8 heads per workgroup) from 128 rows on; below it the per-element kernel of
+    the verify forward.  Same expressions and roundings: q rows and K / V cache rows must be identical, and rows >= n / past the cache untouched."""
+    lib, D, max_len = samd_hip.lib(), 128, 2048
+    g = torch.Generator(device="cuda").manual_seed(rows + H)
+    qkv = torch.randn((rows, (H + 2 * Hkv) * D), generator=g, device="cuda").to(dtype)
+    ang = torch.outer(torch.arange(max_len, dtype=torch.float64), 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float64) / D)))
+    cos, sin = ang.cos().float().cuda().contiguous(), ang.sin().float().cuda().contiguous()
+    code = samd_hip.torch_dtype_code(dtype)
+    n = rows - 3                                                   # the last three rows are beyond the prompt: not written
+
+    def run(chunk):
+        q = torch.full((rows, H, D), 7.0, device="cuda").to(dtype)
+        k = torch.full((Hkv, max_len, D), 5.0, device="cuda").to(dtype)
+        v = torch.full((Hkv, max_len, D), 3.0, device="cuda").to(dtype)
+        for c0 in range(0, rows, chunk):
+            m = min(chunk, rows - c0)
+            rel = torch.arange(m, dtype=torch.int32, device="cuda")
+            d_L = torch.tensor([L + c0], dtype=torch.int32, device="cuda")
+            d_n = torch.tensor([max(0, min(m, n - c0))], dtype=torch.int32, device="cuda")
+            samd_hip.check(lib.samd_rope_kv_write(samd_hip._ptr(qkv[c0:]), samd_hip._ptr(rel), samd_hip._ptr(d_L), samd_hip._ptr(d_n), samd_hip._ptr(cos),
+                                                  samd_hip._ptr(sin), samd_hip._ptr(q[c0:]), samd_hip._ptr(k), samd_hip._ptr(v), m, H, Hkv, D, max_len, max_len,
+                                                  code, 0, 0, samd_hip.current_stream()))
+        torch.cuda.synchronize()
+        return q, k, v
+
+    wide, narrow = run(rows), run(100)                             # one call (>= 128 rows: the wide kernel) / chunks of 100 rows (the narrow one)
+    for a, b in zip(wide, narrow):
+        assert torch.equal(a, b)
+    q, k, v = wide
+    assert (q[n:] == 7.0).all() and (k[:, L + n:] == 5.0).all() and (v[:, L + n:] == 3.0).all() and (k[:, :L] == 5.0).all()
+    x = qkv[:n].view(n, H + 2 * Hkv, D).float()
+    pos = L + torch.arange(n, device="cuda")
+    c, s = cos[pos][:, None, :], sin[pos][:, None, :]
+    x1, x2 = x[:, :H + Hkv, :64], x[:, :H + Hkv, 64:]
+    want = torch.cat([(x1 * c - x2 * s).to(dtype), (x2 * c + x1 * s).to(dtype)], -1)
+    assert torch.equal(q[:n], want[:, :H]) and torch.equal(k[:, L:L + n], want[:, H:].transpose(0, 1))
+    assert torch.equal(v[:, L:L + n], qkv[:n].view(n, H + 2 * Hkv, D)[:, H + Hkv:].transpose(0, 1))
