@@ -573,20 +573,25 @@ class LlamaRunner:
             return self._pf_plan
         max_rows = min(int(max_rows or self.max_len), 4096)          # longer prompts: one call per projection
         w0 = self.w["layers"][0]
-        for key in ("wqkv", "wo", "wgu", "wdown"):
-            wt = w0[key].t()
-            K, N = wt.shape
-            x = torch.zeros((max_rows + 64, K), dtype=self.dtype, device=self.device)
-            out = torch.empty((max_rows + 64, N), dtype=self.dtype, device=self.device)
-            small = {r: self._time_mm(x[:r], wt, out[:r]) for r in (64, 128, 192, 256)}
-            plan = {}
-            for R in range(max(256, (self.PF_SPLIT_MIN_ROWS // 256) * 256), max_rows, 256):
-                t_at = self._time_mm(x[:R], wt, out[:R])
-                t_past = self._time_mm(x[:R + 64], wt, out[:R + 64])
-                # rows in (R, R + 256]: one call costs ~t_past whatever the count (the staircase is flat between steps); two calls t_at + small
-                plan[R] = {r: t_at + small[r] < 0.95 * t_past for r in small}
-            self._pf_plan[key] = plan
-            del x, out
+        try:
+            for key in ("wqkv", "wo", "wgu", "wdown"):
+                wt = w0[key].t()
+                K, N = wt.shape
+                x = torch.zeros((max_rows + 64, K), dtype=self.dtype, device=self.device)
+                out = torch.empty((max_rows + 64, N), dtype=self.dtype, device=self.device)
+                small = {r: self._time_mm(x[:r], wt, out[:r]) for r in (64, 128, 192, 256)}
+                plan = {}
+                for R in range(max(256, (self.PF_SPLIT_MIN_ROWS // 256) * 256), max_rows, 256):
+                    t_at = self._time_mm(x[:R], wt, out[:R])
+                    t_past = self._time_mm(x[:R + 64], wt, out[:R + 64])
+                    # rows in (R, R + 256]: one call costs ~t_past whatever the count (the staircase is flat between steps); two calls t_at + small
+                    plan[R] = {r: t_at + small[r] < 0.95 * t_past for r in small}
+                self._pf_plan[key] = plan
+                del x, out
+        except RuntimeError as e:                                    # e.g. no memory for the scratch operands: the plan is an optimisation, not a need
+            import warnings
+            warnings.warn(f"tune_prefill: measurement failed ({str(e)[:120]}); projections of long prompts stay single library calls", RuntimeWarning)
+            self._pf_plan = {}
         return self._pf_plan
 
     def prefill_plan_summary(self):
