@@ -566,7 +566,7 @@ class LlamaRunner:
         """Where does a projection of the prompt fall off a tile-quantisation cliff?  hipBLASLt's time over the prompt's rows is a staircase
         (q|k|v and gate|up of a 7B layer: 103 / 196 us at 1280 rows, 153 / 298 at 1281-1536 -- a third round of tiles on 256 CUs), while the
         remainder rows alone cost 34-62 us.  For every projection this measures the staircase once -- rows R = 256 k, R + 64, and the small
-        products 64..256 -- and keeps, per R, whether `mm(rows[:R]) + mm(rows[R:])` beats one call.  ~50 ms, once per runner (lazily on the
+        products 64..256 -- and keeps, per R, whether `mm(rows[:R]) + mm(rows[R:])` beats one call.  ~0.2 s at 7B shapes, once per runner (lazily on the
         first prompt of >= PF_SPLIT_MIN_ROWS rows, or call it during warm-up); SAMD_PREFILL_SPLIT=0 disables the splits."""
         self._pf_plan = {}
         if os.environ.get("SAMD_PREFILL_SPLIT", "1") == "0" or self.row_major_released:
