@@ -102,3 +102,19 @@ def test_rope_kv_write_of_the_prompt_rows_is_the_narrow_kernel_bit_for_bit(dtype
     want = torch.cat([(x1 * c - x2 * s).to(dtype), (x2 * c + x1 * s).to(dtype)], -1)
     assert torch.equal(q[:n], want[:, :H]) and torch.equal(k[:, L:L + n], want[:, H:].transpose(0, 1))
     assert torch.equal(v[:, L:L + n], qkv[:n].view(n, H + 2 * Hkv, D)[:, H + Hkv:].transpose(0, 1))
+
+
+def test_tune_prefill_failure_leaves_single_calls(monkeypatch):
+    lm, cfg = small_llama(layers=1, seed=7)
+    runner = LlamaRunner.from_hf(lm, max_cache_len=2048, dtype=torch.float16, share_weights=False)
+
+    def boom(*a, **kw):
+        raise RuntimeError("HIP out of memory (simulated)")
+    monkeypatch.setattr(LlamaRunner, "_time_mm", boom)
+    with pytest.warns(RuntimeWarning, match="tune_prefill"):
+        assert runner.tune_prefill(2048) == {}
+    assert runner._pf_split("wgu", 1500) == 0
+    monkeypatch.setenv("SAMD_PREFILL_SPLIT", "0")
+    monkeypatch.undo()
+    monkeypatch.setenv("SAMD_PREFILL_SPLIT", "0")
+    assert runner.tune_prefill(2048) == {} and runner.prefill_plan_summary() == {}
