@@ -499,6 +499,14 @@ int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_
                        const float *d_cos, const float *d_sin, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
                        int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t max_pos, int32_t dtype,
                        int32_t n_partials, int64_t partial_stride, void *stream);
+/* Causal self-attention of the PROMPT's rows (round 5) -- what the reference runs through HF's LlamaAttention.forward / SDPA on the prompt
+ * (SO/samd_model.py:102-106: the prefill call of the patched forward, attention_mask None -> causal).  q [rows][n_heads][128] (after RoPE),
+ * k_cache / v_cache [n_kv_heads][max_len][128] with the prompt's K / V rows already written at [pos0, pos0 + rows) (samd_rope_kv_write) and the
+ * earlier context at [0, pos0); query row i attends keys 0 .. pos0 + i.  out [rows][n_heads * 128] in the model dtype (the input of o_proj).
+ * Cache rows at or beyond pos0 + rows are never used (masked / zeroed), whatever they hold.  fp32 softmax, P rounded to the model dtype for
+ * the PV product (as fused SDPA kernels do).  head_dim must be 128, pos0 + rows <= max_len.  One launch, no workspace. */
+int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
+                           int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream);
 /* LlamaMLP activation: silu(gate) * up with gate|up concatenated per row */
 int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,
                   int64_t partial_stride, void *stream);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "samd_common.h"
+#include "prefill_attn_device.h"
 #include "warm_device.h"
 
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
@@ -413,6 +414,33 @@ int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inte
     if (dtype == SAMD_F16) hipLaunchKernelGGL(k_silu_mul<_Float16>, grid, block, 0, st, (const _Float16 *)d_gate_up, (_Float16 *)d_out, inter, n_partials, (long long)partial_stride);
     else if (dtype == SAMD_BF16) hipLaunchKernelGGL(k_silu_mul<__bf16>, grid, block, 0, st, (const __bf16 *)d_gate_up, (__bf16 *)d_out, inter, n_partials, (long long)partial_stride);
     else { samd_set_error("samd_silu_mul: dtype must be f16/bf16"); return SAMD_E_INVALID; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+// causal attention of the prompt's rows (csrc/prefill_attn_device.h)
+int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
+                           int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream) {
+    using namespace prefillattn;
+    if (!d_q || !d_k_cache || !d_v_cache || !d_out || rows < 1 || pos0 < 0 || head_dim != 128 || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 ||
+        (int64_t)pos0 + rows > max_len || (dtype != SAMD_F16 && dtype != SAMD_BF16) || !(scale > 0.f)) {
+        samd_set_error("samd_prefill_attention: invalid argument (head_dim 128, pos0 + rows <= max_len, f16/bf16, scale > 0)"); return SAMD_E_INVALID;
+    }
+    static bool configured[2][64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int di = dtype == SAMD_F16 ? 0 : 1;
+    if (dev < 0 || dev >= 64 || !configured[di][dev]) {
+        const hipError_t e = dtype == SAMD_F16 ? hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::F16, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)
+                                               : hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::BF16, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { samd_set_error("samd_prefill_attention: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
+        if (dev >= 0 && dev < 64) configured[di][dev] = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((rows + QB - 1) / QB, n_heads), block(256);
+    const float scale_log2 = scale * 1.4426950408889634f;
+    if (dtype == SAMD_F16) hipLaunchKernelGGL((k_prefill_attention<prefillattn::F16, 4, 2>), grid, block, LDS_BYTES, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache, (const _Float16 *)d_v_cache, (_Float16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2);
+    else hipLaunchKernelGGL((k_prefill_attention<prefillattn::BF16, 4, 2>), grid, block, LDS_BYTES, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache, (const __bf16 *)d_v_cache, (__bf16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2);
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -1,0 +1,305 @@
+// prefill_attn_device.h -- causal self-attention of the PROMPT's rows (the request start; what the reference runs through HF's SDPA inside
+// LlamaAttention.forward on the prompt, SO/samd_model.py:102-106), hand-written for gfx950 (round 5): fused QK^T -> online softmax -> PV on
+// v_mfma_f32_16x16x32 with 128 query rows x 64 keys per workgroup step, instead of PyTorch's fused SDPA (0.18 PFLOP/s on these shapes:
+// 103 us per layer at 1536 rows x 32 heads, profiles/r05_prefill.md).
+//
+// One workgroup = one head x 128 query rows (4 waves x 32 rows = 2 fragments of 16); it walks the 64-key tiles 0 .. diagonal.  Everything is
+// computed TRANSPOSED so that the softmax statistics of a query row and every accumulator of that row live in the same lane:
+//   S^T[key][q] = K Q^T     A operand = K rows from LDS (lane: key l & 15, 8 consecutive d),  B operand = Q, loaded once into registers
+//   O^T[d][q]  += V^T P^T   A operand = V^T from LDS (lane: d l & 15, 8 keys),                 B operand = P^T = the lane's own S^T registers
+// In both products a lane's column is its query row q = l & 15: max / sum / rescale are lane-local but for one reduction over the four lanes
+// (l >> 4) that share a row.  The lane's 8 P values of a 32-key step are keys {4g..4g+3} and {16+4g..16+4g+3} (g = l >> 4) -- an MFMA does not
+// care which k index sits where as long as both operands agree, so V^T is read with the same permutation and P needs no shuffle at all.
+// K tile: [64 keys][128 d], 16-byte slot s of row r stored at s ^ (r & 15) (ds_read_b128 of 16 rows at one slot: 16 different bank groups).
+// V tile: transposed on its way into LDS, key pairs packed per dword (Vt[d][key], row stride 72 halfs).  Both staged through registers one tile
+// ahead, two LDS buffers, one bare barrier per tile (LDS-only wait: the next tile's global loads stay in flight across it).  Rows of K / V at or
+// beyond `total` are masked / zeroed; query rows beyond `rows` are computed on zeros and never stored.
+// Measured (scripts/probes/prefill_attn_probe.hip, profiles/r05_prefill_attn.md; 32 heads): 21.9 / 40.8 / 70.2 us at 512 / 1024 / 1536 rows against
+// 33 / 52-55 / 103-107 for PyTorch's fused SDPA (which also runs 40-80 % slower on row counts that are not multiples of 128; this kernel does not
+// care).  The loop is bound by instruction issue (~630 instructions per tile and wave for 64 MFMAs), not by load latency: a second register
+// stage (two tiles of prefetch distance) and an 8-wave form with one fragment per wave were both measured slower.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace prefillattn {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct F16 { typedef _Float16 elem; typedef half8 vec8; typedef _Float16 vec4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ floatx4 mfma(half8 a, half8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
+struct BF16 { typedef __bf16 elem; typedef bf16x8 vec8; typedef __bf16 vec4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ floatx4 mfma(bf16x8 a, bf16x8 b, floatx4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); } };
+
+// max / sum over the four lanes (l, l ^ 16, l ^ 32, l ^ 48) that share a query row: gfx950's permlane swaps (VALU) instead of ds_bpermute round trips.
+// permlane32_swap(x, x) -> {lower half everywhere, upper half everywhere}; permlane16_swap likewise for the 16-lane rows of each half.
+// (Hand-issued: through __builtin_amdgcn_permlane{32,16}_swap with the same value as both operands, hipcc 7.2 folds the two results into one
+// register -- `v_permlane32_swap v3, v2; v_add v2, v3, v3` -- and every sum comes out four times too large.  The s_nop covers the VALU-write ->
+// permlane-read hazard the compiler would otherwise pad.)
+__device__ __forceinline__ void swap32(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap16(float &a, float &b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float row4_max(float x) {
+#ifdef PA_SHFL
+    x = fmaxf(x, __shfl_xor(x, 16)); return fmaxf(x, __shfl_xor(x, 32));
+#endif
+    float a = x, b = x;
+    swap32(a, b);                              // a = {lower half, lower half}, b = {upper half, upper half}
+    float c = fmaxf(a, b), d = c;
+    swap16(c, d);                              // c = rows {0, 0, 2, 2}, d = rows {1, 1, 3, 3}
+    return fmaxf(c, d);
+}
+__device__ __forceinline__ float row4_sum(float x) {
+#ifdef PA_SHFL
+    x += __shfl_xor(x, 16); return x + __shfl_xor(x, 32);
+#endif
+    float a = x, b = x;
+    swap32(a, b);
+    float c = a + b, d = c;
+    swap16(c, d);
+    return c + d;
+}
+
+#ifdef PA_NO_SGB
+#define PA_SGB(a, b, c) ((void)0)
+#else
+#define PA_SGB(a, b, c) __builtin_amdgcn_sched_group_barrier(a, b, c)
+#endif
+constexpr int QB = 128;            // query rows per workgroup
+constexpr int KT = 64;             // keys per tile
+constexpr int D = 128;             // head_dim
+constexpr int VT_STRIDE = KT + 8;  // halfs per V^T row: 144 B keeps 8-byte alignment and spreads the banks
+constexpr int K_BYTES = KT * D * 2, VT_BYTES = D * VT_STRIDE * 2;
+constexpr int LDS_BYTES = 2 * (K_BYTES + VT_BYTES);
+
+// grid = (ceil(rows / 128), n_heads); blockIdx.x = 0 is the LAST (heaviest) row block.  Query row i sits at position pos0 + i and attends keys
+// 0 .. pos0 + i; keys live in k_cache / v_cache [n_kv_heads][max_len][128]; `total` = pos0 + rows keys exist.
+// NW waves x NF query fragments of 16 rows each = 128 query rows per workgroup: (4, 2) = fewer LDS reads per MFMA, (8, 1) = half the work per
+// wave and tile, i.e. a shorter chain for the long row blocks (which bound the launch) and four waves per SIMD to hide it behind
+template <typename TT, int NW, int NF>
+#ifndef PA_MINW8
+#define PA_MINW8 4
+#endif
+#ifndef PA_MINW4
+#define PA_MINW4 2
+#endif
+__global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_prefill_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
+                                                              const typename TT::elem *__restrict__ vc, typename TT::elem *__restrict__ out,
+                                                              int rows, int pos0, int n_heads, int n_kv_heads, long long max_len, float scale_log2) {
+    typedef typename TT::elem E;
+    typedef typename TT::vec8 V8;
+    typedef typename TT::vec4 V4;
+    extern __shared__ __attribute__((aligned(16))) char pa_lds[];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, g = l >> 4;
+    const int n_blocks = gridDim.x, qb = n_blocks - 1 - (int)blockIdx.x, h = blockIdx.y;
+    const int kvh = h / (n_heads / n_kv_heads);
+    const E *kbase = kc + (size_t)kvh * max_len * D, *vbase = vc + (size_t)kvh * max_len * D;
+    const int total = pos0 + rows;
+    static_assert(NW * NF * 16 == QB, "128 query rows per workgroup");
+    constexpr int NT = 64 * NW, KC = 1024 / NT, VC = 512 / NT;          // threads; K units and V items per thread
+    const int q0 = qb * QB + 16 * NF * w;                                   // this wave's first query row
+    int last_key = pos0 + qb * QB + QB - 1; last_key = last_key < total - 1 ? last_key : total - 1;
+    const int ntiles = last_key / KT + 1;
+
+    // Q as the B operand: lane (q = lr, g) holds d = 8 g + 32 kk .. + 7
+    V8 qf[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        const int row = q0 + 16 * f + lr;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (row < rows) raw = *reinterpret_cast<const uint4 *>(q + ((size_t)row * n_heads + h) * D + 8 * g + 32 * kk);
+            qf[f][kk] = __builtin_bit_cast(V8, raw);
+        }
+    }
+    // staging registers: K tile = 1024 16-byte units, KC per thread (unit u = tid + NT c: key row u >> 4, slot u & 15); V tile: a thread's item =
+    // key pair p x one 8-wide d chunk, VC items.
+    // (named scalars, unconditional loads: as arrays, or requested under a condition, the compiler keeps the staging registers in scratch memory)
+    uint4 st_k0, st_k1, st_k2, st_k3, st_va0, st_va1, st_vb0, st_vb1;
+    // a tile's source addresses = wave-uniform tile base (scalar registers) + a per-lane byte offset fixed for the whole launch: no vector
+    // arithmetic per request.  The tile base is clamped so that the (never used) request past the last tile stays inside the cache.
+    uint32_t k_off[KC], v_off[VC];
+#pragma unroll
+    for (int c = 0; c < KC; c++) { const int u = tid + NT * c; k_off[c] = (uint32_t)((u >> 4) * 256 + 16 * (u & 15)); }
+#pragma unroll
+    for (int it = 0; it < VC; it++) { const int item = tid + NT * it; v_off[it] = (uint32_t)((2 * ((item >> 3) & 31)) * 256 + 16 * ((item & 7) + 8 * (item >> 8))); }
+    auto load_stage = [&](int key0) {
+        long long kc0 = key0; kc0 = kc0 + KT <= max_len ? kc0 : max_len - KT; kc0 = kc0 < 0 ? 0 : kc0;
+        const char *kt = reinterpret_cast<const char *>(kbase) + kc0 * 256, *vtb = reinterpret_cast<const char *>(vbase) + kc0 * 256;
+        st_k0 = *reinterpret_cast<const uint4 *>(kt + k_off[0]); st_k1 = *reinterpret_cast<const uint4 *>(kt + k_off[1]);
+        if (KC == 4) { st_k2 = *reinterpret_cast<const uint4 *>(kt + k_off[2]); st_k3 = *reinterpret_cast<const uint4 *>(kt + k_off[3]); }
+        st_va0 = *reinterpret_cast<const uint4 *>(vtb + v_off[0]); st_vb0 = *reinterpret_cast<const uint4 *>(vtb + v_off[0] + 256);
+        if (VC == 2) { st_va1 = *reinterpret_cast<const uint4 *>(vtb + v_off[VC - 1]); st_vb1 = *reinterpret_cast<const uint4 *>(vtb + v_off[VC - 1] + 256); }
+    };
+    auto store_stage = [&](int key0, int buf) {
+        char *kb_ = pa_lds + buf * (K_BYTES + VT_BYTES);
+        E *vt = reinterpret_cast<E *>(kb_ + K_BYTES);
+        auto k_dst = [&](int c) -> uint4 * {
+            const int u = tid + NT * c, r = u >> 4, sl = u & 15;
+            return reinterpret_cast<uint4 *>(kb_ + r * 256 + ((sl ^ (r & 15)) * 16));
+        };
+        *k_dst(0) = st_k0; *k_dst(1) = st_k1;
+        if (KC == 4) { *k_dst(2) = st_k2; *k_dst(3) = st_k3; }
+        auto v_put = [&](int it, uint4 ra, uint4 rb) {
+            const int item = tid + NT * it, p = (item >> 3) & 31, d0 = 8 * ((item & 7) + 8 * (item >> 8));
+            const int ka = key0 + 2 * p, kb = ka + 1;
+            // rows at or beyond `total` are zero: their P is 0, but 0 x garbage could be NaN
+            if (ka >= total) ra = make_uint4(0, 0, 0, 0);
+            if (kb >= total) rb = make_uint4(0, 0, 0, 0);
+            const unsigned int wa[4] = {ra.x, ra.y, ra.z, ra.w}, wb[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const unsigned int ea = (j & 1) ? wa[j >> 1] >> 16 : wa[j >> 1] & 0xffffu, eb = (j & 1) ? wb[j >> 1] & 0xffff0000u : wb[j >> 1] << 16;
+                *reinterpret_cast<unsigned int *>(&vt[(d0 + j) * VT_STRIDE + 2 * p]) = ea | eb;
+            }
+        };
+        v_put(0, st_va0, st_vb0);
+        if (VC == 2) v_put(1, st_va1, st_vb1);
+    };
+
+    float m_run[NF], l_run[NF];
+    floatx4 o[NF][8];
+#pragma unroll
+    for (int f = 0; f < NF; f++) { m_run[f] = -INFINITY; l_run[f] = 0.f; }
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int df = 0; df < 8; df++) o[f][df] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    // tile 0 into LDS, tile 1 into the staging registers.  Iteration t: the registers (tile t + 1, requested a whole iteration ago) go to the other
+    // LDS buffer, tile t + 2 is requested into them, tile t is computed, barrier.  (A second register set = two tiles of distance was measured
+    // and is slower: the loop is bound by instruction issue -- ~630 instructions per tile and wave for 64 MFMAs -- not by load latency.)
+    load_stage(0);
+    store_stage(0, 0);
+    load_stage(KT);
+    __syncthreads();
+    const int first_q_pos = pos0 + qb * QB;
+    for (int t = 0; t < ntiles; t++) {
+        const int buf = t & 1, key0 = t * KT;
+        if (t + 1 < ntiles) store_stage(key0 + KT, buf ^ 1);        // every wave is past the barrier that ended its reads of that buffer
+        load_stage(key0 + 2 * KT);
+        const char *kb_ = pa_lds + buf * (K_BYTES + VT_BYTES);
+        const E *vt = reinterpret_cast<const E *>(kb_ + K_BYTES);
+        // ---- S^T = K Q^T: 4 key fragments x 2 query fragments
+        floatx4 s[4][NF];
+        {
+            // 16 K fragments (key fragment kf = i >> 2, d step kk = i & 3), read four ahead of the two MFMAs that consume each
+            auto rd = [&](int i) -> V8 {
+                const int kf = i >> 2, kk = i & 3;
+                return *reinterpret_cast<const V8 *>(kb_ + (16 * kf + lr) * 256 + (((g + 4 * kk) ^ lr) * 16));
+            };
+            V8 ring[4] = {rd(0), rd(1), rd(2), rd(3)};
+            PA_SGB(0x100, 4, 0);        // the four reads of the prologue first: the loop's groups then run four ahead
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int kf = i >> 2, kk = i & 3;
+                const V8 a = ring[i & 3];
+                if (i + 4 < 16) ring[i & 3] = rd(i + 4);
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    if (kk == 0) s[kf][f] = (floatx4){0.f, 0.f, 0.f, 0.f};
+                    s[kf][f] = TT::mfma(a, qf[f][kk], s[kf][f]);
+                }
+                PA_SGB(0x008, NF, 0);   // the MFMAs of this fragment ...
+                PA_SGB(0x100, 1, 0);    // ... then the LDS read four fragments ahead
+            }
+        }
+        // ---- causal mask (only the tiles that reach past the block's first row, or past the last key)
+        if (key0 + KT - 1 > first_q_pos || key0 + KT > total) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                const int qpos = pos0 + q0 + 16 * f + lr;
+#pragma unroll
+                for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int key = key0 + 16 * kf + 4 * g + r;
+                        if (key > qpos || key >= total) s[kf][f][r] = -INFINITY;
+                    }
+            }
+        }
+        // ---- online softmax per query row (this lane's column), exp2 domain
+        V8 pb[NF][2];                                             // P^T as the B operand: [query fragment][32-key step]
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[kf][f][r]);
+            mx = row4_max(mx);
+            const float m_new = fmaxf(m_run[f], mx * scale_log2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+            m_run[f] = m_new;
+            float sum = 0.f;
+            E pv[4][4];
+#pragma unroll
+            for (int kf = 0; kf < 4; kf++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float p = __builtin_amdgcn_exp2f(s[kf][f][r] * scale_log2 - m_new);
+                    pv[kf][r] = (E)p;
+                    sum += p;
+                }
+            l_run[f] = l_run[f] * alpha + sum;
+            if (__any(alpha != 1.f)) {                           // wave-uniform: once the running maxima have settled the 32 multiplies go
+#pragma unroll
+                for (int df = 0; df < 8; df++) o[f][df] *= alpha;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                V8 b;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { b[r] = pv[2 * ks][r]; b[4 + r] = pv[2 * ks + 1][r]; }
+                pb[f][ks] = b;
+            }
+        }
+        // ---- O^T += V^T P^T: 8 d fragments x 2 key steps; the lane's 8 keys of a step = {32 ks + 4 g ..+3} and {32 ks + 16 + 4 g ..+3}
+        {
+            auto rd = [&](int i) -> V8 {
+                const int df = i >> 1, ks = i & 1;
+                const E *row = vt + (16 * df + lr) * VT_STRIDE + 4 * g + 32 * ks;
+                const V4 lo = *reinterpret_cast<const V4 *>(row), hi = *reinterpret_cast<const V4 *>(row + 16);
+                V8 a;
+#pragma unroll
+                for (int r = 0; r < 4; r++) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+                return a;
+            };
+            V8 ring[4] = {rd(0), rd(1), rd(2), rd(3)};
+            PA_SGB(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int df = i >> 1, ks = i & 1;
+                const V8 a = ring[i & 3];
+                if (i + 4 < 16) ring[i & 3] = rd(i + 4);
+#pragma unroll
+                for (int f = 0; f < NF; f++) o[f][df] = TT::mfma(a, pb[f][ks], o[f][df]);
+                PA_SGB(0x008, NF, 0);
+                PA_SGB(0x100, 1, 0);
+            }
+        }
+        // bare s_barrier behind an LDS-only wait: the global loads just requested for the tile after next stay in flight across it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    // ---- normalise and store: lane (q = lr, g) holds d = 16 df + 4 g + r of its row
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        const float lsum = row4_sum(l_run[f]);
+        const int row = q0 + 16 * f + lr;
+        if (row >= rows) continue;
+        const float inv = 1.f / lsum;
+        E *dst = out + ((size_t)row * n_heads + h) * D + 4 * g;
+#pragma unroll
+        for (int df = 0; df < 8; df++) {
+            V4 v = {(E)(o[f][df][0] * inv), (E)(o[f][df][1] * inv), (E)(o[f][df][2] * inv), (E)(o[f][df][3] * inv)};
+            *reinterpret_cast<V4 *>(dst + 16 * df) = v;
+        }
+    }
+}
+
+}  // namespace prefillattn

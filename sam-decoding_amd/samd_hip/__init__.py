@@ -158,6 +158,7 @@ _PROTOS = {
     "samd_rmsnorm_warm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _F32, _I32, _I32, _I64, _VP, _VP]),
     "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
     "samd_silu_mul": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I64, _VP]),
+    "samd_prefill_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I64, C.c_float, _VP]),
     "samd_gemm_splits": (C.c_int, [_I32, _I32, _I32]),
     "samd_gemm_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_gemm_pack_weights": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),

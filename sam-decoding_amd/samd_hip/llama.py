@@ -619,7 +619,8 @@ class LlamaRunner:
 
     def _prefill_wide(self, session: Session, ids, on_chunk=None):
         """the whole prompt in one pass: compute-bound, so the GEMMs go to the library (N x K x N_out at full MFMA rate) and
-        the causal attention to PyTorch's fused SDPA; norm / RoPE + K/V write / SiLU*up / arg-max stay our kernels.  A
+        the causal attention to samd_prefill_attention (round 5; PyTorch's fused SDPA before, and still for a transposed V cache); norm /
+        RoPE + K/V write / SiLU*up / arg-max are our kernels as well.  A
         per-chunk consumer (Token Recycle: the prompt's logits, EAGLE: its last hidden states) gets them afterwards in
         64-row slices of one [N, V] lm_head product.  Round 5: a projection whose row count sits just past a tile-quantisation step of
         the library is issued as two calls (tune_prefill), and the attention runs on the row count padded to a multiple of 128 -- zero
@@ -628,9 +629,13 @@ class LlamaRunner:
         dev, ty = self.device, self.dtype
         z = lambda *sz: torch.empty(sz, dtype=ty, device=dev)
         x, h = z(N, s.hidden), z(N, s.hidden)
-        Np = -(-N // self.PF_ATTN_PAD) * self.PF_ATTN_PAD
+        # the prompt's causal attention: our kernel (samd_prefill_attention: any row count, nothing behind the prompt is read) on the row-major
+        # cache; PyTorch's fused SDPA otherwise (transposed V cache of a draft head's runner, head_dim != 128, SAMD_PREFILL_ATTENTION=sdpa)
+        own_attn = (not self.v_transposed) and s.head_dim == 128 and os.environ.get("SAMD_PREFILL_ATTENTION", "own") != "sdpa"
+        Np = N if own_attn else -(-N // self.PF_ATTN_PAD) * self.PF_ATTN_PAD
         if Np > self.max_len:
             Np = N
+        ao = z(N, s.heads * s.head_dim) if own_attn else None
         qkv_p, qp = z(Np, (s.heads + 2 * s.kv_heads) * s.head_dim), z(Np, s.heads, s.head_dim)
         qkv, q = qkv_p[:N], qp[:N]
         if Np > N:
@@ -660,11 +665,16 @@ class LlamaRunner:
                                            _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), N, s.heads, s.kv_heads, s.head_dim, self.max_len,
                                            self.rope_rows, dt, 0, 0, st))
                 vv = self.kv[li, 1][:, :Np]
-            kk = self.kv[li, 0][:, :Np]
-            if s.kv_heads != s.heads:
-                kk, vv = kk.repeat_interleave(s.heads // s.kv_heads, dim=0), vv.repeat_interleave(s.heads // s.kv_heads, dim=0)
-            att = torch.nn.functional.scaled_dot_product_attention(qp.transpose(0, 1)[None], kk[None], vv[None], is_causal=True, scale=self.scale)
-            self._pf_mm(att[0, :, :N].transpose(0, 1).reshape(N, -1), w["wo"], o, "wo")
+            if own_attn:
+                check(L.samd_prefill_attention(_ptr(q), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(ao), dt, N, 0, s.heads, s.kv_heads,
+                                               s.head_dim, self.max_len, self.scale, st))
+                self._pf_mm(ao, w["wo"], o, "wo")
+            else:
+                kk = self.kv[li, 0][:, :Np]
+                if s.kv_heads != s.heads:
+                    kk, vv = kk.repeat_interleave(s.heads // s.kv_heads, dim=0), vv.repeat_interleave(s.heads // s.kv_heads, dim=0)
+                att = torch.nn.functional.scaled_dot_product_attention(qp.transpose(0, 1)[None], kk[None], vv[None], is_causal=True, scale=self.scale)
+                self._pf_mm(att[0, :, :N].transpose(0, 1).reshape(N, -1), w["wo"], o, "wo")
             check(L.samd_rmsnorm(_ptr(x), _ptr(o), _ptr(w["ln2"]), _ptr(h), N, s.hidden, s.eps, dt, 0, 0, st))
             self._pf_mm(h, w["wgu"], gu, "wgu")
             check(L.samd_silu_mul(_ptr(gu), _ptr(act), N, s.inter, dt, 0, 0, st))

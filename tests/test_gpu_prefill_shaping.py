@@ -118,3 +118,68 @@ def test_tune_prefill_failure_leaves_single_calls(monkeypatch):
     monkeypatch.undo()
     monkeypatch.setenv("SAMD_PREFILL_SPLIT", "0")
     assert runner.tune_prefill(2048) == {} and runner.prefill_plan_summary() == {}
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("rows,H,Hkv,pos0", [(200, 32, 32, 0), (1333, 32, 8, 0), (128, 8, 8, 0), (1, 4, 2, 37), (700, 16, 16, 300), (129, 8, 1, 1900), (2048, 4, 4, 0)])
+def test_prefill_attention_against_fp32_softmax_attention(dtype, tol, rows, H, Hkv, pos0):
+    """samd_prefill_attention (csrc/prefill_attn_device.h) against a plain fp32 causal attention in torch: every row, every head; the cache
+    behind the prompt is NaN (it must not be read into a result), as is `out` before the launch (every row < rows must be written)."""
+    lib, D, max_len = samd_hip.lib(), 128, 2048
+    g = torch.Generator(device="cuda").manual_seed(rows * 7 + H)
+    q = (torch.randn((rows, H, D), generator=g, device="cuda") * 1.5).to(dtype)
+    k = torch.randn((Hkv, max_len, D), generator=g, device="cuda").to(dtype)
+    v = (torch.randn((Hkv, max_len, D), generator=g, device="cuda") * torch.linspace(0.5, 2.0, D, device="cuda")).to(dtype)
+    total = pos0 + rows
+    k[:, total:] = float("nan")
+    v[:, total:] = float("nan")
+    out = torch.full((rows, H * D), float("nan"), device="cuda").to(dtype)
+    scale = 1.0 / D ** 0.5
+    samd_hip.check(lib.samd_prefill_attention(samd_hip._ptr(q), samd_hip._ptr(k), samd_hip._ptr(v), samd_hip._ptr(out), samd_hip.torch_dtype_code(dtype),
+                                              rows, pos0, H, Hkv, D, max_len, scale, samd_hip.current_stream()))
+    torch.cuda.synchronize()
+    kk = k[:, :total].float().repeat_interleave(H // Hkv, dim=0)                    # [H, total, D]
+    vv = v[:, :total].float().repeat_interleave(H // Hkv, dim=0)
+    s = torch.einsum("rhd,htd->hrt", q.float(), kk) * scale
+    keys, pos = torch.arange(total, device="cuda")[None, None, :], (pos0 + torch.arange(rows, device="cuda"))[None, :, None]
+    s = s.masked_fill(keys > pos, float("-inf"))
+    want = torch.einsum("hrt,htd->rhd", torch.softmax(s, dim=-1), vv).reshape(rows, H * D)
+    got = out.float()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    assert err < tol * max(1.0, want.abs().max().item()), err
+
+
+def test_prefill_attention_rejects_what_it_cannot_do():
+    lib = samd_hip.lib()
+    q = torch.zeros((4, 2, 64), dtype=torch.float16, device="cuda")
+    kv = torch.zeros((2, 16, 64), dtype=torch.float16, device="cuda")
+    out = torch.zeros((4, 128), dtype=torch.float16, device="cuda")
+    args = lambda **kw: [samd_hip._ptr(q), samd_hip._ptr(kv), samd_hip._ptr(kv), samd_hip._ptr(out), 0, kw.get("rows", 4), kw.get("pos0", 0), 2, kw.get("hkv", 2),
+                         kw.get("d", 128), kw.get("max_len", 16), kw.get("scale", 0.1), samd_hip.current_stream()]
+    assert lib.samd_prefill_attention(*args(d=64)) == -1                                                        # SAMD_E_INVALID
+    assert lib.samd_prefill_attention(*args(rows=0)) < 0 and lib.samd_prefill_attention(*args(pos0=14)) < 0      # pos0 + rows > max_len
+    assert lib.samd_prefill_attention(*args(hkv=3)) < 0 and lib.samd_prefill_attention(*args(scale=0.0)) < 0
+
+
+@pytest.mark.parametrize("N", [300, 1100, 1536])
+def test_prefill_with_own_attention_matches_the_sdpa_form(N, monkeypatch):
+    lm, cfg = small_llama(seed=8)
+    runner = LlamaRunner.from_hf(lm, max_cache_len=2048, dtype=torch.float16, share_weights=False)
+    runner._pf_plan = {}
+    sess = samd_hip.Session(2048)
+    ids = torch.tensor([np.random.default_rng(N + 1).integers(3, cfg["vocab_size"], N).tolist()], device="cuda")
+    res = {}
+    for mode in ("own", "sdpa"):
+        monkeypatch.setenv("SAMD_PREFILL_ATTENTION", mode)
+        runner.kv.fill_(float("nan"))
+        sess.reset()
+        res[mode] = (runner.prefill(sess, ids).float().clone(), runner.kv[:, :, :, :N].float().clone())
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        want = lm(input_ids=ids, logits_to_keep=1).logits[0, -1].float()
+    e_own, e_sdpa = (res["own"][0] - want).abs().max().item(), (res["sdpa"][0] - want).abs().max().item()
+    print(f"N={N}: |d logit| vs fp32 HF own attention {e_own:.4f}, SDPA {e_sdpa:.4f} of {want.abs().max().item():.2f}")
+    assert torch.isfinite(res["own"][0]).all() and torch.isfinite(res["own"][1]).all()
+    assert e_own < max(1.5 * e_sdpa, 0.02 * max(1.0, want.abs().max().item()))
+    assert (res["own"][1] - res["sdpa"][1]).abs().max().item() < 0.01 * max(1.0, res["sdpa"][1].abs().max().item())
