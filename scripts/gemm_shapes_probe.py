@@ -9,7 +9,8 @@ import torch
 if os.environ.get("SAMD_PROBE_TUNABLE"):
     import torch.cuda.tunable as tun
     tun.enable(True); tun.tuning_enable(True); tun.set_filename(os.environ["SAMD_PROBE_TUNABLE"])
-    tun.set_max_tuning_duration(20); tun.set_max_tuning_iterations(20)
+    if not os.environ.get("SAMD_PROBE_TUNABLE_ENV"):                  # (else: duration / iterations / rotating buffer from the PYTORCH_TUNABLEOP_* variables)
+        tun.set_max_tuning_duration(20); tun.set_max_tuning_iterations(20)
 rows = [int(x) for x in sys.argv[1:]] or [512, 1024, 1280, 1536, 2048]
 H, I = 4096, 11008
 shapes = {"qkv": (3 * H, H), "o": (H, H), "gate|up": (2 * I, H), "down": (H, I)}
