@@ -437,10 +437,20 @@ int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d
         if (dev >= 0 && dev < 64) configured[di][dev] = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((rows + QB - 1) / QB, n_heads), block(256);
+    const int n_blocks = (rows + QB - 1) / QB;
+    static int cu_cache[64];                                               // compute units of the device, looked up once
+    int cus = (dev >= 0 && dev < 64) ? cu_cache[dev] : 0;
+    if (cus <= 0) {
+        cus = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        if (dev >= 0 && dev < 64) cu_cache[dev] = cus;
+    }
+    const int pair = n_blocks * n_heads > cus ? 1 : 0;                    // a heavy + a light row block per workgroup once the blocks outnumber the CUs
+    const dim3 grid(pair ? (n_blocks + 1) / 2 : n_blocks, n_heads), block(256);
     const float scale_log2 = scale * 1.4426950408889634f;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL((k_prefill_attention<prefillattn::F16, 4, 2>), grid, block, LDS_BYTES, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache, (const _Float16 *)d_v_cache, (_Float16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2);
-    else hipLaunchKernelGGL((k_prefill_attention<prefillattn::BF16, 4, 2>), grid, block, LDS_BYTES, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache, (const __bf16 *)d_v_cache, (__bf16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL((k_prefill_attention<prefillattn::F16, 4, 2>), grid, block, LDS_BYTES, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache, (const _Float16 *)d_v_cache, (_Float16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
+    else hipLaunchKernelGGL((k_prefill_attention<prefillattn::BF16, 4, 2>), grid, block, LDS_BYTES, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache, (const __bf16 *)d_v_cache, (__bf16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
     LAUNCHCHK();
     return SAMD_OK;
 }

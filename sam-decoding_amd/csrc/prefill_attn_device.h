@@ -14,7 +14,7 @@
 // V tile: transposed on its way into LDS, key pairs packed per dword (Vt[d][key], row stride 72 halfs).  Both staged through registers one tile
 // ahead, two LDS buffers, one bare barrier per tile (LDS-only wait: the next tile's global loads stay in flight across it).  Rows of K / V at or
 // beyond `total` are masked / zeroed; query rows beyond `rows` are computed on zeros and never stored.
-// Measured (scripts/probes/prefill_attn_probe.hip, profiles/r05_prefill_attn.md; 32 heads): 21.9 / 40.8 / 70.2 us at 512 / 1024 / 1536 rows against
+// Measured (scripts/probes/prefill_attn_probe.hip, profiles/r05_prefill_attn.md; 32 heads): 22.7 / 41.9 / 65.3 us at 512 / 1024 / 1536 rows against
 // 33 / 52-55 / 103-107 for PyTorch's fused SDPA (which also runs 40-80 % slower on row counts that are not multiples of 128; this kernel does not
 // care).  The loop is bound by instruction issue (~630 instructions per tile and wave for 64 MFMAs), not by load latency: a second register
 // stage (two tiles of prefetch distance) and an 8-wave form with one fragment per wave were both measured slower.
@@ -74,7 +74,8 @@ constexpr int VT_STRIDE = KT + 8;  // halfs per V^T row: 144 B keeps 8-byte alig
 constexpr int K_BYTES = KT * D * 2, VT_BYTES = D * VT_STRIDE * 2;
 constexpr int LDS_BYTES = 2 * (K_BYTES + VT_BYTES);
 
-// grid = (ceil(rows / 128), n_heads); blockIdx.x = 0 is the LAST (heaviest) row block.  Query row i sits at position pos0 + i and attends keys
+// grid = (pair ? ceil(n_blocks / 2) : n_blocks, n_heads) with n_blocks = ceil(rows / 128): with `pair` a workgroup takes a heavy and a light
+// row block (see the loop) -- worth it once there are more row blocks x heads than CUs (> 1024 rows at 32 heads); below that, more workgroups win.  Query row i sits at position pos0 + i and attends keys
 // 0 .. pos0 + i; keys live in k_cache / v_cache [n_kv_heads][max_len][128]; `total` = pos0 + rows keys exist.
 // NW waves x NF query fragments of 16 rows each = 128 query rows per workgroup: (4, 2) = fewer LDS reads per MFMA, (8, 1) = half the work per
 // wave and tile, i.e. a shorter chain for the long row blocks (which bound the launch) and four waves per SIMD to hide it behind
@@ -87,34 +88,19 @@ template <typename TT, int NW, int NF>
 #endif
 __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_prefill_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
                                                               const typename TT::elem *__restrict__ vc, typename TT::elem *__restrict__ out,
-                                                              int rows, int pos0, int n_heads, int n_kv_heads, long long max_len, float scale_log2) {
+                                                              int rows, int pos0, int n_heads, int n_kv_heads, long long max_len, float scale_log2, int pair) {
     typedef typename TT::elem E;
     typedef typename TT::vec8 V8;
     typedef typename TT::vec4 V4;
     extern __shared__ __attribute__((aligned(16))) char pa_lds[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, g = l >> 4;
-    const int n_blocks = gridDim.x, qb = n_blocks - 1 - (int)blockIdx.x, h = blockIdx.y;
+    const int h = blockIdx.y;
     const int kvh = h / (n_heads / n_kv_heads);
     const E *kbase = kc + (size_t)kvh * max_len * D, *vbase = vc + (size_t)kvh * max_len * D;
     const int total = pos0 + rows;
     static_assert(NW * NF * 16 == QB, "128 query rows per workgroup");
     constexpr int NT = 64 * NW, KC = 1024 / NT, VC = 512 / NT;          // threads; K units and V items per thread
-    const int q0 = qb * QB + 16 * NF * w;                                   // this wave's first query row
-    int last_key = pos0 + qb * QB + QB - 1; last_key = last_key < total - 1 ? last_key : total - 1;
-    const int ntiles = last_key / KT + 1;
 
-    // Q as the B operand: lane (q = lr, g) holds d = 8 g + 32 kk .. + 7
-    V8 qf[NF][4];
-#pragma unroll
-    for (int f = 0; f < NF; f++) {
-        const int row = q0 + 16 * f + lr;
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            uint4 raw = make_uint4(0, 0, 0, 0);
-            if (row < rows) raw = *reinterpret_cast<const uint4 *>(q + ((size_t)row * n_heads + h) * D + 8 * g + 32 * kk);
-            qf[f][kk] = __builtin_bit_cast(V8, raw);
-        }
-    }
     // staging registers: K tile = 1024 16-byte units, KC per thread (unit u = tid + NT c: key row u >> 4, slot u & 15); V tile: a thread's item =
     // key pair p x one 8-wide d chunk, VC items.
     // (named scalars, unconditional loads: as arrays, or requested under a condition, the compiler keeps the staging registers in scratch memory)
@@ -160,6 +146,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_pref
         if (VC == 2) v_put(1, st_va1, st_vb1);
     };
 
+    // Causal work grows with the row block: block b walks 2 (b + 1) key tiles.  A workgroup therefore takes TWO blocks, n_blocks - 1 - x and then x
+    // (x = blockIdx.x < n_blocks / 2; the middle block of an odd count alone): every workgroup walks the same n_blocks + 1 tiles, where one block
+    // per workgroup left the launch waiting for the last block's 2 n_blocks tiles (70 -> 65 us per layer at 1536 rows, 113 -> 86 at 2048;
+    // slower below ~1100 rows, where it halves a workgroup count that is already under the CU count: the host decides).
+    const int n_blocks = (rows + QB - 1) / QB;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+    const int qb = pass == 0 ? n_blocks - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    if (pass == 1 && (!pair || qb >= n_blocks - 1 - (int)blockIdx.x)) break;
+    const int q0 = qb * QB + 16 * NF * w;                                   // this wave's first query row
+    int last_key = pos0 + qb * QB + QB - 1; last_key = last_key < total - 1 ? last_key : total - 1;
+    const int ntiles = last_key / KT + 1;
+    // Q as the B operand: lane (q = lr, g) holds d = 8 g + 32 kk .. + 7
+    V8 qf[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        const int row = q0 + 16 * f + lr;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (row < rows) raw = *reinterpret_cast<const uint4 *>(q + ((size_t)row * n_heads + h) * D + 8 * g + 32 * kk);
+            qf[f][kk] = __builtin_bit_cast(V8, raw);
+        }
+    }
     float m_run[NF], l_run[NF];
     floatx4 o[NF][8];
 #pragma unroll
@@ -299,6 +309,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_pref
             V4 v = {(E)(o[f][df][0] * inv), (E)(o[f][df][1] * inv), (E)(o[f][df][2] * inv), (E)(o[f][df][3] * inv)};
             *reinterpret_cast<V4 *>(dst + 16 * df) = v;
         }
+    }
+    __syncthreads();                                                        // the next block's first tile goes into LDS buffer 0
     }
 }
 

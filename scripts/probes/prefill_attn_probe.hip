@@ -58,10 +58,11 @@ int main(int argc, char **argv) {
     const float scale = 1.0f / sqrtf(128.f);
     CHK(hipFuncSetAttribute((const void *)k_prefill_attention<F16, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     CHK(hipFuncSetAttribute((const void *)k_prefill_attention<F16, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    const dim3 grid((rows + QB - 1) / QB, H);
+    const int n_blocks = (rows + QB - 1) / QB, pair = getenv("PA_PAIR") ? atoi(getenv("PA_PAIR")) : (n_blocks * H > 256);
+    const dim3 grid(pair ? (n_blocks + 1) / 2 : n_blocks, H);
     auto launch = [&]() {
-        if (waves == 4) hipLaunchKernelGGL((k_prefill_attention<F16, 4, 2>), grid, dim3(256), LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f);
-        else hipLaunchKernelGGL((k_prefill_attention<F16, 8, 1>), grid, dim3(512), LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f);
+        if (waves == 4) hipLaunchKernelGGL((k_prefill_attention<F16, 4, 2>), grid, dim3(256), LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f, pair);
+        else hipLaunchKernelGGL((k_prefill_attention<F16, 8, 1>), grid, dim3(512), LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f, pair);
     };
     launch(); CHK(hipDeviceSynchronize());
     hipLaunchKernelGGL(k_ref, dim3(rows, H), dim3(128), 0, 0, q, kc, vc, ref, rows, pos0, H, Hkv, max_len, scale);
