@@ -431,8 +431,8 @@ int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d
     (void)hipGetDevice(&dev);
     const int di = dtype == SAMD_F16 ? 0 : 1;
     if (dev < 0 || dev >= 64 || !configured[di][dev]) {
-        const hipError_t e = dtype == SAMD_F16 ? hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::F16, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)
-                                               : hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::BF16, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        const hipError_t e = dtype == SAMD_F16 ? hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::F16, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BYTES)
+                                               : hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::BF16, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BYTES);
         if (e != hipSuccess) { samd_set_error("samd_prefill_attention: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
         if (dev >= 0 && dev < 64) configured[di][dev] = true;
     }
@@ -447,10 +447,10 @@ int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d
         if (dev >= 0 && dev < 64) cu_cache[dev] = cus;
     }
     const int pair = n_blocks * n_heads > cus ? 1 : 0;                    // a heavy + a light row block per workgroup once the blocks outnumber the CUs
-    const dim3 grid(pair ? (n_blocks + 1) / 2 : n_blocks, n_heads), block(256);
+    const dim3 grid(pair ? (n_blocks + 1) / 2 : n_blocks, n_heads), block(512);                    // two key groups of 4 waves
     const float scale_log2 = scale * 1.4426950408889634f;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL((k_prefill_attention<prefillattn::F16, 4, 2>), grid, block, LDS_BYTES, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache, (const _Float16 *)d_v_cache, (_Float16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
-    else hipLaunchKernelGGL((k_prefill_attention<prefillattn::BF16, 4, 2>), grid, block, LDS_BYTES, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache, (const __bf16 *)d_v_cache, (__bf16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL((k_prefill_attention<prefillattn::F16, 4, 2, 2>), grid, block, 2 * LDS_BYTES, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache, (const _Float16 *)d_v_cache, (_Float16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
+    else hipLaunchKernelGGL((k_prefill_attention<prefillattn::BF16, 4, 2, 2>), grid, block, 2 * LDS_BYTES, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache, (const __bf16 *)d_v_cache, (__bf16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
     LAUNCHCHK();
     return SAMD_OK;
 }

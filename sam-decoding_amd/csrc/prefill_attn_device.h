@@ -14,7 +14,7 @@
 // V tile: transposed on its way into LDS, key pairs packed per dword (Vt[d][key], row stride 72 halfs).  Both staged through registers one tile
 // ahead, two LDS buffers, one bare barrier per tile (LDS-only wait: the next tile's global loads stay in flight across it).  Rows of K / V at or
 // beyond `total` are masked / zeroed; query rows beyond `rows` are computed on zeros and never stored.
-// Measured (scripts/probes/prefill_attn_probe.hip, profiles/r05_prefill_attn.md; 32 heads): 22.7 / 41.9 / 65.3 us at 512 / 1024 / 1536 rows against
+// Measured (scripts/probes/prefill_attn_probe.hip, profiles/r05_prefill_attn.md; 32 heads, two key groups): 20.8 / 37.7 / 58.0 us at 512 / 1024 / 1536 rows against
 // 33 / 52-55 / 103-107 for PyTorch's fused SDPA (which also runs 40-80 % slower on row counts that are not multiples of 128; this kernel does not
 // care).  The loop is bound by instruction issue (~630 instructions per tile and wave for 64 MFMAs), not by load latency: a second register
 // stage (two tiles of prefetch distance) and an 8-wave form with one fragment per wave were both measured slower.
@@ -72,34 +72,39 @@ constexpr int KT = 64;             // keys per tile
 constexpr int D = 128;             // head_dim
 constexpr int VT_STRIDE = KT + 8;  // halfs per V^T row: 144 B keeps 8-byte alignment and spreads the banks
 constexpr int K_BYTES = KT * D * 2, VT_BYTES = D * VT_STRIDE * 2;
-constexpr int LDS_BYTES = 2 * (K_BYTES + VT_BYTES);
+constexpr int LDS_BYTES = 2 * (K_BYTES + VT_BYTES);       // per key group
 
 // grid = (pair ? ceil(n_blocks / 2) : n_blocks, n_heads) with n_blocks = ceil(rows / 128): with `pair` a workgroup takes a heavy and a light
 // row block (see the loop) -- worth it once there are more row blocks x heads than CUs (> 1024 rows at 32 heads); below that, more workgroups win.  Query row i sits at position pos0 + i and attends keys
 // 0 .. pos0 + i; keys live in k_cache / v_cache [n_kv_heads][max_len][128]; `total` = pos0 + rows keys exist.
+// NG = 2 (round 5, last): TWO groups of NW waves work on the same 128 query rows, group i on the key tiles i, i + 2, ... with its own LDS
+// buffers and accumulators; at the end group 1 hands (m, l, O) to group 0 through LDS.  The chain of a row block -- what bounds the launch --
+// is half as long, for one in-workgroup merge (no global partials, no second launch).  8 waves, 136 KiB of LDS: one workgroup per CU.
 // NW waves x NF query fragments of 16 rows each = 128 query rows per workgroup: (4, 2) = fewer LDS reads per MFMA, (8, 1) = half the work per
 // wave and tile, i.e. a shorter chain for the long row blocks (which bound the launch) and four waves per SIMD to hide it behind
-template <typename TT, int NW, int NF>
+template <typename TT, int NW, int NF, int NG = 1>
 #ifndef PA_MINW8
 #define PA_MINW8 4
 #endif
 #ifndef PA_MINW4
 #define PA_MINW4 2
 #endif
-__global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_prefill_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
+__global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : PA_MINW8)) void k_prefill_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
                                                               const typename TT::elem *__restrict__ vc, typename TT::elem *__restrict__ out,
                                                               int rows, int pos0, int n_heads, int n_kv_heads, long long max_len, float scale_log2, int pair) {
     typedef typename TT::elem E;
     typedef typename TT::vec8 V8;
     typedef typename TT::vec4 V4;
     extern __shared__ __attribute__((aligned(16))) char pa_lds[];
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, g = l >> 4;
+    constexpr int NT = 64 * NW, KC = 1024 / NT, VC = 512 / NT;          // threads of a group; K units and V items per thread
+    const int gi = NG == 1 ? 0 : (int)threadIdx.x / NT;                  // key group of this wave
+    const int tid = (int)threadIdx.x - gi * NT, w = tid >> 6, l = tid & 63, lr = l & 15, g = l >> 4;
+    char *grp_lds = pa_lds + gi * 2 * (K_BYTES + VT_BYTES);
     const int h = blockIdx.y;
     const int kvh = h / (n_heads / n_kv_heads);
     const E *kbase = kc + (size_t)kvh * max_len * D, *vbase = vc + (size_t)kvh * max_len * D;
     const int total = pos0 + rows;
     static_assert(NW * NF * 16 == QB, "128 query rows per workgroup");
-    constexpr int NT = 64 * NW, KC = 1024 / NT, VC = 512 / NT;          // threads; K units and V items per thread
 
     // staging registers: K tile = 1024 16-byte units, KC per thread (unit u = tid + NT c: key row u >> 4, slot u & 15); V tile: a thread's item =
     // key pair p x one 8-wide d chunk, VC items.
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_pref
         if (VC == 2) { st_va1 = *reinterpret_cast<const uint4 *>(vtb + v_off[VC - 1]); st_vb1 = *reinterpret_cast<const uint4 *>(vtb + v_off[VC - 1] + 256); }
     };
     auto store_stage = [&](int key0, int buf) {
-        char *kb_ = pa_lds + buf * (K_BYTES + VT_BYTES);
+        char *kb_ = grp_lds + buf * (K_BYTES + VT_BYTES);
         E *vt = reinterpret_cast<E *>(kb_ + K_BYTES);
         auto k_dst = [&](int c) -> uint4 * {
             const int u = tid + NT * c, r = u >> 4, sl = u & 15;
@@ -182,16 +187,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_pref
     // tile 0 into LDS, tile 1 into the staging registers.  Iteration t: the registers (tile t + 1, requested a whole iteration ago) go to the other
     // LDS buffer, tile t + 2 is requested into them, tile t is computed, barrier.  (A second register set = two tiles of distance was measured
     // and is slower: the loop is bound by instruction issue -- ~630 instructions per tile and wave for 64 MFMAs -- not by load latency.)
-    load_stage(0);
-    store_stage(0, 0);
-    load_stage(KT);
+    load_stage(gi * KT);
+    store_stage(gi * KT, 0);
+    load_stage((gi + NG) * KT);
     __syncthreads();
     const int first_q_pos = pos0 + qb * QB;
-    for (int t = 0; t < ntiles; t++) {
-        const int buf = t & 1, key0 = t * KT;
-        if (t + 1 < ntiles) store_stage(key0 + KT, buf ^ 1);        // every wave is past the barrier that ended its reads of that buffer
-        load_stage(key0 + 2 * KT);
-        const char *kb_ = pa_lds + buf * (K_BYTES + VT_BYTES);
+    for (int j = 0; j * NG < ntiles; j++) {
+        const int t = NG * j + gi, buf = j & 1, key0 = t * KT;          // this group's tile of the iteration (NG == 2: the last one may not exist)
+        if (t + NG < ntiles) store_stage(key0 + NG * KT, buf ^ 1);      // every wave is past the barrier that ended its reads of that buffer
+        load_stage(key0 + 2 * NG * KT);
+        if (t < ntiles) {
+        const char *kb_ = grp_lds + buf * (K_BYTES + VT_BYTES);
         const E *vt = reinterpret_cast<const E *>(kb_ + K_BYTES);
         // ---- S^T = K Q^T: 4 key fragments x 2 query fragments
         floatx4 s[4][NF];
@@ -242,7 +248,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_pref
                 for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[kf][f][r]);
             mx = row4_max(mx);
             const float m_new = fmaxf(m_run[f], mx * scale_log2);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_new);
+            // (a row that has seen nothing but masked keys so far -- the second key group's first tiles -- keeps m = -inf: exponentials against 0)
+            const float m_use = (NG > 1 && m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);
             m_run[f] = m_new;
             float sum = 0.f;
             E pv[4][4];
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_pref
             for (int kf = 0; kf < 4; kf++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float p = __builtin_amdgcn_exp2f(s[kf][f][r] * scale_log2 - m_new);
+                    const float p = __builtin_amdgcn_exp2f(s[kf][f][r] * scale_log2 - m_use);
                     pv[kf][r] = (E)p;
                     sum += p;
                 }
@@ -291,17 +299,46 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? PA_MINW4 : PA_MINW8) void k_pref
                 PA_SGB(0x100, 1, 0);
             }
         }
+        }
         // bare s_barrier behind an LDS-only wait: the global loads just requested for the tile after next stay in flight across it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    }
+    if constexpr (NG == 2) {
+        // group 1 -> group 0 through group 1's (now idle) LDS buffers: per wave [68 values][64 lanes] fp32, value index major (conflict-free)
+        float *xch = reinterpret_cast<float *>(pa_lds + 2 * (K_BYTES + VT_BYTES)) + (size_t)w * (NF * 34) * 64 + l;
+        if (gi == 1) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                xch[(f * 34 + 0) * 64] = m_run[f]; xch[(f * 34 + 1) * 64] = l_run[f];
+#pragma unroll
+                for (int df = 0; df < 8; df++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) xch[(f * 34 + 2 + 4 * df + r) * 64] = o[f][df][r];
+            }
+        }
+        __syncthreads();
+        if (gi == 0) {
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                const float m1 = xch[(f * 34 + 0) * 64], l1 = xch[(f * 34 + 1) * 64];
+                const float m = fmaxf(m_run[f], m1);
+                const float a0 = __builtin_amdgcn_exp2f(m_run[f] - m), a1 = m1 == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m1 - m);
+                l_run[f] = l_run[f] * a0 + l1 * a1;
+#pragma unroll
+                for (int df = 0; df < 8; df++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[f][df][r] = o[f][df][r] * a0 + xch[(f * 34 + 2 + 4 * df + r) * 64] * a1;
+            }
+        }
     }
     // ---- normalise and store: lane (q = lr, g) holds d = 16 df + 4 g + r of its row
 #pragma unroll
     for (int f = 0; f < NF; f++) {
         const float lsum = row4_sum(l_run[f]);
         const int row = q0 + 16 * f + lr;
-        if (row >= rows) continue;
+        if (row >= rows || gi != 0) continue;
         const float inv = 1.f / lsum;
         E *dst = out + ((size_t)row * n_heads + h) * D + 4 * g;
 #pragma unroll

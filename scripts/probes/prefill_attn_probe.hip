@@ -1,6 +1,6 @@
 // prefill_attn_probe.hip -- harness of csrc/prefill_attn_device.h outside the library: random q / K / V in the runner's layouts, the kernel's output
 // against a plain fp32 causal softmax-attention on the GPU (every row, every head), and its launch time.
-// usage: prefill_attn_probe <rows> [heads 32] [kv_heads 32] [pos0 0] [iters 20] [max_len 2048] [waves 4|8]
+// usage: prefill_attn_probe <rows> [heads 32] [kv_heads 32] [pos0 0] [iters 20] [max_len 2048] [form: 4 = 4 waves x 2 fragments, 8 = 8 waves x 1, 42 = two key groups of 4 x 2]
 #include "../../sam-decoding_amd/csrc/prefill_attn_device.h"
 #include <cstdio>
 #include <cstdlib>
@@ -58,10 +58,12 @@ int main(int argc, char **argv) {
     const float scale = 1.0f / sqrtf(128.f);
     CHK(hipFuncSetAttribute((const void *)k_prefill_attention<F16, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     CHK(hipFuncSetAttribute((const void *)k_prefill_attention<F16, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    CHK(hipFuncSetAttribute((const void *)(k_prefill_attention<F16, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BYTES));
     const int n_blocks = (rows + QB - 1) / QB, pair = getenv("PA_PAIR") ? atoi(getenv("PA_PAIR")) : (n_blocks * H > 256);
     const dim3 grid(pair ? (n_blocks + 1) / 2 : n_blocks, H);
     auto launch = [&]() {
-        if (waves == 4) hipLaunchKernelGGL((k_prefill_attention<F16, 4, 2>), grid, dim3(256), LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f, pair);
+        if (waves == 42) hipLaunchKernelGGL((k_prefill_attention<F16, 4, 2, 2>), grid, dim3(512), 2 * LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f, pair);
+        else if (waves == 4) hipLaunchKernelGGL((k_prefill_attention<F16, 4, 2>), grid, dim3(256), LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f, pair);
         else hipLaunchKernelGGL((k_prefill_attention<F16, 8, 1>), grid, dim3(512), LDS_BYTES, 0, q, kc, vc, out, rows, pos0, H, Hkv, max_len, scale * 1.4426950408889634f, pair);
     };
     launch(); CHK(hipDeviceSynchronize());
