@@ -143,8 +143,8 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
             const unsigned int wa[4] = {ra.x, ra.y, ra.z, ra.w}, wb[4] = {rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const unsigned int ea = (j & 1) ? wa[j >> 1] >> 16 : wa[j >> 1] & 0xffffu, eb = (j & 1) ? wb[j >> 1] & 0xffff0000u : wb[j >> 1] << 16;
-                *reinterpret_cast<unsigned int *>(&vt[(d0 + j) * VT_STRIDE + 2 * p]) = ea | eb;
+                // {key 2p's element j, key 2p + 1's element j} in one v_perm_b32 (bytes 0-3 = wa, 4-7 = wb)
+                *reinterpret_cast<unsigned int *>(&vt[(d0 + j) * VT_STRIDE + 2 * p]) = __builtin_amdgcn_perm(wb[j >> 1], wa[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
             }
         };
         v_put(0, st_va0, st_vb0);
@@ -252,16 +252,22 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
             const float m_use = (NG > 1 && m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run[f] - m_use);
             m_run[f] = m_new;
-            float sum = 0.f;
+            // two scores per instruction where the ISA has a packed fp32 form (v_pk_fma_f32, v_pk_add_f32): the loop is bound by instruction issue
+            typedef float float2v __attribute__((ext_vector_type(2)));
+            float2v sum2 = {0.f, 0.f};
+            const float2v sc2 = {scale_log2, scale_log2}, nm2 = {-m_use, -m_use};
             E pv[4][4];
 #pragma unroll
             for (int kf = 0; kf < 4; kf++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float p = __builtin_amdgcn_exp2f(s[kf][f][r] * scale_log2 - m_use);
-                    pv[kf][r] = (E)p;
-                    sum += p;
+                for (int r = 0; r < 4; r += 2) {
+                    float2v x = {s[kf][f][r], s[kf][f][r + 1]};
+                    x = __builtin_elementwise_fma(x, sc2, nm2);
+                    const float2v p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    sum2 += p;
+                    pv[kf][r] = (E)p[0]; pv[kf][r + 1] = (E)p[1];
                 }
+            const float sum = sum2[0] + sum2[1];
             l_run[f] = l_run[f] * alpha + sum;
             if (__any(alpha != 1.f)) {                           // wave-uniform: once the running maxima have settled the 32 multiplies go
 #pragma unroll
