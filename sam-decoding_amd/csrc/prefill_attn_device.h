@@ -136,6 +136,9 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
         if (KC == 4) { *k_dst(2) = st_k2; *k_dst(3) = st_k3; }
         auto v_put = [&](int it, uint4 ra, uint4 rb) {
             const int item = tid + NT * it, p = (item >> 3) & 31, d0 = 8 * ((item & 7) + 8 * (item >> 8));
+            // the key-pair column is XORed with 4 x (d chunk & 7): a wave's 64 dword stores (8 pairs x 8 chunks, rows 144 B apart = the same
+            // bank for every chunk) then fall on 32 different banks instead of 8 -- 2-way instead of 8-way conflicts; readers undo it
+            const int vx = (item & 7) << 2;
             const int ka = key0 + 2 * p, kb = ka + 1;
             // rows at or beyond `total` are zero: their P is 0, but 0 x garbage could be NaN
             if (ka >= total) ra = make_uint4(0, 0, 0, 0);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 // {key 2p's element j, key 2p + 1's element j} in one v_perm_b32 (bytes 0-3 = wa, 4-7 = wb)
-                *reinterpret_cast<unsigned int *>(&vt[(d0 + j) * VT_STRIDE + 2 * p]) = __builtin_amdgcn_perm(wb[j >> 1], wa[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
+                *reinterpret_cast<unsigned int *>(&vt[(d0 + j) * VT_STRIDE + 2 * (p ^ vx)]) = __builtin_amdgcn_perm(wb[j >> 1], wa[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
             }
         };
         v_put(0, st_va0, st_vb0);
@@ -285,8 +288,9 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
         {
             auto rd = [&](int i) -> V8 {
                 const int df = i >> 1, ks = i & 1;
-                const E *row = vt + (16 * df + lr) * VT_STRIDE + 4 * g + 32 * ks;
-                const V4 lo = *reinterpret_cast<const V4 *>(row), hi = *reinterpret_cast<const V4 *>(row + 16);
+                const int vx = ((2 * df + (lr >> 3)) & 7) << 2;                     // the writer's column swizzle (in key pairs)
+                const E *row = vt + (16 * df + lr) * VT_STRIDE;
+                const V4 lo = *reinterpret_cast<const V4 *>(row + 2 * ((16 * ks + 2 * g) ^ vx)), hi = *reinterpret_cast<const V4 *>(row + 2 * ((16 * ks + 8 + 2 * g) ^ vx));
                 V8 a;
 #pragma unroll
                 for (int r = 0; r < 4; r++) { a[r] = lo[r]; a[4 + r] = hi[r]; }
