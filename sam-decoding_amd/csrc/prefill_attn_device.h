@@ -62,6 +62,9 @@ __device__ __forceinline__ float row4_sum(float x) {
     return c + d;
 }
 
+#ifndef PA_ABL
+#define PA_ABL 0        // diagnostic builds of scripts/probes/prefill_attn_probe.hip only (results wrong, timing only): bit 0 no exponentials, bit 1 one V^T
+#endif                  // fragment read per tile instead of 16, bit 2 one K fragment read instead of 16, bit 3 no staging after the prologue
 #ifdef PA_NO_SGB
 #define PA_SGB(a, b, c) ((void)0)
 #else
@@ -197,8 +200,8 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
     const int first_q_pos = pos0 + qb * QB;
     for (int j = 0; j * NG < ntiles; j++) {
         const int t = NG * j + gi, buf = j & 1, key0 = t * KT;          // this group's tile of the iteration (NG == 2: the last one may not exist)
-        if (t + NG < ntiles) store_stage(key0 + NG * KT, buf ^ 1);      // every wave is past the barrier that ended its reads of that buffer
-        load_stage(key0 + 2 * NG * KT);
+        if (t + NG < ntiles && !(PA_ABL & 8)) store_stage(key0 + NG * KT, buf ^ 1);      // every wave is past the barrier that ended its reads of that buffer
+        if (!(PA_ABL & 8)) load_stage(key0 + 2 * NG * KT);
         if (t < ntiles) {
         const char *kb_ = grp_lds + buf * (K_BYTES + VT_BYTES);
         const E *vt = reinterpret_cast<const E *>(kb_ + K_BYTES);
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
             for (int i = 0; i < 16; i++) {
                 const int kf = i >> 2, kk = i & 3;
                 const V8 a = ring[i & 3];
-                if (i + 4 < 16) ring[i & 3] = rd(i + 4);
+                if (i + 4 < 16 && !(PA_ABL & 4)) ring[i & 3] = rd(i + 4);
 #pragma unroll
                 for (int f = 0; f < NF; f++) {
                     if (kk == 0) s[kf][f] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
                 for (int r = 0; r < 4; r += 2) {
                     float2v x = {s[kf][f][r], s[kf][f][r + 1]};
                     x = __builtin_elementwise_fma(x, sc2, nm2);
-                    const float2v p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    const float2v p = (PA_ABL & 1) ? x : (float2v){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
                     sum2 += p;
                     pv[kf][r] = (E)p[0]; pv[kf][r + 1] = (E)p[1];
                 }
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
             for (int i = 0; i < 16; i++) {
                 const int df = i >> 1, ks = i & 1;
                 const V8 a = ring[i & 3];
-                if (i + 4 < 16) ring[i & 3] = rd(i + 4);
+                if (i + 4 < 16 && !(PA_ABL & 2)) ring[i & 3] = rd(i + 4);
 #pragma unroll
                 for (int f = 0; f < NF; f++) o[f][df] = TT::mfma(a, pb[f][ks], o[f][df]);
                 PA_SGB(0x008, NF, 0);
