@@ -36,8 +36,9 @@ if [ ! -f "$ORA" ] || [ "$ROOT/oracle/sam_oracle.c" -nt "$ORA" ]; then
 fi
 RT="$("$CLANG" -print-file-name=libclang_rt.asan-x86_64.so)"
 [ -f "$RT" ] || { echo "[asan] sanitizer runtime not found: $RT" >&2; exit 3; }
-nm -D "$LIB" | grep -q __asan_init || { echo "[asan] $LIB is not instrumented" >&2; exit 3; }
-nm -D "$ORA" | grep -q __asan_init || { echo "[asan] $ORA is not instrumented" >&2; exit 3; }
+# (through a file, not `nm | grep -q`: with pipefail, grep leaving at its first match kills nm with SIGPIPE and the check fails at random)
+nm -D "$LIB" > "$OUT/libsamd_hip.syms"; grep -q __asan_init "$OUT/libsamd_hip.syms" || { echo "[asan] $LIB is not instrumented" >&2; exit 3; }
+nm -D "$ORA" > "$OUT/libsam_oracle.syms"; grep -q __asan_init "$OUT/libsam_oracle.syms" || { echo "[asan] $ORA is not instrumented" >&2; exit 3; }
 cd "$ROOT"
 # detect_leaks=0: the interpreter itself leaks by design at exit; everything else (heap / stack / global overflows, use after free,
 # UB such as signed overflow, misaligned or null access, out-of-range shifts) aborts the run with a report
