@@ -121,7 +121,8 @@ def test_tune_prefill_failure_leaves_single_calls(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
-@pytest.mark.parametrize("rows,H,Hkv,pos0", [(200, 32, 32, 0), (1333, 32, 8, 0), (128, 8, 8, 0), (1, 4, 2, 37), (700, 16, 16, 300), (129, 8, 1, 1900), (2048, 4, 4, 0)])
+@pytest.mark.parametrize("rows,H,Hkv,pos0", [(200, 32, 32, 0), (1333, 32, 8, 0), (128, 8, 8, 0), (1, 4, 2, 37), (700, 16, 16, 300), (129, 8, 1, 1900), (2048, 4, 4, 0),
+                                            (96, 8, 8, 1952), (1536, 32, 32, 0), (63, 2, 1, 0), (65, 2, 2, 63)])
 def test_prefill_attention_against_fp32_softmax_attention(dtype, tol, rows, H, Hkv, pos0):
     """samd_prefill_attention (csrc/prefill_attn_device.h) against a plain fp32 causal attention in torch: every row, every head; the cache
     behind the prompt is NaN (it must not be read into a result), as is `out` before the launch (every row < rows must be written)."""
@@ -148,6 +149,34 @@ def test_prefill_attention_against_fp32_softmax_attention(dtype, tol, rows, H, H
     assert torch.isfinite(got).all()
     err = (got - want).abs().max().item()
     assert err < tol * max(1.0, want.abs().max().item()), err
+
+
+def test_prefill_attention_long_context_with_paired_row_blocks():
+    """4096 prompt rows of a Llama-3 geometry (32 query / 8 KV heads, bf16, 8192-position cache): 32 row blocks x 32 heads > the CU count, so a
+    workgroup takes a heavy and a light block; every row and head against fp32 attention, computed head by head."""
+    lib, D, max_len, rows, H, Hkv = samd_hip.lib(), 128, 8192, 4096, 32, 8
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(4096)
+    q = torch.randn((rows, H, D), generator=g, device="cuda").to(dtype)
+    k = torch.randn((Hkv, max_len, D), generator=g, device="cuda").to(dtype)
+    v = torch.randn((Hkv, max_len, D), generator=g, device="cuda").to(dtype)
+    k[:, rows:] = float("nan")
+    v[:, rows:] = float("nan")
+    out = torch.full((rows, H * D), float("nan"), device="cuda").to(dtype)
+    scale = 1.0 / D ** 0.5
+    samd_hip.check(lib.samd_prefill_attention(samd_hip._ptr(q), samd_hip._ptr(k), samd_hip._ptr(v), samd_hip._ptr(out), samd_hip.torch_dtype_code(dtype),
+                                              rows, 0, H, Hkv, D, max_len, scale, samd_hip.current_stream()))
+    torch.cuda.synchronize()
+    got = out.float().view(rows, H, D)
+    assert torch.isfinite(got).all()
+    causal = torch.ones((rows, rows), dtype=torch.bool, device="cuda").tril()
+    worst = 0.0
+    for h in range(H):
+        kk, vv = k[h // (H // Hkv), :rows].float(), v[h // (H // Hkv), :rows].float()
+        s = (q[:, h].float() @ kk.t()) * scale
+        want = torch.softmax(s.masked_fill(~causal, float("-inf")), dim=-1) @ vv
+        worst = max(worst, (got[:, h] - want).abs().max().item())
+    assert worst < 1.6e-2, worst
 
 
 def test_prefill_attention_rejects_what_it_cannot_do():
