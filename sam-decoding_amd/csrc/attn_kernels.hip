@@ -261,21 +261,18 @@ __global__ __launch_bounds__(64 * AB_WAVES, 1) void k_attn_block(const typename 
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            float v = tmax[r];
-            v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-            v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+            const float v = row16_max(tmax[r]);          // DPP row reductions (samd_common.h): no ds_bpermute round trips in the tile loop
             const float m_new = fmaxf(m_run[r], v);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = exp2f(m_run[r] - m_use);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[r] - m_use);
             float psum = 0.f;
 #pragma unroll
             for (int st = 0; st < 4; st++) {
-                const float p = exp2f(s[st][r] - m_use);
+                const float p = __builtin_amdgcn_exp2f(s[st][r] - m_use);
                 psum += p;
                 Pmine[(4 * lg + r) * AB_PSTRIDE + 16 * st + lr] = (E)p;     // C layout -> A layout through this wave's own LDS rows
             }
-            psum += __shfl_xor(psum, 1); psum += __shfl_xor(psum, 2);
-            psum += __shfl_xor(psum, 4); psum += __shfl_xor(psum, 8);
+            psum = row16_sum(psum);
             l_run[r] = l_run[r] * alpha + psum;
             m_run[r] = m_new;
 #pragma unroll

@@ -28,18 +28,7 @@
 
 #define LAUNCHCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { samd_set_error("kernel launch: %s", hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
 
-// compute units of the CURRENT device, looked up once per device (a process may drive several GPUs)
-static int samd_cu_count() {
-    static int cached[64];
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess) return 256;
-    if (d >= 0 && d < 64 && cached[d] > 0) return cached[d];
-    int n = 256;
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
-    if (d >= 0 && d < 64) cached[d] = n;
-    return n;
-}
+static int samd_cu_count() { return samd_device_cus(); }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

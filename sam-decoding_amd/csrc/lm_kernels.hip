@@ -426,26 +426,16 @@ int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d
         (int64_t)pos0 + rows > max_len || (dtype != SAMD_F16 && dtype != SAMD_BF16) || !(scale > 0.f)) {
         samd_set_error("samd_prefill_attention: invalid argument (head_dim 128, pos0 + rows <= max_len, f16/bf16, scale > 0)"); return SAMD_E_INVALID;
     }
-    static bool configured[2][64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const int di = dtype == SAMD_F16 ? 0 : 1;
-    if (dev < 0 || dev >= 64 || !configured[di][dev]) {
-        const hipError_t e = dtype == SAMD_F16 ? hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::F16, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BYTES)
-                                               : hipFuncSetAttribute((const void *)k_prefill_attention<prefillattn::BF16, 4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BYTES);
+    // one-time, per-device setup through samd_reserve_lds / samd_device_cus (atomic bookkeeping: first calls from several host threads may race)
+    {
+        static unsigned long long done_f16 = 0ull, done_bf16 = 0ull;
+        const hipError_t e = dtype == SAMD_F16 ? samd_reserve_lds((const void *)k_prefill_attention<prefillattn::F16, 4, 2, 2>, 2 * LDS_BYTES, &done_f16)
+                                               : samd_reserve_lds((const void *)k_prefill_attention<prefillattn::BF16, 4, 2, 2>, 2 * LDS_BYTES, &done_bf16);
         if (e != hipSuccess) { samd_set_error("samd_prefill_attention: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
-        if (dev >= 0 && dev < 64) configured[di][dev] = true;
     }
     hipStream_t st = (hipStream_t)stream;
     const int n_blocks = (rows + QB - 1) / QB;
-    static int cu_cache[64];                                               // compute units of the device, looked up once
-    int cus = (dev >= 0 && dev < 64) ? cu_cache[dev] : 0;
-    if (cus <= 0) {
-        cus = 256;
-        hipDeviceProp_t pr;
-        if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
-        if (dev >= 0 && dev < 64) cu_cache[dev] = cus;
-    }
+    const int cus = samd_device_cus();
     const int pair = n_blocks * n_heads > cus ? 1 : 0;                    // a heavy + a light row block per workgroup once the blocks outnumber the CUs
     const dim3 grid(pair ? (n_blocks + 1) / 2 : n_blocks, n_heads), block(512);                    // two key groups of 4 waves
     const float scale_log2 = scale * 1.4426950408889634f;

@@ -114,19 +114,39 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
     // (named scalars, unconditional loads: as arrays, or requested under a condition, the compiler keeps the staging registers in scratch memory)
     uint4 st_k0, st_k1, st_k2, st_k3, st_va0, st_va1, st_vb0, st_vb1;
     // a tile's source addresses = wave-uniform tile base (scalar registers) + a per-lane byte offset fixed for the whole launch: no vector
-    // arithmetic per request.  The tile base is clamped so that the (never used) request past the last tile stays inside the cache.
+    // arithmetic per request (the cache's last, partial tile excepted: load_stage).
     uint32_t k_off[KC], v_off[VC];
 #pragma unroll
     for (int c = 0; c < KC; c++) { const int u = tid + NT * c; k_off[c] = (uint32_t)((u >> 4) * 256 + 16 * (u & 15)); }
 #pragma unroll
     for (int it = 0; it < VC; it++) { const int item = tid + NT * it; v_off[it] = (uint32_t)((2 * ((item >> 3) & 31)) * 256 + 16 * ((item & 7) + 8 * (item >> 8))); }
     auto load_stage = [&](int key0) {
-        long long kc0 = key0; kc0 = kc0 + KT <= max_len ? kc0 : max_len - KT; kc0 = kc0 < 0 ? 0 : kc0;
+        // A tile that lies inside the cache (every tile but the last one of a cache whose length is not a multiple of 64, and the never-used
+        // request past the last tile) takes the precomputed offsets.  The cache's LAST, partial tile clamps every ROW to max_len - 1 instead
+        // (round 6, ADVICE r05: clamping the tile BASE shifted the keys of a needed tile while store_stage / the causal mask still indexed them
+        // as key0 .., and read past a cache shorter than one tile): rows at or beyond `total` are masked (K) / zeroed (V) whatever they hold.
+        long long kc0 = key0 < max_len ? key0 : max_len - 1; kc0 = kc0 < 0 ? 0 : kc0;
         const char *kt = reinterpret_cast<const char *>(kbase) + kc0 * 256, *vtb = reinterpret_cast<const char *>(vbase) + kc0 * 256;
-        st_k0 = *reinterpret_cast<const uint4 *>(kt + k_off[0]); st_k1 = *reinterpret_cast<const uint4 *>(kt + k_off[1]);
-        if (KC == 4) { st_k2 = *reinterpret_cast<const uint4 *>(kt + k_off[2]); st_k3 = *reinterpret_cast<const uint4 *>(kt + k_off[3]); }
-        st_va0 = *reinterpret_cast<const uint4 *>(vtb + v_off[0]); st_vb0 = *reinterpret_cast<const uint4 *>(vtb + v_off[0] + 256);
-        if (VC == 2) { st_va1 = *reinterpret_cast<const uint4 *>(vtb + v_off[VC - 1]); st_vb1 = *reinterpret_cast<const uint4 *>(vtb + v_off[VC - 1] + 256); }
+        uint32_t ko[KC], va[VC], vb[VC];
+        if (kc0 + KT <= max_len) {                                  // wave-uniform
+#pragma unroll
+            for (int c = 0; c < KC; c++) ko[c] = k_off[c];
+#pragma unroll
+            for (int it = 0; it < VC; it++) { va[it] = v_off[it]; vb[it] = v_off[it] + 256; }
+        } else {
+            const uint32_t lim = (uint32_t)(max_len - 1 - kc0);     // last row of the tile that exists in the cache
+#pragma unroll
+            for (int c = 0; c < KC; c++) { const uint32_t r = k_off[c] >> 8; ko[c] = (r < lim ? r : lim) * 256 + (k_off[c] & 255); }
+#pragma unroll
+            for (int it = 0; it < VC; it++) {
+                const uint32_t r = v_off[it] >> 8, lo = v_off[it] & 255;
+                va[it] = (r < lim ? r : lim) * 256 + lo; vb[it] = (r + 1 < lim ? r + 1 : lim) * 256 + lo;
+            }
+        }
+        st_k0 = *reinterpret_cast<const uint4 *>(kt + ko[0]); st_k1 = *reinterpret_cast<const uint4 *>(kt + ko[1]);
+        if (KC == 4) { st_k2 = *reinterpret_cast<const uint4 *>(kt + ko[2]); st_k3 = *reinterpret_cast<const uint4 *>(kt + ko[3]); }
+        st_va0 = *reinterpret_cast<const uint4 *>(vtb + va[0]); st_vb0 = *reinterpret_cast<const uint4 *>(vtb + vb[0]);
+        if (VC == 2) { st_va1 = *reinterpret_cast<const uint4 *>(vtb + va[VC - 1]); st_vb1 = *reinterpret_cast<const uint4 *>(vtb + vb[VC - 1]); }
     };
     auto store_stage = [&](int key0, int buf) {
         char *kb_ = grp_lds + buf * (K_BYTES + VT_BYTES);

@@ -8,8 +8,13 @@
 // `next` dict are appended to flat int32 tables and freed; the `states` list only counts; `states_topk_next` (re-derived by the builder:
 // SO/sam/static_sam.py:137-146 is a pure function of the states) is discarded element by element; `input_ids` goes straight into the
 // text array.  Peak memory = the tables (~28 B per state + 8 B per edge) + the 64-byte node image layout() makes of them.  Nothing in
-// the stream is executed: a GLOBAL is a name, REDUCE / NEWOBJ build inert records -- loading an untrusted pickle runs no code.
-// Anything outside the subset returns SAMD_E_IO with the opcode named; the Python binding then falls back to pickle.load.
+// the stream is executed BY THIS READER: a GLOBAL is a name, REDUCE / NEWOBJ build inert records.  Anything outside the subset returns
+// SAMD_E_IO with the opcode named.  (The Python binding's fallback for such a file is pickle.load, which DOES execute the stream: the
+// "runs no code" property belongs to this reader, not to samd_sam_only.sam.utils.load_reference_pickle as a whole.)
+// Ownership: containers own their items and the graph dump_sam writes is a tree, so a box has ONE reference -- the stack slot or the
+// container that holds it.  The memo is the only way to make a second one, so BINGET / LONG_BINGET of a container or object is refused
+// (a real dump_sam stream only GETs strings and class names); every dereference of a box still checks that it is live and long enough
+// (round 6: a crafted stream could free a memoized list through the discarded `states_topk_next` sink and BUILD on the dead box).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -65,6 +70,12 @@ struct VM {
         return id;
     }
     static bool is_box(const Val &v) { return v.tag == T_TUPLE || v.tag == T_LIST || v.tag == T_DICT || v.tag == T_OBJ; }
+    // the live box behind v with at least min_items items, or nullptr (never trust an index that came through the stream's own bookkeeping)
+    Box *box_of(const Val &v, size_t min_items = 0) {
+        if (!is_box(v) || v.i < 0 || v.i >= (int64_t)boxes.size()) return nullptr;
+        Box &b = boxes[v.i];
+        return b.live && b.items.size() >= min_items ? &b : nullptr;
+    }
     void free_val(const Val &v) {                           // recursive: containers own their items (the graph the reference dumps is a tree)
         if (!is_box(v)) return;
         std::vector<int64_t> todo{v.i};
@@ -87,7 +98,7 @@ struct VM {
         return g.size() >= n && g.compare(g.size() - n, n, suffix) == 0;
     }
     int64_t find_mark() const { for (int64_t k = (int64_t)stack.size() - 1; k >= 0; k--) if (stack[k].tag == T_MARK) return k; return -1; }
-    void memoize(int64_t idx, const Val &v) { memo[idx] = v; if (is_box(v) && boxes[v.i].memo_id < 0) boxes[v.i].memo_id = idx; }
+    void memoize(int64_t idx, const Val &v) { memo[idx] = v; if (Box *b = box_of(v)) { if (b->memo_id < 0) b->memo_id = idx; } }
 
     bool append_items(Box &dst, size_t from) {             // list.extend(stack[from:])
         for (size_t k = from; k < stack.size(); k++) {
@@ -114,7 +125,7 @@ struct VM {
     }
     // BUILD of a SAMState: its __dict__ -> one row of the tables, its `next` dict -> the edge arrays (dict order), everything freed
     bool sink_state(const Val &state) {
-        if (state.tag != T_DICT) return fail("SAMState state is not a dict");
+        if (state.tag != T_DICT || !box_of(state)) return fail("SAMState state is not a dict");
         Box &d = boxes[state.i];
         int64_t lk = 0, len = 0, ax = 0; bool got_l = false, got_len = false, got_ax = false, got_next = false;
         for (size_t k = 0; k + 1 < d.items.size(); k += 2) {
@@ -122,7 +133,7 @@ struct VM {
             if (key.tag != T_STR) return fail("SAMState attribute name is not a string");
             const std::string &name = strs[key.i];
             if (name == "next") {
-                if (v.tag != T_DICT) return fail("SAMState.next is not a dict");
+                if (v.tag != T_DICT || !box_of(v)) return fail("SAMState.next is not a dict");
                 const Box &nx = boxes[v.i];
                 if (nx.items.size() / 2 > (size_t)INT32_MAX) return fail("degree overflow");
                 for (size_t e = 0; e + 1 < nx.items.size(); e += 2) {
@@ -227,7 +238,7 @@ bool run(Reader &r, VM &vm, Val &result) {
             if (op == 'e') { const int64_t m = vm.find_mark(); if (m < 1) return vm.fail("APPENDS without MARK"); from = (size_t)m + 1; }
             else { if (vm.stack.size() < 2) return vm.fail("stack underflow"); from = vm.stack.size() - 1; }
             const Val lst = vm.stack[op == 'e' ? from - 2 : from - 1];
-            if (lst.tag != T_LIST) return vm.fail("APPEND to a non-list");
+            if (lst.tag != T_LIST || !vm.box_of(lst)) return vm.fail("APPEND to a non-list");
             if (!vm.append_items(vm.boxes[lst.i], from)) return false;
             if (op == 'e') vm.stack.pop_back();                                        // the MARK
             break;
@@ -237,7 +248,7 @@ bool run(Reader &r, VM &vm, Val &result) {
             if (op == 'u') { const int64_t m = vm.find_mark(); if (m < 1) return vm.fail("SETITEMS without MARK"); from = (size_t)m + 1; }
             else { if (vm.stack.size() < 3) return vm.fail("stack underflow"); from = vm.stack.size() - 2; }
             const Val d = vm.stack[op == 'u' ? from - 2 : from - 1];
-            if (d.tag != T_DICT) return vm.fail("SETITEM on a non-dict");
+            if (d.tag != T_DICT || !vm.box_of(d)) return vm.fail("SETITEM on a non-dict");
             if (!vm.set_items(vm.boxes[d.i], from)) return false;
             if (op == 'u') vm.stack.pop_back();
             break;
@@ -258,7 +269,7 @@ bool run(Reader &r, VM &vm, Val &result) {
             const Val args = vm.stack.back(), cls = vm.stack[vm.stack.size() - 2];
             vm.stack.resize(vm.stack.size() - 2);
             // protocols 2 / 3 name a NESTED class (StaticSAM.SAMState) as getattr(<global StaticSAM>, 'SAMState'): still just a name
-            if (op == 'R' && (vm.global_ends_with(cls, "\ngetattr")) && args.tag == T_TUPLE && vm.boxes[args.i].items.size() == 2 &&
+            if (op == 'R' && (vm.global_ends_with(cls, "\ngetattr")) && args.tag == T_TUPLE && vm.box_of(args, 2) && vm.boxes[args.i].items.size() == 2 &&
                 vm.boxes[args.i].items[0].tag == T_GLOBAL && vm.boxes[args.i].items[1].tag == T_STR) {
                 const std::string name = vm.strs[vm.boxes[args.i].items[0].i] + "." + vm.strs[vm.boxes[args.i].items[1].i];
                 vm.free_val(args);
@@ -274,7 +285,7 @@ bool run(Reader &r, VM &vm, Val &result) {
             if (vm.stack.size() < 2) return vm.fail("stack underflow");
             const Val state = vm.stack.back(); vm.stack.pop_back();
             Val &obj = vm.stack.back();
-            if (obj.tag != T_OBJ) return vm.fail("BUILD on a non-object");
+            if (obj.tag != T_OBJ || !vm.box_of(obj, 2)) return vm.fail("BUILD on a non-object");
             Box &ob = vm.boxes[obj.i];
             if (vm.global_ends_with(ob.items[0], "StaticSAM.SAMState") || vm.global_ends_with(ob.items[0], "\nSAMState")) {
                 if (!vm.sink_state(state)) return false;
@@ -301,6 +312,8 @@ bool run(Reader &r, VM &vm, Val &result) {
             if (!r.bytes(tmp, w)) return vm.fail("truncated");
             const auto it = vm.memo.find(le_int(tmp, w, false));
             if (it == vm.memo.end()) return vm.fail("GET of an object this reader already consumed (shared sub-objects are outside the supported subset)");
+            // a second reference to a container / object would outlive the owner that frees it (see the ownership note in the header)
+            if (VM::is_box(it->second)) return vm.fail("GET of a container or object (shared sub-objects are outside the supported subset)");
             vm.stack.push_back(it->second); break;
         }
         case '0': if (vm.stack.empty()) return vm.fail("stack underflow"); vm.stack.pop_back(); break;                  // POP
@@ -326,9 +339,9 @@ extern "C" int samd_static_from_pickle(const char *path, int32_t kind, double ou
         Val top;
         if (!run(r, vm, top)) { fclose(f); samd_set_error("%s: %s", path, vm.err.c_str()); return SAMD_E_IO; }
         fclose(f); f = nullptr;
-        if (top.tag != T_OBJ || !vm.global_ends_with(vm.boxes[top.i].items[0], "\nStaticSAM")) { samd_set_error("%s: the pickle does not hold a StaticSAM object", path); return SAMD_E_IO; }
+        if (top.tag != T_OBJ || !vm.box_of(top, 2) || !vm.global_ends_with(vm.boxes[top.i].items[0], "\nStaticSAM")) { samd_set_error("%s: the pickle does not hold a StaticSAM object", path); return SAMD_E_IO; }
         const Val st = vm.boxes[top.i].items[1];
-        if (st.tag != T_DICT) { samd_set_error("%s: StaticSAM without attributes", path); return SAMD_E_IO; }
+        if (st.tag != T_DICT || !vm.box_of(st)) { samd_set_error("%s: StaticSAM without attributes", path); return SAMD_E_IO; }
         if (out_params) for (int k = 0; k < 8; k++) out_params[k] = -1.0;
         int64_t listed = -1;
         const Box &d = vm.boxes[st.i];
@@ -336,7 +349,7 @@ extern "C" int samd_static_from_pickle(const char *path, int32_t kind, double ou
             const Val &key = d.items[k], &v = d.items[k + 1];
             if (key.tag != T_STR) continue;
             const std::string &name = vm.strs[key.i];
-            if (name == "states") { if (v.tag == T_LIST && vm.boxes[v.i].role == R_SINK_STATES) listed = vm.boxes[v.i].count; continue; }
+            if (name == "states") { if (v.tag == T_LIST && vm.box_of(v) && vm.boxes[v.i].role == R_SINK_STATES) listed = vm.boxes[v.i].count; continue; }
             if (!out_params) continue;
             const double num = v.tag == T_INT ? (double)v.i : (v.tag == T_FLOAT ? v.f : -1.0);
             // out_params: [0] max_predicts [1] alpha [2] K [3] n_predicts [4] cur_index [5] cur_length [6] last [7] max_length

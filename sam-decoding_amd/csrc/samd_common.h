@@ -204,21 +204,52 @@ void samd_set_error(const char *fmt, ...);
 void samd_set_error_detail(const char *fmt, ...);      // kept until the next samd_set_error, which appends it
 
 #if defined(__HIPCC__)
+// max / sum over the 16 lanes (l & 15) of a DPP row -- the 16 keys of an MFMA column block that share a query row -- on the DPP network:
+// xor 1 / xor 2 as quad permutes, then row_half_mirror and row_mirror (after the quad steps every lane of a quad holds the quad's value,
+// so mirroring pairs quads exactly as xor 4 / xor 8 would): the SAME reduction tree, hence bit-identical sums, as four __shfl_xor steps,
+// which hipcc lowers to ds_bpermute_b32 -- an LDS round trip each, 32 of them per key tile in the one computing wave's critical path
+// (round 6; used by k_tree_attention, k_tree_attention_rope and k_attn_block: the compute wave of a <= 16-row step is the launch's critical path once its tile has landed).
+template <int CTRL> __device__ __forceinline__ float att_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, att_dpp<0xB1>(v)); v = fmaxf(v, att_dpp<0x4E>(v));       // quad_perm [1,0,3,2], [2,3,0,1]
+    v = fmaxf(v, att_dpp<0x141>(v)); return fmaxf(v, att_dpp<0x140>(v));  // row_half_mirror, row_mirror
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += att_dpp<0xB1>(v); v += att_dpp<0x4E>(v);
+    v += att_dpp<0x141>(v); return v + att_dpp<0x140>(v);
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it once per (kernel, device), not once per
 // process (a process that moves to another device would otherwise launch there without it).  `done` = one bitmask per kernel
-// instantiation (function-local static at the call site); devices >= 64 set it on every call.
+// instantiation (function-local static at the call site); devices >= 64 set it on every call.  The mask is read and updated with atomic
+// operations: host threads that drive different devices may make their first call at the same time (setting the attribute twice is
+// harmless, a torn or lost update of the mask would not be a defined program).
 static inline hipError_t samd_reserve_lds(const void *kernel, int bytes, unsigned long long *done) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && ((*done >> dev) & 1ull)) return hipSuccess;
+    if (dev >= 0 && dev < 64 && ((__atomic_load_n(done, __ATOMIC_ACQUIRE) >> dev) & 1ull)) return hipSuccess;
     e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {                                   // say what the device offers (a 64 KiB-LDS part cannot run these kernels)
         int optin = 0;
         if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess)
             samd_set_error_detail("device %d offers %d bytes of LDS per workgroup, the kernel needs %d (written for gfx950: 160 KiB)", dev, optin, bytes);
     }
-    if (e == hipSuccess && dev >= 0 && dev < 64) *done |= 1ull << dev;
+    if (e == hipSuccess && dev >= 0 && dev < 64) __atomic_fetch_or(done, 1ull << dev, __ATOMIC_RELEASE);
     return e;
+}
+// compute units of the CURRENT device, looked up once per device (a process may drive several GPUs; relaxed atomics: see above)
+static inline int samd_device_cus() {
+    static int cached[64];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return 256;
+    if (d >= 0 && d < 64) { const int c = __atomic_load_n(&cached[d], __ATOMIC_RELAXED); if (c > 0) return c; }
+    int n = 256;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+    if (d >= 0 && d < 64) __atomic_store_n(&cached[d], n, __ATOMIC_RELAXED);
+    return n;
 }
 #endif

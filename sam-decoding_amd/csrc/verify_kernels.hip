@@ -141,7 +141,11 @@ __device__ __forceinline__ int att_head_of_block(int bx, int n_heads) {
     return (n_heads & 7) == 0 ? (bx & 7) * (n_heads >> 3) + (bx >> 3) : bx;
 }
 
-template <typename TT>
+// WIDE = a draft of 65..128 nodes: two 64-row tiles (blockIdx.z), two mask words per row.  The <= 64-node instantiation -- every step of every
+// BASELINE configuration -- is the round-4 kernel again: one mask word, no second word to select (round 5 ran ONE generic kernel whose
+// `rel < 64 ? lo >> rel : hi >> (rel - 64)` the compiler turned into exec-mask branches per score in the one computing wave's softmax:
+// 8.81 -> 9.32 us per launch across the bench, +0.5 % on every row bucket's step)
+template <typename TT, bool WIDE>
 __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
                                                         const typename TT::elem *__restrict__ vc, float *__restrict__ ws,
                                                         int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lg = l >> 4;
     // blockIdx.z = the 64-row tile of the draft (round 5: drafts of up to 128 nodes are two tiles; row i's ancestor mask is two u64 words,
     // the high words -- nodes 64..127 -- stored SAMD_MAX_DRAFT entries behind the low ones; a draft of <= 64 nodes has one tile, low words only)
-    const int row_base = 64 * (int)blockIdx.z + 16 * w;
+    const int row_base = (WIDE ? 64 * (int)blockIdx.z : 0) + 16 * w;
     // loads that do not depend on L / n go out first (Q fragments, mask rows), together with the two scalars
     V8 qa[4];
     {
@@ -175,11 +179,11 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
             qa[kk] = __builtin_bit_cast(V8, raw);
         }
     }
-    unsigned long long mrow[4], mrow_hi[4];
+    unsigned long long mrow[4], mrow_hi[WIDE ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < 4; r++) {                                             // the mask holds n_q_pad rows (<= 64: low words only); rows >= n are zeroed below
         mrow[r] = mask[row_base + 4 * lg + r];
-        mrow_hi[r] = n_q_pad > 64 ? mask[SAMD_MAX_DRAFT + row_base + 4 * lg + r] : 0ull;
+        if constexpr (WIDE) mrow_hi[r] = mask[SAMD_MAX_DRAFT + row_base + 4 * lg + r];
     }
     // Split s owns the key tiles s, s + ATT_SPLITS, s + 2 ATT_SPLITS, ...: the FIRST tile of a workgroup is known from its
     // block index alone, so its K fragments and V rows are requested here, in the same memory round trip as the two scalars
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     if (split >= ntiles) return;                       // no keys for this split: k_attn_combine only reads the splits in use
     const bool active = row_base < n;
 #pragma unroll
-    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) { mrow[r] = 0ull; mrow_hi[r] = 0ull; }
+    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) { mrow[r] = 0ull; if constexpr (WIDE) mrow_hi[r] = 0ull; }
 
     float m_run[4], l_run[4];
     floatx4 o[8];
@@ -270,7 +274,11 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int rel = key - L;                                   // index of a NEW key among the draft's nodes
-                    const bool ok = key < L || (key < total && (((rel < 64 ? mrow[r] >> rel : mrow_hi[r] >> (rel - 64))) & 1ull));
+                    bool ok;
+                    if constexpr (WIDE) {                                      // the word is SELECTED (v_cndmask), then one shift: no branch per score
+                        const unsigned long long word = rel < 64 ? mrow[r] : mrow_hi[r];
+                        ok = (key < L) | ((key < total) & (bool)((word >> (rel & 63)) & 1ull));
+                    } else ok = (key < L) | ((key < total) & (bool)((mrow[r] >> (rel & 63)) & 1ull));        // bitwise: no exec-mask branch per score
                     const float v = ok ? s[st][r] * scale_log2 : -INFINITY;
                     s[st][r] = v;
                     tmax[r] = fmaxf(tmax[r], v);
@@ -278,21 +286,20 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = tmax[r];
-                v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-                v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+                const float v = row16_max(tmax[r]);
                 const float m_new = fmaxf(m_run[r], v);
                 const float m_use = m_new == -INFINITY ? 0.f : m_new;
-                const float alpha = exp2f(m_run[r] - m_use);          // m_run = -inf -> 0
+                // v_exp_f32 itself (arguments <= 0; results below 2^-126 flush to zero, as weights of that size may): exp2f() wraps it in a
+                // denormal-range rescale -- a compare, two selects and an ldexp per score
+                const float alpha = __builtin_amdgcn_exp2f(m_run[r] - m_use);          // m_run = -inf -> 0
                 float psum = 0.f;
 #pragma unroll
                 for (int st = 0; st < 4; st++) {
-                    const float p = exp2f(s[st][r] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(s[st][r] - m_use);
                     psum += p;
                     Pmine[(4 * lg + r) * P_STRIDE + 16 * st + lr] = (E)p;
                 }
-                psum += __shfl_xor(psum, 1); psum += __shfl_xor(psum, 2);
-                psum += __shfl_xor(psum, 4); psum += __shfl_xor(psum, 8);
+                psum = row16_sum(psum);
                 l_run[r] = l_run[r] * alpha + psum;
                 m_run[r] = m_new;
 #pragma unroll
@@ -631,21 +638,18 @@ __global__ __launch_bounds__(256, 2) void k_tree_attention_rope(const typename T
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = tmax[r];
-                v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
-                v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+                const float v = row16_max(tmax[r]);
                 const float m_new = fmaxf(m_run[r], v);
                 const float m_use = m_new == -INFINITY ? 0.f : m_new;
-                const float alpha = exp2f(m_run[r] - m_use);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[r] - m_use);
                 float psum = 0.f;
 #pragma unroll
                 for (int st = 0; st < 4; st++) {
-                    const float p = exp2f(s[st][r] - m_use);
+                    const float p = __builtin_amdgcn_exp2f(s[st][r] - m_use);
                     psum += p;
                     Pmine[(4 * lg + r) * P_STRIDE + 16 * st + lr] = (E)p;
                 }
-                psum += __shfl_xor(psum, 1); psum += __shfl_xor(psum, 2);
-                psum += __shfl_xor(psum, 4); psum += __shfl_xor(psum, 8);
+                psum = row16_sum(psum);
                 l_run[r] = l_run[r] * alpha + psum;
                 m_run[r] = m_new;
 #pragma unroll
@@ -1069,17 +1073,17 @@ static int tree_attention_impl(const void *d_q, const void *d_k_cache, const voi
     hipStream_t st = (hipStream_t)stream;
     const float scale_log2 = scale * 1.4426950408889634f;
     float *ws = (float *)d_workspace;
+#define ATT_GO(TT, ET, W) hipLaunchKernelGGL((k_tree_attention<TT, W>), dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const ET *)d_q, \
+                           (const ET *)d_k_cache, (const ET *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len, \
+                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split)
     if (dtype == SAMD_F16) {
-        hipLaunchKernelGGL(k_tree_attention<F16>, dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache,
-                           (const _Float16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
-                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
+        if (row_tiles > 1) ATT_GO(F16, _Float16, true); else ATT_GO(F16, _Float16, false);
         hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     } else {
-        hipLaunchKernelGGL(k_tree_attention<BF16>, dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache,
-                           (const __bf16 *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len,
-                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split);
+        if (row_tiles > 1) ATT_GO(BF16, __bf16, true); else ATT_GO(BF16, __bf16, false);
         hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     }
+#undef ATT_GO
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -41,7 +41,8 @@ class DraftModel(SessionPlumbing, torch.nn.Module):
         self._start = None
 
     def params(self) -> samd_hip.Params:
-        return s_params(self.config.n_predicts, self.len_threshold, self.len_bias, isinstance(self.sam_static, NullStaticSAM))
+        return s_params(self.config.n_predicts, self.len_threshold, self.len_bias, isinstance(self.sam_static, NullStaticSAM),
+                        cap=getattr(self, "draft_cap", None))
 
     def reset(self):
         self.session().reset()                       # dynamic automaton wiped, static cursor to the root

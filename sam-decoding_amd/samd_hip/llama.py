@@ -372,6 +372,13 @@ class LlamaRunner:
                                 ssq=torch.zeros((max(s.hidden // 16, 1), 16), dtype=torch.float32, device=dev))
         return self._buf[R]
 
+    def max_draft_rows(self):
+        """the largest draft (nodes) this runner can verify: 128 needs the library GEMM on the row-major matrices and the split tree
+        attention's two-tile form; otherwise the streaming kernels' 64-row tile is the limit.  DraftModel parameters are clamped to this
+        when a session's engine is made (samd_sam_only.sam._common.clamp_to_verifier), so a wide draft never fails inside forward_rows."""
+        wide_ok = (not self.row_major_released) and self.attention in ("split", "split3") and not getattr(self, "draft_head", False)
+        return MAX_DRAFT if wide_ok else min(MAX_DRAFT, 64)
+
     def bucket(self, n):
         for b in self.BUCKETS:
             if n <= b:
@@ -550,6 +557,12 @@ class LlamaRunner:
     PF_SPLIT_MIN_ROWS = 1024          # below this no projection of the prompt is worth splitting (and short prompts keep one code path)
     PF_ATTN_PAD = 128                 # fused causal SDPA runs 40-45 % slower on row counts that are not a multiple of this (r05_gemm_rows.log)
 
+    def _is_gfx950(self):
+        if not hasattr(self, "_gfx950"):
+            name = getattr(torch.cuda.get_device_properties(self.device), "gcnArchName", "") or ""
+            self._gfx950 = name.split(":")[0] == "gfx950"
+        return self._gfx950
+
     def _time_mm(self, x, wt, out, reps=3):
         best = float("inf")
         torch.mm(x, wt, out=out)
@@ -631,7 +644,8 @@ class LlamaRunner:
         x, h = z(N, s.hidden), z(N, s.hidden)
         # the prompt's causal attention: our kernel (samd_prefill_attention: any row count, nothing behind the prompt is read) on the row-major
         # cache; PyTorch's fused SDPA otherwise (transposed V cache of a draft head's runner, head_dim != 128, SAMD_PREFILL_ATTENTION=sdpa)
-        own_attn = (not self.v_transposed) and s.head_dim == 128 and os.environ.get("SAMD_PREFILL_ATTENTION", "own") != "sdpa"
+        own_attn = ((not self.v_transposed) and s.head_dim == 128 and os.environ.get("SAMD_PREFILL_ATTENTION", "own") != "sdpa"
+                    and self._is_gfx950())             # the kernel needs 136 KiB of LDS and gfx950's permlane swaps: any other device takes SDPA
         Np = N if own_attn else -(-N // self.PF_ATTN_PAD) * self.PF_ATTN_PAD
         if Np > self.max_len:
             Np = N

@@ -84,7 +84,7 @@ class DraftModel(SessionPlumbing, torch.nn.Module):
 
     def params(self) -> samd_hip.Params:
         c = self.config
-        return so_params(c.max_predicts, c.alpha, c.K, self.len_bias)
+        return so_params(c.max_predicts, c.alpha, c.K, self.len_bias, cap=getattr(self, "draft_cap", None))
 
     # ---- reference API ----------------------------------------------------------------------------------------------
     def reset(self):

@@ -10,21 +10,41 @@ def dev_i32(values, device="cuda"):
     return torch.as_tensor(np.asarray(values, dtype=np.int32)).to(device)
 
 
-def so_params(max_predicts=60, alpha=4.0, K=8, len_bias=0):
+def so_params(max_predicts=60, alpha=4.0, K=8, len_bias=0, cap=None):
     """device parameters of the SAM-only variant.  A draft holds at most samd_hip.MAX_DRAFT (128) nodes -- one wavefront builds it two
     nodes per lane, two 64-bit mask words per node, two 64-row verify tiles (include/samd_hip.h SAMD_MAX_DRAFT); larger max_predicts are
-    served with 128-node drafts (decoding stays lossless, only the accept lengths of very long matches differ from the reference's)."""
+    served with 128-node drafts (decoding stays lossless, only the accept lengths of very long matches differ from the reference's).
+    `cap`: the largest draft the verifier behind this draft model can run (LlamaRunner.max_draft_rows(): 64 once the row-major matrices are
+    released or the attention mode has no two-tile form) -- the draft is clamped HERE, when the session's parameters are made, instead of
+    failing inside forward_rows on the first wide draft."""
     p = samd_hip.Params()
-    p.variant, p.max_predicts, p.alpha, p.K, p.len_bias = 0, min(int(max_predicts), samd_hip.MAX_DRAFT), float(alpha), int(K), int(len_bias)
+    lim = samd_hip.MAX_DRAFT if cap is None else max(1, min(int(cap), samd_hip.MAX_DRAFT))
+    p.variant, p.max_predicts, p.alpha, p.K, p.len_bias = 0, min(int(max_predicts), lim), float(alpha), int(K), int(len_bias)
     p.n_predicts, p.len_threshold, p.static_null = 0, 0, 0
     return p
 
 
-def s_params(n_predicts=40, len_threshold=5, len_bias=5, static_null=False):
+def s_params(n_predicts=40, len_threshold=5, len_bias=5, static_null=False, cap=None):
     p = samd_hip.Params()
+    lim = samd_hip.MAX_DRAFT if cap is None else max(1, min(int(cap), samd_hip.MAX_DRAFT))
     p.variant, p.max_predicts, p.alpha, p.K = 1, 0, 0.0, 0
-    p.len_bias, p.n_predicts, p.len_threshold, p.static_null = int(len_bias), min(int(n_predicts), samd_hip.MAX_DRAFT), int(len_threshold), int(static_null)
+    p.len_bias, p.n_predicts, p.len_threshold, p.static_null = int(len_bias), min(int(n_predicts), lim), int(len_threshold), int(static_null)
     return p
+
+
+def clamp_to_verifier(draft_model, verifier, asked, what):
+    """set draft_model.draft_cap from what `verifier` can run (a runner without row-major matrices, or in attention mode
+    'block' / 'split2', serves drafts of at most 64 nodes); warns once per model when the configured draft size is above it"""
+    cap = getattr(verifier, "max_draft_rows", None)
+    cap = int(cap()) if callable(cap) else samd_hip.MAX_DRAFT
+    prev = getattr(draft_model, "draft_cap", None)
+    draft_model.draft_cap = cap
+    if asked > cap and prev != cap:
+        import warnings
+        warnings.warn(f"{what} = {asked}: this verifier runs drafts of at most {cap} nodes (row-major projection matrices released, or an "
+                      f"attention mode without a two-tile form); drafts are capped at {cap} -- decoding stays lossless, accept lengths of "
+                      f"very long matches differ from the reference's", RuntimeWarning, stacklevel=3)
+    return cap
 
 
 def tree_buffers_from_draft(d, device):

@@ -39,13 +39,18 @@ def load_image_or_pickle(path: str, cls):
 
 def load_reference_pickle(path: str, cls):
     """a pickle written by the reference's dump_sam (SO/sam/utils.py:20-22).  First the native streaming reader
-    (samd_static_from_pickle: the states go straight into flat tables, peak memory ~ the node image, nothing in the stream is executed --
-    the published 20-35 M-state automata would otherwise become ~10^8 live Python objects); a pickle outside its opcode subset falls back to
-    pickle.load + cls.__setstate__ (small files, odd protocols), with a warning that says why."""
+    (samd_static_from_pickle: the states go straight into flat tables, peak memory ~ the node image, the native reader executes nothing of
+    the stream -- the published 20-35 M-state automata would otherwise become ~10^8 live Python objects); a pickle outside its opcode subset
+    falls back to pickle.load + cls.__setstate__ (small files, odd protocols), with a warning that says why.  NOTE: that fallback is
+    CPython's unpickler and DOES execute the stream, exactly as the reference's load_sam does (SO/sam/utils.py:24-39) -- only load files
+    you trust, or set SAMD_PICKLE_NO_FALLBACK=1 to turn a decline into an error instead."""
     try:
         auto, pickled = samd_hip.StaticAutomaton.from_reference_pickle(path, cls.KIND)
     except samd_hip.SamdError as e:
+        import os
         import warnings
+        if os.environ.get("SAMD_PICKLE_NO_FALLBACK", "0") == "1":
+            raise
         warnings.warn(f"native pickle reader declined {path} ({e}); falling back to pickle.load", RuntimeWarning)
         with open(path, "rb") as f:
             sam = pickle.load(f)

@@ -141,6 +141,15 @@ class SamdModel(nn.Module):
             if isinstance(self.verifier, LlamaRunner) and self.cache is None:
                 self.cache = _RunnerCacheView(self.verifier)
         session = self.draft.ensure_capacity(max_len + samd_hip.MAX_DRAFT)
+        # the verifier says how wide a draft it can run; the session's parameters are clamped to that here, with a warning, not mid-generation
+        from .sam._common import clamp_to_verifier
+        if hasattr(self.draft, "tree_model"):               # samd (full variant): the automata draft n_predicts-token sequences
+            asked, what = getattr(self.samd_config, "n_predicts", 0), "n_predicts"
+        else:
+            asked, what = getattr(self.samd_config, "max_predicts", 0), "max_predicts"
+        cap_before = getattr(self.draft, "draft_cap", None)
+        if clamp_to_verifier(self.draft, self.verifier, int(asked or 0), what) != cap_before and cap_before is not None:
+            self.engine = None                               # parameters changed: the engine holds a copy
         if self.engine is None or self.engine.session is not session:
             self.engine = self._make_engine(session)
 

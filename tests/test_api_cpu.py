@@ -48,6 +48,41 @@ def test_draft_size_limit_is_a_warning_not_an_error():
         SO.SamdConfig(max_predicts=0)
 
 
+def test_draft_size_follows_what_the_verifier_can_run():
+    """a runner without row-major matrices (or in an attention mode without the two-tile form) verifies at most 64 rows; the
+    session's parameters are clamped to that when the engine is made -- with a warning -- instead of failing inside forward_rows on the
+    first wide draft.  Host logic only: no GPU needed."""
+    import warnings
+    from samd_sam_only.sam._common import clamp_to_verifier, s_params, so_params
+
+    class Verifier:
+        def __init__(self, cap):
+            self.cap = cap
+
+        def max_draft_rows(self):
+            return self.cap
+
+    class Draft:
+        pass
+    assert so_params(128).max_predicts == 128 and so_params(128, cap=64).max_predicts == 64 and so_params(40, cap=64).max_predicts == 40
+    assert s_params(128).n_predicts == 128 and s_params(100, cap=64).n_predicts == 64 and so_params(500, cap=None).max_predicts == samd_hip.MAX_DRAFT
+    d = Draft()
+    with pytest.warns(RuntimeWarning, match="capped at 64"):
+        assert clamp_to_verifier(d, Verifier(64), 100, "max_predicts") == 64
+    assert d.draft_cap == 64
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert clamp_to_verifier(d, Verifier(64), 100, "max_predicts") == 64      # said once per model and cap
+        assert clamp_to_verifier(d, Verifier(128), 100, "max_predicts") == 128    # nothing to say: the verifier can run it
+        assert clamp_to_verifier(Draft(), object(), 100, "max_predicts") == samd_hip.MAX_DRAFT   # a verifier that says nothing: the library's limit
+    from samd_hip.llama import LlamaRunner
+    r = LlamaRunner.__new__(LlamaRunner)
+    for released, mode, head, want in ((False, "split", False, 128), (True, "split", False, 64), (False, "block", False, 64), (False, "split2", False, 64),
+                                       (False, "split3", False, 128), (False, "split", True, 64)):
+        r.row_major_released, r.attention, r.draft_head = released, mode, head
+        assert r.max_draft_rows() == want, (released, mode, head)
+
+
 def test_s_surface_and_defaults():
     import samd as S
     c = S.SamdConfig()

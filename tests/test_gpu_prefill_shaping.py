@@ -121,12 +121,19 @@ def test_tune_prefill_failure_leaves_single_calls(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
-@pytest.mark.parametrize("rows,H,Hkv,pos0", [(200, 32, 32, 0), (1333, 32, 8, 0), (128, 8, 8, 0), (1, 4, 2, 37), (700, 16, 16, 300), (129, 8, 1, 1900), (2048, 4, 4, 0),
-                                            (96, 8, 8, 1952), (1536, 32, 32, 0), (63, 2, 1, 0), (65, 2, 2, 63)])
-def test_prefill_attention_against_fp32_softmax_attention(dtype, tol, rows, H, Hkv, pos0):
+@pytest.mark.parametrize("case", [(200, 32, 32, 0), (1333, 32, 8, 0), (128, 8, 8, 0), (1, 4, 2, 37), (700, 16, 16, 300), (129, 8, 1, 1900), (2048, 4, 4, 0),
+                                  (96, 8, 8, 1952), (1536, 32, 32, 0), (63, 2, 1, 0), (65, 2, 2, 63),
+                                  # round 6: (rows, H, Hkv, pos0, max_len) -- caches whose length is not a multiple of the 64-key tile with
+                                  # the prompt ending inside the LAST, partial tile (its keys were read from a shifted tile base), and caches
+                                  # shorter than one tile (64 rows were read past them)
+                                  (990, 8, 8, 0, 1000), (130, 4, 2, 860, 1000), (1000, 4, 4, 0, 1000), (40, 4, 4, 0, 48), (7, 2, 2, 20, 27),
+                                  (1, 2, 1, 0, 1), (200, 4, 4, 1801, 2001)], ids=lambda c: "x".join(map(str, c)))
+def test_prefill_attention_against_fp32_softmax_attention(dtype, tol, case):
     """samd_prefill_attention (csrc/prefill_attn_device.h) against a plain fp32 causal attention in torch: every row, every head; the cache
     behind the prompt is NaN (it must not be read into a result), as is `out` before the launch (every row < rows must be written)."""
-    lib, D, max_len = samd_hip.lib(), 128, 2048
+    rows, H, Hkv, pos0 = case[:4]
+    max_len = case[4] if len(case) > 4 else 2048
+    lib, D = samd_hip.lib(), 128
     g = torch.Generator(device="cuda").manual_seed(rows * 7 + H)
     q = (torch.randn((rows, H, D), generator=g, device="cuda") * 1.5).to(dtype)
     k = torch.randn((Hkv, max_len, D), generator=g, device="cuda").to(dtype)

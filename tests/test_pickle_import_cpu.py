@@ -161,6 +161,60 @@ def test_nothing_is_executed_and_foreign_pickles_are_declined(tmp_path):
             assert ((e["link"][1:] >= 0) & (e["link"][1:] < n)).all() and ((e["edge_dst"] >= 0) & (e["edge_dst"] < n)).all()
 
 
+def _declined(tmp_path, data, name="crafted.pkl"):
+    p = str(tmp_path / name)
+    open(p, "wb").write(data)
+    h = C.c_void_p()
+    rc = samd_hip.lib().samd_static_from_pickle(os.fsencode(p), 0, None, C.byref(h))
+    assert rc == -4 and not h.value, (name, rc, data[:64])
+    return samd_hip.lib().samd_last_error()
+
+
+def test_a_memoized_container_cannot_be_reached_twice(tmp_path):
+    """a box reached through BINPUT / BINGET could be freed by the discarding `states_topk_next` sink while a copy sat on the
+    stack; BUILD then read items[0] / items[1] of the dead (or recycled) box.  The 40-byte stream the advisor crashed the library with,
+    the same idea through LONG_BINPUT / LONG_BINGET / MEMOIZE, and a GET of a freed object after its box id was handed out again."""
+    obj = b"cm\nStaticSAM\n)\x81"                                        # GLOBAL m.StaticSAM, EMPTY_TUPLE, NEWOBJ -> an object box
+    key = b"\x8c\x10states_topk_next"                                     # SHORT_BINUNICODE 'states_topk_next': the next list discards its items
+    streams = {
+        "advisor": obj + b"q\x00" + key + b"]h\x00a00}b.",                # PUT 0, list, GET 0, APPEND (frees the object), POP, POP, BUILD on the dead box
+        "long":    obj + b"r\x00\x00\x00\x00" + key + b"]j\x00\x00\x00\x00a00}b.",
+        "memoize": b"\x80\x04" + obj + b"\x94" + key + b"]h\x00a00}b.",
+        "reuse":   obj + b"q\x00" + key + b"]h\x00a00" + b"}" + b"h\x00" + b"}b.",   # ... a new dict takes the freed id, GET 0 again, BUILD
+        "list_in_list": key + b"]q\x01" + key + b"]h\x01a0h\x01.",       # a discarding list appended to another one, then fetched again
+        "tuple_get": b"K\x01K\x02\x86q\x05" + key + b"]h\x05a0h\x05.",
+    }
+    for name, data in streams.items():
+        msg = _declined(tmp_path, data, name + ".pkl")
+        assert msg
+    # mutator: every BINGET / LONG_BINGET operand of the reference's own pickle re-pointed at every memo slot that holds a container
+    good = open(os.path.join(HERE, "golden", "ref_static_sam.pkl"), "rb").read()
+    import pickletools
+    ops = list(pickletools.genops(good))
+    gets = [(pos, op.name, arg) for op, arg, pos in ops if op.name in ("BINGET", "LONG_BINGET")]
+    memo_ops = [(pos, op.name) for op, arg, pos in ops if op.name in ("MEMOIZE", "BINPUT", "LONG_BINPUT")]
+    assert gets and memo_ops
+    rng = np.random.default_rng(11)
+    n_memo = len(memo_ops)
+    tried = 0
+    for pos, name, arg in gets[:: max(1, len(gets) // 40)]:
+        width = 1 if name == "BINGET" else 4
+        for target in {0, 1, 2, 3, int(rng.integers(0, min(n_memo, 256 ** width))), int(rng.integers(0, min(n_memo, 256 ** width)))}:
+            if target == arg:
+                continue
+            m = bytearray(good)
+            m[pos + 1:pos + 1 + width] = int(target).to_bytes(width, "little")
+            p = str(tmp_path / "get.pkl")
+            open(p, "wb").write(bytes(m))
+            h = C.c_void_p()
+            rc = samd_hip.lib().samd_static_from_pickle(os.fsencode(p), 0, None, C.byref(h))
+            assert rc in (0, -1, -2, -4), (pos, target, rc)                # declined or sound -- never a crash (the ASan build runs this too)
+            if rc == 0:
+                samd_hip.StaticAutomaton(h).export()
+            tried += 1
+    assert tried >= 40
+
+
 def test_load_sam_falls_back_to_pickle_load_with_a_warning(tmp_path, monkeypatch):
     """protocol 0/1 text pickles are outside the reader's subset: load_sam still loads them through the object graph"""
     docs = [[3, 4, 5, 3, 4, 6], [7, 3, 4]]
