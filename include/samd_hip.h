@@ -111,6 +111,13 @@ int samd_static_info(const samd_static_t *sam, int64_t out[8]);
  * state of degree >= 2, csrc/samd_common.h; sized like the bigram table).  These bytes are resident per GPU replica NEXT to
  * samd_static_info's device bytes (the image). */
 int samd_static_derived_info(const samd_static_t *sam, int64_t out[6]);
+/* round 6: the EDGE BLOCKS and HOT WORDS that replace the edge table when they fit (csrc/samd_common.h: per-state blocks of 16-byte slots
+ * whose every slot carries the owning state's fail header -- a probe, hit or miss, is one request that also says where transfer_state's climb
+ * (static_sam.py:99-101) goes next -- and one 16-byte hot word per state in place of node word 0): out[0] = bytes of the hot words, out[1] =
+ * bytes of the blocks, out[2] = their slots, out[3] = states that own a block; zeros when the handle walks through the edge table instead
+ * (SAMD_EDGE_BLOCKS=0, or something did not fit: samd_static_derived_info's out[4] / out[5] are then non-zero).  Resident per GPU replica
+ * next to the image, like everything samd_static_derived_info reports. */
+int samd_static_edge_blocks_info(const samd_static_t *sam, int64_t out[4]);
 /* re-size the bigram table of an uploaded automaton: slots_per_pair in 2 .. 64 (0 = the default, 4).  A tuning entry with no reference
  * counterpart: a sparser table only helps the BATCHED walk (samd_static_walk* / samd_static_lookup_batch: 64 cursors in lock-step pay a
  * second probe round when any collides -- 16 per pair measured best, profiles/r04_walk.md); one-cursor walks of a session are

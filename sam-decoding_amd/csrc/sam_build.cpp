@@ -294,6 +294,8 @@ void samd_static_free(samd_static_t *s) {
     if (s->d_rc_bits) (void)hipFree(s->d_rc_bits);
     if (s->d_topk_cnt) (void)hipFree(s->d_topk_cnt);
     if (s->d_ehash) (void)hipFree(s->d_ehash);
+    if (s->d_hot) (void)hipFree(s->d_hot);
+    if (s->d_blocks) (void)hipFree(s->d_blocks);
     free(s);
 }
 
@@ -313,6 +315,16 @@ int samd_static_derived_info(const samd_static_t *s, int64_t out[6]) {
     out[1] = s->d_d1hash ? s->n_d1hash * 16 + s->vocab * 16 + ((s->vocab + 31) / 32) * 4 : 0;
     out[2] = s->d_topk_cnt ? s->n_states * (int64_t)SAMD_TOPK * 4 : 0;
     out[3] = s->d_d1hash ? s->n_d1hash : 0;
+    return SAMD_OK;
+}
+
+int samd_static_edge_blocks_info(const samd_static_t *s, int64_t out[4]) {
+    if (!s || !out) return SAMD_E_INVALID;
+    const bool on = s->d_hot && s->d_blocks;
+    out[0] = on ? s->n_states * 16 : 0;
+    out[1] = on ? (s->n_block_slots ? s->n_block_slots : 1) * 16 : 0;
+    out[2] = on ? s->n_block_slots : 0;
+    out[3] = on ? s->n_block_states : 0;
     return SAMD_OK;
 }
 

@@ -91,7 +91,8 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
 // its next transition probes the table without looking at the node
 // ptok = the token of the transition that brought the cursor to its state (-1: unknown): what the flagged climb keys the bigram table with.  It
 // lives IN the cursor's word so that it cannot go stale: st_transfer_chain sets it after every transition, a fresh cursor (chain_none) has none.
-struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next, hub, ptok; };
+// hub also carries, on the EDGE BLOCK path (round 6, samd_common.h), the cursor's state's BLOCK REFERENCE (never 0) instead of a plain 1
+struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next; unsigned hub; int ptok; };
 __device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = c.nlo = c.nhi = ~0ull; c.used = 0; c.have_next = 0; c.hub = 0; c.ptok = -1; return c; }
 __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
     const uint4 c = S.chain[state];
@@ -161,8 +162,11 @@ __device__ __forceinline__ void st_from_root(const StaticDev &S, const uint32_t 
 template <int W>
 __device__ __forceinline__ int st_transfer_chain_impl(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw);
 template <int W>
+__device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw);
+template <int W>
 __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, ChainWord &cw) {
-    const int visited = st_transfer_chain_impl<W>(S, bits, idx, len, tok, cw.ptok, cw);
+    const int visited = S.blocks ? st_transfer_blocks_impl<W>(S, bits, idx, len, tok, cw.ptok, cw)       // (uniform: one path per automaton)
+                                 : st_transfer_chain_impl<W>(S, bits, idx, len, tok, cw.ptok, cw);
     cw.ptok = tok;                                           // (the word may have been replaced inside: set last)
     return visited;
 }
@@ -321,6 +325,182 @@ __device__ __forceinline__ int st_transfer_chain_impl(const StaticDev &S, const 
         if (nx >= 0) { idx = nx; len += 1; if (nx > 0) cw = chain_load(S, idx); return visited; }
         idx = w0.x; hopped = true;
         if (idx == 0) len = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the same transition over EDGE BLOCKS and HOT WORDS (samd_common.h).  What differs from st_transfer_chain_impl is only WHERE the
+// facts come from -- the states visited, their order, the lengths and the count are transfer_state's (static_sam.py:98-107):
+//   * the cursor's own state: its block (reference known from the entry that led here: one probe), or its hot word (then its block);
+//   * every hop of the climb: ONE request -- the fail header that came with the last probe / hot word says what the link is (root,
+//     root child, hub, plain state), where to look and what the match length becomes there;
+//   * a miss at a hub needs nothing more: the header rode in the slot that ended the probe.
+// Requires the chain words and the bigram table (the derivation builds blocks only with both).
+// ------------------------------------------------------------------------------------------------
+struct FailHdr { unsigned kind, ref, len; bool len_ok; };
+__device__ __forceinline__ FailHdr fail_of_slot(const StaticDev &S, const uint4 &e) {
+    FailHdr f;
+    f.kind = (e.y >> SAMD_EB_KIND_SHIFT) & 3u; f.ref = e.w;
+    const unsigned lmax = (1u << (32 - S.eb_tok_bits)) - 1u;
+    f.len = e.x >> S.eb_tok_bits; f.len_ok = f.len != lmax;
+    return f;
+}
+__device__ __forceinline__ FailHdr fail_of_hot(const uint4 &h) {
+    FailHdr f;
+    f.kind = (h.y >> 27) & 3u; f.ref = h.x; f.len = h.y & SAMD_EB_IDX_MASK; f.len_ok = true;
+    return f;
+}
+// probe the block `ref` for tok: e = the slot already loaded at position p (relative to the block).  On return e is the slot that ended the
+// probe -- the hit, or the empty slot -- and carries the block's fail header either way.
+__device__ __forceinline__ bool block_find(const StaticDev &S, unsigned ref, int tok, uint32_t p, uint4 &e) {
+    const unsigned tmask = (1u << S.eb_tok_bits) - 1u, base = samd_eb_base(ref), bmask = samd_eb_mask(ref);
+    const bool in_range = (unsigned)tok < tmask;
+    for (uint32_t probes = 0; probes <= bmask; probes++) {
+        const unsigned t = e.x & tmask;
+        if (in_range && t == (unsigned)tok) return true;
+        if (t == tmask) return false;
+        p = (p + 1) & bmask; e = S.blocks[base + p];
+    }
+    return false;
+}
+template <int W>
+__device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw) {
+    constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
+    if (tok < 0) { idx = 0; len = 0; cw = chain_none(); return 1; }
+    const unsigned ent = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+    const bool is_tok = (ent & LOW) != LOW;
+    if (is_tok && (ent & LOW) == (unsigned)tok) {            // register path: identical to st_transfer_chain_impl
+        idx += 1; len += 1; cw.hub = 0;
+        if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
+        else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
+        if (++cw.used == W) {
+            if (cw.have_next) { cw.lo = cw.nlo; cw.hi = cw.nhi; cw.nlo = cw.nhi = ~0ull; cw.used = 0; cw.have_next = 0; }
+            else { cw = chain_load(S, idx); return 1; }
+        }
+        const unsigned e2 = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+        if (cw.used == W - 1 && (e2 & LOW) != LOW) {
+            const uint4 c = S.chain[idx + 1];
+            cw.nlo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
+            cw.nhi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
+            cw.have_next = 1;
+        }
+        return 1;
+    }
+    // flagged chain entry: the cursor's state has one edge (not `tok`) and its link is the root child of ptok
+    const bool climbing = is_tok && !(ent & HI) && ptok >= 0;
+    const unsigned my_ref = idx > 0 ? cw.hub : 0u;           // this state's block, when the entry that led here named it
+    cw = chain_none();
+    int visited = climbing ? 1 : 0;
+    const bool probing = climbing || st_on_child(idx);
+    if (!probing && idx == 0) { st_from_root(S, bits, tok, idx, len); return 1; }
+
+    // what a hit in a block / the bigram table installs
+    auto follow_block = [&](const uint4 &e) {
+        len += 1;
+        if (e.y & SAMD_EB_ROOTCHILD) { idx = st_child_of(tok); return; }           // its edges live in the bigram table
+        idx = (int)(e.y & SAMD_EB_IDX_MASK);
+        if (e.y & SAMD_EB_HUB) cw.hub = e.z; else cw = chain_from_edge<W>(e.z);
+    };
+    // one bigram probe under (a, tok), conclusive: the child of a visited (the caller counted it), then either the edge or the root
+    auto bigram = [&](int a, uint4 e, uint32_t h, bool set_len) -> int {
+        bool hit = false;
+        for (uint32_t probes = 0; probes <= S.bigram_mask; probes++) {
+            if (W == 8) hit = (e.x & 0x3FFFFFFFu) == ((unsigned)a | ((unsigned)tok << 15)) && tok < 0x8000;
+            else hit = (e.x & 0x7FFFFFFFu) == (unsigned)a && (e.y & 0x7FFFFFFFu) == (unsigned)tok;
+            if (hit || e.x == 0xFFFFFFFFu) break;
+            h = (h + 1) & S.bigram_mask; e = S.bigram[h];
+        }
+        if (hit) {
+            if (set_len) {
+                const unsigned lb = W == 8 ? e.x >> 30 : (e.x >> 31) | ((e.y >> 31) << 1);
+                len = lb < 3 ? (int)lb + 1 : (int)S.root16[a].w;
+            }
+            len += 1;
+            const unsigned d = W == 8 ? e.y : e.z, extra = W == 8 ? e.z : e.w;
+            if (d & SAMD_EB_ROOTCHILD) { idx = st_child_of(tok); return 0; }
+            idx = (int)(d & SAMD_EB_IDX_MASK);
+            if (d & 0x80000000u) cw.hub = extra;
+            else if (W == 8) cw = chain_half<W>(e.z, e.w);
+            else cw = chain_first<W>(e.w);
+            return 0;
+        }
+        st_from_root(S, bits, tok, idx, len);                 // no edge: the child's suffix link is the root -- visited too
+        return 1;
+    };
+    // THE FIRST LOAD OF EVERY LANE IS ONE INSTRUCTION (a lock-step wave pays dependent phases, not loads): a bigram slot, a slot of the
+    // cursor's block, or the cursor's hot word
+    const int a0 = climbing ? ptok : -2 - idx;
+    const uint32_t hb = probing ? samd_bigram_hash(a0, tok) & S.bigram_mask : 0u;
+    const uint32_t p0 = my_ref ? samd_eb_hash(tok) & samd_eb_mask(my_ref) : 0u;
+    const uint4 *addr = probing ? S.bigram + hb : (my_ref ? S.blocks + samd_eb_base(my_ref) + p0 : S.hot + idx);
+    const uint4 first = *addr;
+    if (probing) {
+        visited += 1;                                          // the root child itself
+        return visited + bigram(a0, first, hb, climbing);
+    }
+    visited++;                                                 // the cursor's own state
+    FailHdr f;
+    if (my_ref) {                                              // a known hub: the probe decides
+        uint4 e = first;
+        if (block_find(S, my_ref, tok, p0, e)) { follow_block(e); return visited; }
+        f = fail_of_slot(S, e);
+    } else {
+        const uint4 h = first;
+        f = fail_of_hot(h);
+        if (h.y & SAMD_SINGLE) {
+            if ((int)h.z == tok) {                             // its only edge
+                idx = (int)h.w; len += 1;
+                if (h.y & SAMD_RUN) cw = chain_load(S, idx);
+                return visited;
+            }
+        } else if (f.kind == SAMD_FK_ROOT) {                   // a branching ROOT CHILD met by index: its edges are in the bigram table
+            const int a = (int)h.x;
+            const uint32_t h2 = samd_bigram_hash(a, tok) & S.bigram_mask;
+            return visited + bigram(a, S.bigram[h2], h2, false);
+        } else {                                               // a hub met by index: its hot word names its block
+            const unsigned ref = h.z;
+            const uint32_t p = samd_eb_hash(tok) & samd_eb_mask(ref);
+            uint4 e = S.blocks[samd_eb_base(ref) + p];
+            if (block_find(S, ref, tok, p, e)) { follow_block(e); return visited; }
+        }
+    }
+    // ---- the climb (static_sam.py:99-101): f describes the suffix link of the state just examined; one request per hop --------------
+    for (;;) {
+        visited++;
+        if (f.kind == SAMD_FK_ROOT) { len = 0; st_from_root(S, bits, tok, idx, len); return visited; }
+        if (f.kind == SAMD_FK_ROOTCHILD) {
+            const int a = (int)f.ref;
+            const uint32_t h2 = samd_bigram_hash(a, tok) & S.bigram_mask;
+            return visited + bigram(a, S.bigram[h2], h2, true);
+        }
+        len = (int)f.len;                                      // length <- states[link].length (a HUB header's always fits: the derivation
+        if (f.kind == SAMD_FK_HUB) {                           //  demotes a hub whose length overflows the slot field to STATE kind)
+            const unsigned ref = f.ref;
+            const uint32_t p = samd_eb_hash(tok) & samd_eb_mask(ref);
+            uint4 e = S.blocks[samd_eb_base(ref) + p];
+            if (block_find(S, ref, tok, p, e)) { follow_block(e); return visited; }
+            f = fail_of_slot(S, e);
+            continue;
+        }
+        // SAMD_FK_STATE: a plain state index -- its hot word is its only edge + its own fail header (or, for a hub the derivation demoted
+        // to this kind, its block reference)
+        const int p_idx = (int)f.ref;
+        const uint4 h = S.hot[p_idx];
+        if (!f.len_ok) len = S.nodes[p_idx].length & SAMD_LEN_MASK;
+        if (h.y & SAMD_SINGLE) {
+            if ((int)h.z == tok) {
+                idx = (int)h.w; len += 1;
+                if (h.y & SAMD_RUN) cw = chain_load(S, idx);
+                return visited;
+            }
+            f = fail_of_hot(h);
+        } else {
+            const unsigned ref = h.z;
+            const uint32_t p = samd_eb_hash(tok) & samd_eb_mask(ref);
+            uint4 e = S.blocks[samd_eb_base(ref) + p];
+            if (block_find(S, ref, tok, p, e)) { follow_block(e); return visited; }
+            f = fail_of_hot(h);
+        }
     }
 }
 

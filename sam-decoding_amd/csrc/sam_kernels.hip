@@ -6,6 +6,7 @@
 #include <cstring>
 #include <ctime>
 #include <vector>
+#include <hipcub/hipcub.hpp>
 #include "sam_device.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { samd_set_error("%s: %s", #x, hipGetErrorString(e_)); return SAMD_E_HIP; } } while (0)
@@ -21,6 +22,7 @@ static inline StaticDev static_view(const samd_static_t *s) {
     v.rc_bits = (const uint32_t *)s->d_rc_bits;
     v.ehash = (const uint4 *)s->d_ehash; v.edge_mask = s->n_ehash > 0 ? (uint32_t)(s->n_ehash - 1) : 0u;
     v.topk_cnt = (const int32_t *)s->d_topk_cnt;
+    v.hot = (const uint4 *)s->d_hot; v.blocks = s->d_hot ? (const uint4 *)s->d_blocks : nullptr; v.eb_tok_bits = samd_eb_tok_bits(s->vocab);
     return v;
 }
 
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void k_bg_count(const SamNode *__restrict__ no
 }
 __global__ __launch_bounds__(256) void k_bg_fill(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, const int32_t *__restrict__ root_next,
                                                  int vocab, const uint4 *__restrict__ chain, uint4 *__restrict__ root16, uint4 *__restrict__ table, uint32_t mask,
-                                                 uint32_t *__restrict__ rc_bits, int W, int with_hub) {
+                                                 uint32_t *__restrict__ rc_bits, int W, int with_hub, const uint32_t *__restrict__ bref) {
     const int tok = blockIdx.x * blockDim.x + threadIdx.x;
     if (tok >= vocab) return;
     const int dst = root_next[tok];
@@ -453,8 +455,13 @@ __global__ __launch_bounds__(256) void k_bg_fill(const SamNode *__restrict__ nod
     auto put = [&](int t, int d) {
         if (t < 0) return;
         uint32_t h = samd_bigram_hash(tok, t) & mask;
-        const uint4 c = d > 0 ? chain[d] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        const unsigned hub = (with_hub && d > 0 && !(nodes[d].length & SAMD_SINGLE)) ? 0x80000000u : 0u;     // dst is branching: it is in the edge table
+        uint4 c = d > 0 ? chain[d] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        unsigned hub = (with_hub && d > 0 && !(nodes[d].length & SAMD_SINGLE)) ? 0x80000000u : 0u;     // dst is branching: it is in the edge table
+        if (bref) {                                          // EDGE BLOCKS (round 6): hub = dst owns a block, whose reference takes the chain word's place;
+            hub = (d > 0 && bref[d]) ? 0x80000000u : 0u;     // a dst that is a root child is flagged (the cursor takes the unresolved form)
+            if (hub) c.x = bref[d];
+            if (d > 0 && nodes[d].link == 0) hub |= SAMD_EB_ROOTCHILD;
+        }
         if (W == 8) {
             const unsigned key = (unsigned)tok | ((unsigned)t << 15) | (lb << 30);
             for (;;) {
@@ -532,6 +539,89 @@ __global__ __launch_bounds__(256) void k_eh_fill(const SamNode *__restrict__ nod
     }
 }
 
+// ---- EDGE BLOCKS + HOT WORDS (samd_common.h, round 6) -------------------------------------------------------------------------------
+// slots of state s's block (0: none -- the root, root children, states with fewer than two edges); lengths / indices that do not fit raise `bad`
+__global__ __launch_bounds__(256) void k_eb_size(const SamNode *__restrict__ nodes, long long n, int per, uint32_t *__restrict__ sizes,
+                                                 unsigned long long *__restrict__ total, unsigned *__restrict__ bad) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long m = 0;
+    if (s < n) {
+        const SamNode &nd = nodes[s];
+        if ((unsigned)(nd.length & SAMD_LEN_MASK) > SAMD_EB_IDX_MASK - 1u) atomicOr(bad, 1u);
+        if (s >= 1 && nd.deg >= 2 && nd.link != 0) { m = 4; while (m < (unsigned long long)per * (unsigned)nd.deg) m <<= 1; }
+        if (m > (1ull << 26)) { atomicOr(bad, 2u); m = 0; }
+        sizes[s] = (uint32_t)m;
+    }
+    unsigned long long c = m ? 1ull : 0ull;
+    for (int o = 32; o > 0; o >>= 1) { m += __shfl_xor(m, o); c += __shfl_xor(c, o); }
+    if ((threadIdx.x & 63) == 0 && m) { atomicAdd(total, m); atomicAdd(total + 1, c); }
+}
+// block references from the sizes and their exclusive prefix sums (in place over the offsets); rctok[root child] = its token
+__global__ __launch_bounds__(256) void k_eb_ref(const uint32_t *__restrict__ sizes, uint32_t *__restrict__ off_to_ref, long long n) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t m = sizes[s];
+    off_to_ref[s] = m ? (off_to_ref[s] | ((uint32_t)(31 - __clz(m)) << 27)) : 0u;
+}
+__global__ __launch_bounds__(256) void k_eb_rctok(const int32_t *__restrict__ root_next, int vocab, int32_t *__restrict__ rctok) {
+    const int tok = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tok < vocab) { const int d = root_next[tok]; if (d > 0) rctok[d] = tok; }
+}
+// the fail header of state s: what its suffix link is and what a hop there needs (samd_common.h); lmax = the largest length the field holds
+__device__ __forceinline__ void eb_fail(const SamNode *__restrict__ nodes, const uint32_t *__restrict__ bref, const int32_t *__restrict__ rctok, long long s,
+                                        unsigned lmax, unsigned &kind, unsigned &ref, unsigned &len) {
+    const int p = nodes[s].link;
+    if (p <= 0) { kind = SAMD_FK_ROOT; ref = 0u; len = 0u; return; }
+    if (nodes[p].link == 0) { kind = SAMD_FK_ROOTCHILD; ref = (unsigned)rctok[p]; len = 0u; return; }
+    const unsigned L = (unsigned)(nodes[p].length & SAMD_LEN_MASK);
+    if (bref[p] && L < lmax) { kind = SAMD_FK_HUB; ref = bref[p]; len = L; return; }
+    kind = SAMD_FK_STATE; ref = (unsigned)p; len = L < lmax ? L : lmax;          // lmax = "read it from the node"
+}
+// one thread per state: its hot word, and -- for a state that owns a block -- every slot of the block (header everywhere, then the edges)
+__global__ __launch_bounds__(256) void k_eb_fill(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, long long n, const uint4 *__restrict__ chain,
+                                                 const uint32_t *__restrict__ bref, const int32_t *__restrict__ rctok, int tok_bits,
+                                                 uint4 *__restrict__ hot, uint4 *__restrict__ blocks) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int *w = reinterpret_cast<const int *>(nodes + s);
+    if (s == 0) { hot[0] = make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu); return; }
+    unsigned kind, ref, len;
+    eb_fail(nodes, bref, rctok, s, SAMD_EB_IDX_MASK, kind, ref, len);
+    const bool single = (w[1] & SAMD_SINGLE) != 0;
+    const unsigned flags = (unsigned)w[1] & (unsigned)(SAMD_SINGLE | SAMD_RUN);
+    hot[s] = make_uint4(kind == SAMD_FK_ROOT ? (unsigned)rctok[s] : ref, len | (kind << 27) | flags, single ? (unsigned)w[2] : bref[s], (unsigned)w[3]);
+    const uint32_t my = bref[s];
+    if (!my) return;
+    const unsigned tmask = (1u << tok_bits) - 1u, lmax = (1u << (32 - tok_bits)) - 1u;
+    eb_fail(nodes, bref, rctok, s, lmax, kind, ref, len);                          // (the slot's length field is narrower than the hot word's)
+    const unsigned base = samd_eb_base(my), bmask = samd_eb_mask(my);
+    const unsigned x_empty = tmask | (len << tok_bits), y_hdr = kind << SAMD_EB_KIND_SHIFT;
+    uint4 *blk = blocks + base;
+    for (unsigned k = 0; k <= bmask; k++) blk[k] = make_uint4(x_empty, y_hdr, 0xFFFFFFFFu, ref);
+    auto put = [&](int t, int d) {
+        if (t < 0 || d < 0 || (unsigned)t >= tmask) return;
+        unsigned p = samd_eb_hash(t) & bmask;
+        for (unsigned probes = 0; probes <= bmask; probes++) {
+            const unsigned cur = blk[p].x & tmask;
+            if (cur == (unsigned)t) return;                                         // (the spill head repeats ranks 5..7)
+            if (cur == tmask) {
+                const unsigned dref = bref[d];
+                unsigned y = ((unsigned)d & SAMD_EB_IDX_MASK) | y_hdr | (dref ? SAMD_EB_HUB : 0u) | (nodes[d].link == 0 && d > 0 ? SAMD_EB_ROOTCHILD : 0u);
+                blk[p] = make_uint4((unsigned)t | (len << tok_bits), y, dref ? dref : chain[d].x, ref);
+                return;
+            }
+            p = (p + 1) & bmask;
+        }
+    };
+    const int deg = w[5];
+    for (int k = 0; k < SAMD_INLINE_EDGES; k++) put(w[SAMD_EDGE_WORD(k)], w[SAMD_EDGE_WORD(k) + 1]);
+    if (deg > SAMD_INLINE_EDGES) {
+        const SamEdge *sp = spill + w[14];
+        const uint32_t slots = samd_spill_slots(deg);
+        for (uint32_t k = 0; k < SAMD_SPILL_HEAD + slots; k++) put(sp[k].tok, sp[k].dst);
+    }
+}
+
 static long long table_budget_bytes() {
     long long budget = 8ll << 30;
     size_t free_b = 0, total_b = 0;
@@ -585,6 +675,63 @@ static int derive_edge_hash(samd_static_t *s, hipStream_t st, int per_arg) {
     return SAMD_OK;
 }
 
+// hot words + edge blocks (samd_common.h, round 6).  On success *out_bref = the per-state block references (device, owned by the caller: the
+// bigram table's fill needs them, then they go).  An accelerator like the tables it replaces: whenever something does not fit -- memory, a
+// length or an index beyond 27 bits, more than 2^27 slots -- the handle simply has none and the walks use the edge table.  SAMD_EDGE_BLOCKS=0
+// switches it off (A/B, tests).
+static int derive_edge_blocks(samd_static_t *s, hipStream_t st, int per_arg, uint32_t **out_bref) {
+    *out_bref = nullptr;
+    const char *env = getenv("SAMD_EDGE_BLOCKS");                     // read at every derivation: tests upload the same automaton every way
+    if (s->d_hot) { (void)hipFree(s->d_hot); s->d_hot = nullptr; }
+    if (s->d_blocks) { (void)hipFree(s->d_blocks); s->d_blocks = nullptr; }
+    s->n_block_slots = s->n_block_states = 0;
+    const long long n = (long long)s->n_states;
+    const int tok_bits = samd_eb_tok_bits(s->vocab);
+    if ((env && env[0] == '0') || !s->d_chain || n < 2 || n > (long long)SAMD_EB_IDX_MASK || tok_bits > 24 || s->vocab < 1 || s->vocab > (1 << 24)) return SAMD_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    uint32_t *d_sizes = nullptr, *d_bref = nullptr; int32_t *d_rctok = nullptr; unsigned long long *d_total = nullptr; unsigned *d_bad = nullptr; void *d_tmp = nullptr;
+    void *d_hot = nullptr, *d_blk = nullptr;
+    auto cleanup = [&](bool keep_bref) {
+        if (d_sizes) (void)hipFree(d_sizes); if (d_rctok) (void)hipFree(d_rctok); if (d_total) (void)hipFree(d_total);
+        if (d_bad) (void)hipFree(d_bad); if (d_tmp) (void)hipFree(d_tmp);
+        if (!keep_bref && d_bref) { (void)hipFree(d_bref); d_bref = nullptr; }
+    };
+    auto none = [&]() { (void)hipGetLastError(); cleanup(false); if (d_hot) (void)hipFree(d_hot); if (d_blk) (void)hipFree(d_blk); return SAMD_OK; };
+    if (hipMalloc((void **)&d_sizes, (size_t)n * 4) != hipSuccess || hipMalloc((void **)&d_bref, (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void **)&d_rctok, (size_t)n * 4) != hipSuccess || hipMalloc((void **)&d_total, 16) != hipSuccess || hipMalloc((void **)&d_bad, 4) != hipSuccess) return none();
+    int per = table_slots_per_entry(per_arg);
+    const long long budget = table_budget_bytes();
+    unsigned long long total[2] = {0, 0};
+    for (;;) {
+        unsigned bad = 0;
+        if (hipMemsetAsync(d_total, 0, 16, st) != hipSuccess || hipMemsetAsync(d_bad, 0, 4, st) != hipSuccess) return none();
+        hipLaunchKernelGGL(k_eb_size, dim3(blocks), dim3(256), 0, st, s->d_nodes, n, per, d_sizes, d_total, d_bad);
+        if (hipMemcpyAsync(total, d_total, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) return none();
+        if (bad) return none();
+        if (((long long)total[0] * 16 > budget || total[0] > (unsigned long long)SAMD_EB_IDX_MASK) && per > 2) { per = per / 2 < 2 ? 2 : per / 2; continue; }
+        break;
+    }
+    if ((long long)total[0] * 16 > budget || total[0] > (unsigned long long)SAMD_EB_IDX_MASK) return none();
+    size_t tmp_bytes = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes, d_bref, (int)n, st) != hipSuccess) return none();
+    if (hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) return none();
+    if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_sizes, d_bref, (int)n, st) != hipSuccess) return none();
+    hipLaunchKernelGGL(k_eb_ref, dim3(blocks), dim3(256), 0, st, d_sizes, d_bref, n);
+    if (hipMemsetAsync(d_rctok, 0xFF, (size_t)n * 4, st) != hipSuccess) return none();
+    hipLaunchKernelGGL(k_eb_rctok, dim3((unsigned)((s->vocab + 255) / 256)), dim3(256), 0, st, s->d_root, (int)s->vocab, d_rctok);
+    if (hipMalloc(&d_hot, (size_t)n * 16) != hipSuccess || hipMalloc(&d_blk, (size_t)(total[0] ? total[0] : 1) * 16) != hipSuccess) return none();
+    hipLaunchKernelGGL(k_eb_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, n, (const uint4 *)s->d_chain, d_bref, d_rctok, tok_bits, (uint4 *)d_hot, (uint4 *)d_blk);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipGetLastError(); cleanup(false); (void)hipFree(d_hot); (void)hipFree(d_blk);
+        samd_set_error("edge block derivation failed"); return SAMD_E_HIP;
+    }
+    s->d_hot = d_hot; s->d_blocks = d_blk; s->n_block_slots = (int64_t)total[0]; s->n_block_states = (int64_t)total[1];
+    cleanup(true);
+    *out_bref = d_bref;
+    return SAMD_OK;
+}
+
 static int derive_topk_counts(samd_static_t *s, hipStream_t st) {
     static const bool enabled = [] { const char *e = getenv("SAMD_TOPK_COUNTS"); return !(e && e[0] == '0'); }();       // A/B switch, read once
     if (!enabled || s->kind != SAMD_KIND_COUNT) return SAMD_OK;
@@ -595,7 +742,7 @@ static int derive_topk_counts(samd_static_t *s, hipStream_t st) {
     return SAMD_OK;
 }
 
-static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg = 0) {
+static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg = 0, const uint32_t *d_bref = nullptr) {
     static const bool enabled = [] { const char *e = getenv("SAMD_ROOT_HASH"); return !(e && e[0] == '0'); }();      // A/B switch, read once
     if (s->d_root16) { (void)hipFree(s->d_root16); s->d_root16 = nullptr; }
     if (s->d_d1hash) { (void)hipFree(s->d_d1hash); s->d_d1hash = nullptr; }
@@ -640,7 +787,7 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg =
         if (rc == SAMD_OK && (hipMemsetAsync(s->d_d1hash, 0xFF, (size_t)slots * 16, st) != hipSuccess || hipMemsetAsync(s->d_rc_bits, 0, bit_bytes, st) != hipSuccess)) rc = SAMD_E_HIP;
         if (rc == SAMD_OK) {
             hipLaunchKernelGGL(k_bg_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, (const uint4 *)s->d_chain, (uint4 *)s->d_root16,
-                               (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, samd_chain_w(vocab), s->d_ehash ? 1 : 0);
+                               (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, samd_chain_w(vocab), s->d_ehash ? 1 : 0, d_bref);
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
         }
         if (rc == SAMD_OK) s->n_d1hash = slots;
@@ -655,6 +802,24 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg =
     return SAMD_OK;
 }
 
+// the derived walk tables in the order they depend on each other: edge blocks (+ hot words) when they fit, else the edge table; then the
+// bigram table, whose entries name a target's block.  The block path needs the bigram table: without one the blocks go and the edge table
+// (which does not) comes back.
+static int derive_walk_tables(samd_static_t *s, hipStream_t st, int per_arg) {
+    uint32_t *d_bref = nullptr;
+    int rc = derive_edge_blocks(s, st, per_arg, &d_bref);
+    if (rc == SAMD_OK && !s->d_blocks) rc = derive_edge_hash(s, st, per_arg);
+    else if (rc == SAMD_OK && s->d_ehash) { (void)hipFree(s->d_ehash); s->d_ehash = nullptr; s->n_ehash = 0; }
+    if (rc == SAMD_OK) rc = derive_root_hash(s, st, per_arg, d_bref);
+    if (d_bref) (void)hipFree(d_bref);
+    if (rc == SAMD_OK && s->d_blocks && !s->d_d1hash) {
+        (void)hipFree(s->d_hot); (void)hipFree(s->d_blocks); s->d_hot = s->d_blocks = nullptr; s->n_block_slots = s->n_block_states = 0;
+        rc = derive_edge_hash(s, st, per_arg);
+        if (rc == SAMD_OK) rc = derive_root_hash(s, st, per_arg, nullptr);
+    }
+    return rc;
+}
+
 int samd_static_derive_chain(samd_static_t *s, void *stream) {
     if (!s || !s->uploaded || !s->d_nodes) return SAMD_E_INVALID;
     if (!s->d_chain && hipMalloc(&s->d_chain, (size_t)s->n_states * 16) != hipSuccess) { s->d_chain = nullptr; samd_set_error("hipMalloc(chain words) failed"); return SAMD_E_HIP; }
@@ -663,8 +828,7 @@ int samd_static_derive_chain(samd_static_t *s, void *stream) {
     else hipLaunchKernelGGL(k_build_chain<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s->d_nodes, (long long)s->n_states, (uint4 *)s->d_chain);
     LAUNCHCHK();
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) { samd_set_error("chain-word derivation failed"); return SAMD_E_HIP; }
-    int rc = derive_edge_hash(s, (hipStream_t)stream, 0);
-    if (rc == SAMD_OK) rc = derive_root_hash(s, (hipStream_t)stream);
+    const int rc = derive_walk_tables(s, (hipStream_t)stream, 0);
     return rc != SAMD_OK ? rc : derive_topk_counts(s, (hipStream_t)stream);
 }
 
@@ -672,8 +836,7 @@ int samd_static_set_bigram_slots(samd_static_t *s, int32_t slots_per_pair, void 
     if (!s || !s->uploaded || !s->d_nodes || slots_per_pair < 0) { samd_set_error("samd_static_set_bigram_slots: invalid argument"); return SAMD_E_INVALID; }
     if (!s->d_chain) return SAMD_OK;                                           // no derived tables on this handle: nothing to re-size
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return SAMD_E_HIP;      // nothing may still read the tables that are replaced
-    const int rc = derive_edge_hash(s, (hipStream_t)stream, slots_per_pair);             // (both tables follow the same knob)
-    return rc != SAMD_OK ? rc : derive_root_hash(s, (hipStream_t)stream, slots_per_pair);
+    return derive_walk_tables(s, (hipStream_t)stream, slots_per_pair);                   // (every table follows the same knob)
 }
 
 int samd_static_walk(const samd_static_t *sam, int32_t *d_cursors, const int32_t *d_tokens, int32_t B, int32_t T,

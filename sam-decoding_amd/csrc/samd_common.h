@@ -73,6 +73,17 @@ SAMD_HD static inline uint32_t samd_edge_hash(int32_t state, int32_t tok) {
 SAMD_HD static inline uint32_t samd_spill_hash(int32_t tok, uint32_t slots) {
     return (((uint32_t)tok * 0x9E3779B1u) >> 7) & (slots - 1);
 }
+// EDGE BLOCKS (StaticDev): kinds of a fail header, the pieces of a block reference, the first slot a token probes inside a block
+enum { SAMD_FK_ROOT = 0, SAMD_FK_ROOTCHILD = 1, SAMD_FK_HUB = 2, SAMD_FK_STATE = 3 };
+#define SAMD_EB_IDX_MASK 0x07FFFFFFu          // 27 bits: state indices, first slots, lengths in hot words
+#define SAMD_EB_HUB 0x08000000u               // slot.y: dst owns a block (slot.z = its reference)
+#define SAMD_EB_KIND_SHIFT 28                 // slot.y / hot.y >> 27: kind(link)  (slot.y uses bits 28-29, hot.y bits 27-28)
+#define SAMD_EB_ROOTCHILD 0x40000000u         // slot.y / bigram entry: dst is the root child of the probed token
+SAMD_HD static inline uint32_t samd_eb_base(uint32_t ref) { return ref & SAMD_EB_IDX_MASK; }
+SAMD_HD static inline uint32_t samd_eb_mask(uint32_t ref) { return (1u << (ref >> 27)) - 1u; }
+SAMD_HD static inline uint32_t samd_eb_hash(int32_t tok) { uint32_t h = (uint32_t)tok * 0x9E3779B1u; return h ^ (h >> 15); }
+// bits of a block slot's x word that hold the token: the smallest width whose all-ones value is not a token id
+SAMD_HD static inline int samd_eb_tok_bits(int64_t vocab) { int b = 8; while (b < 31 && ((int64_t)1 << b) - 1 < vocab) b++; return b; }
 
 // device view of a static automaton
 struct StaticDev {
@@ -111,6 +122,33 @@ struct StaticDev {
     // only edge of a non-branching state) and its probe together: one round per hop.  The bigram table's entries carry the same hub bit.
     const uint4 *ehash;
     uint32_t edge_mask;
+    // EDGE BLOCKS + HOT WORDS (device-only, derived at upload; may be null; round 6: they REPLACE the edge table when they fit).  On a
+    // natural-language-like automaton the edge-table walk still paid TWO requests per hop of a climb (the hop target's node word 0 for its
+    // link and length + the probe of its edges) and a node word after every miss at a hub: 0.76-0.93 requests per visited state against
+    // 0.37 on the headline corpus (profiles/r05_walk_sweep.md).  Here every branching state below the root children owns a BLOCK of 16-byte
+    // slots (a power of two >= slots-per-entry x degree, at least 4; linear probing inside the block) and EVERY slot of a block -- used or
+    // empty -- carries the owning state's FAIL HEADER: what transfer_state needs when the token is not there (static_sam.py:99-101):
+    //   slot.x = tok | len(link) << tok_bits        tok all-ones = empty; len all-ones = "does not fit": read it from the node
+    //   slot.y = dst (27 bits) | hub(dst) << 27 | kind(link) << 28 | rootchild(dst) << 30
+    //   slot.z = first entries of chain[dst] (as the edge table), or the BLOCK REFERENCE of dst when hub(dst)
+    //   slot.w = ref(link): by kind -- 0 ROOT: nothing; 1 ROOTCHILD: the child's token a (the hop is one bigram probe (a, tok), conclusive);
+    //            2 HUB: the link's block reference (the hop is one probe of that block: hit, or its header names the next hop);
+    //            3 STATE: the link's index (the hop reads hot[link]: its only edge + its own fail header)
+    //   block reference = first slot (27 bits) | log2(slots) << 27   (never 0: a block has >= 4 slots)
+    // so a probe -- hit or miss -- is ONE 16-byte request that also answers "where next", and a climb costs one request per hop whatever
+    // the hop target is.  rootchild(dst): dst is the root child of the probed token (its edges live in the bigram table; the cursor takes
+    // the unresolved form idx = -2 - tok).  Root children own no block.
+    // hot[s] (16 B per state) replaces node word 0 on this path:
+    //   hot.x = ref(link(s)) as above -- for a root child (kind ROOT) its own TOKEN instead: a branching root child met by index probes the
+    //           bigram table under it
+    //   hot.y = len(link(s)) (27 bits) | kind(link) << 27 | SAMD_RUN | SAMD_SINGLE (the node's flag bits, same positions)
+    //   hot.z = e0.tok (SAMD_SINGLE) or the state's own block reference (branching; 0 for a root child)      hot.w = e0.dst
+    // Derivation needs every length < 2^27, every state index < 2^27 and all blocks within 2^27 slots (2 GB); otherwise -- or when the
+    // device cannot spare the memory, or with SAMD_EDGE_BLOCKS=0 -- the walks keep the edge table.  Results are identical by construction
+    // and by test (tests/test_gpu_sam.py: traces, cursors and visited-state counts against the oracle and against the other two paths).
+    const uint4 *hot;
+    const uint4 *blocks;
+    int32_t eb_tok_bits;        // bits of slot.x that hold the token (the rest: len(link))
     // TOP-K COUNTS (device-only, derived at upload; may be null): topk_cnt[8 s + k] = cnt_endpos of state s's rank-k successor, the
     // numerators of the best-first tree's child probabilities (static_sam.py:205-210).  Without it an expansion is two dependent round
     // trips (the parent's node for the edges, then the children's nodes for their counts); with it one.
@@ -192,6 +230,8 @@ struct samd_static {
     int64_t n_d1hash;           // the bigram table's slots (a power of two)
     void *d_ehash;              // the edge table of the branching states (StaticDev); owned by the handle
     int64_t n_ehash;            // its slots (a power of two)
+    void *d_hot, *d_blocks;     // hot words + edge blocks (StaticDev, round 6); owned by the handle; when present, d_ehash is not derived
+    int64_t n_block_slots, n_block_states;
 };
 
 // sam_kernels.hip: (re)derive the chain words from the device image; called by upload / adopt and lazily by the walks

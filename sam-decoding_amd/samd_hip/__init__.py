@@ -78,6 +78,7 @@ _PROTOS = {
     "samd_static_info": (C.c_int, [_VP, _VP]),
     "samd_static_from_pickle": (C.c_int, [C.c_char_p, _I32, _VP, _VP]),
     "samd_static_derived_info": (C.c_int, [_VP, _VP]),
+    "samd_static_edge_blocks_info": (C.c_int, [_VP, _VP]),
     "samd_static_set_bigram_slots": (C.c_int, [_VP, _I32, _VP]),
     "samd_static_export": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "samd_static_device_image": (C.c_int, [_VP, _VP, _VP]),
@@ -331,7 +332,11 @@ class StaticAutomaton:
         out = (C.c_int64 * 6)()
         check(lib().samd_static_derived_info(self._h, out))
         d = dict(zip(("chain_bytes", "bigram_bytes", "topk_count_bytes", "bigram_slots", "edge_table_bytes", "edge_table_slots"), list(out)))
-        d["resident_bytes"] = self.info()["device_bytes"] + d["chain_bytes"] + d["bigram_bytes"] + d["topk_count_bytes"] + d["edge_table_bytes"]      # image + derived, per replica
+        eb = (C.c_int64 * 4)()                                       # round 6: hot words + edge blocks (they replace the edge table when they fit)
+        check(lib().samd_static_edge_blocks_info(self._h, eb))
+        d.update(zip(("hot_word_bytes", "edge_block_bytes", "edge_block_slots", "edge_block_states"), list(eb)))
+        d["resident_bytes"] = (self.info()["device_bytes"] + d["chain_bytes"] + d["bigram_bytes"] + d["topk_count_bytes"] + d["edge_table_bytes"]
+                               + d["hot_word_bytes"] + d["edge_block_bytes"])      # image + derived, per replica
         return d
 
     def set_bigram_slots(self, slots_per_pair=0):

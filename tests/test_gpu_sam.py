@@ -371,7 +371,9 @@ def test_bigram_table_size_changes_nothing_but_bytes(vocab):
             assert info["bigram_slots"] * 2 == pairs_x4 or info["bigram_slots"] == 1024
         else:
             assert info["bigram_slots"] == pairs_x4 * per_pair // 4
-        assert info["resident_bytes"] == prod.info()["device_bytes"] + info["chain_bytes"] + info["bigram_bytes"] + info["topk_count_bytes"] + info["edge_table_bytes"]
+        assert info["resident_bytes"] == (prod.info()["device_bytes"] + info["chain_bytes"] + info["bigram_bytes"] + info["topk_count_bytes"] + info["edge_table_bytes"]
+                                          + info["hot_word_bytes"] + info["edge_block_bytes"])
+        assert (info["edge_block_slots"] > 0) != (info["edge_table_slots"] > 0) or info["edge_block_states"] == 0       # blocks REPLACE the edge table
         res = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
         v = torch.zeros(1, dtype=torch.int64, device="cuda")
         prod.lookup_batch(root, d_toks, res, visited=v)
@@ -391,7 +393,9 @@ def test_static_walk_zipf_corpus_with_deep_hubs(vocab, n_tok, monkeypatch):
     """a natural-language-like corpus (bench.synth_corpus_zipf: Zipfian vocabulary, hubs of degree >> 5 at depth 1-4): the EDGE TABLE path of
     the walk (round 5: one probe per transition out of a branching state, node word 0 + probe together on every hop of a climb) against the
     oracle -- every (index, length) of every stream, the visited-state count state for state, cursors carried over a second pass -- and
-    against the same automaton uploaded WITHOUT the table (SAMD_EDGE_TABLE=0)."""
+    against the same automaton uploaded WITHOUT the table (SAMD_EDGE_TABLE=0).  Round 6: the default upload walks through EDGE BLOCKS and
+    HOT WORDS (every slot of a branching state's block carries its fail header: one request per hop of a climb); the same automaton is
+    uploaded with SAMD_EDGE_BLOCKS=0 (the round-5 edge table) and with both switched off, and all three must agree in everything."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
@@ -400,7 +404,8 @@ def test_static_walk_zipf_corpus_with_deep_hubs(vocab, n_tok, monkeypatch):
     ora = O.StaticSAM.build(docs, 2)
     prod = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
     info = prod.derived_info()
-    assert info["edge_table_slots"] >= 1024 and info["edge_table_bytes"] == 16 * info["edge_table_slots"]
+    assert info["edge_table_slots"] == 0 and info["edge_block_states"] > 20 and info["edge_block_bytes"] == 16 * info["edge_block_slots"]
+    assert info["edge_block_slots"] >= 4 * info["edge_block_states"] and info["hot_word_bytes"] == 16 * prod.info()["n_states"]
     e = ora.export()
     assert int(((e["deg"] > 5) & (e["length"] >= 2)).sum()) > 20                    # hubs below the root children exist
     rng = np.random.default_rng(vocab)
@@ -448,16 +453,23 @@ def test_static_walk_zipf_corpus_with_deep_hubs(vocab, n_tok, monkeypatch):
         sess.reset()
         sess.static_walk(prod, dev(toks[:, b].copy()), T, commit=True, d_out=out)
         assert out.cpu().tolist() == [int(got[T - 1, b, 0]), int(got[T - 1, b, 1])]
-    # and without the table: identical traces and counts
-    monkeypatch.setenv("SAMD_EDGE_TABLE", "0")
-    plain = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
-    assert plain.derived_info()["edge_table_slots"] == 0
-    cur3 = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
-    trace3 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
-    v3 = torch.zeros(1, dtype=torch.int64, device="cuda")
-    plain.walk(cur3, dev(toks), commit=True, trace=trace3)
-    plain.lookup_batch(torch.zeros((B, 2), dtype=torch.int32, device="cuda"), dev(toks), res, visited=v3)
-    assert torch.equal(trace3, trace) and torch.equal(cur3, cur) and int(v3.item()) == int(visited.item())
+    # the round-5 edge table instead of the blocks, then neither: identical traces, cursors and counts
+    for blocks_env, table_env in (("0", "1"), ("0", "0")):
+        monkeypatch.setenv("SAMD_EDGE_BLOCKS", blocks_env)
+        monkeypatch.setenv("SAMD_EDGE_TABLE", table_env)
+        plain = samd_hip.StaticAutomaton.build(docs, 2, 0).upload()
+        pinfo = plain.derived_info()
+        assert pinfo["edge_block_slots"] == 0 and pinfo["hot_word_bytes"] == 0 and (pinfo["edge_table_slots"] >= 1024) == (table_env == "1")
+        cur3 = torch.zeros((B, 2), dtype=torch.int32, device="cuda")
+        trace3 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+        v3 = torch.zeros(1, dtype=torch.int64, device="cuda")
+        plain.walk(cur3, dev(toks), commit=True, trace=trace3)
+        plain.lookup_batch(torch.zeros((B, 2), dtype=torch.int32, device="cuda"), dev(toks), res, visited=v3)
+        assert torch.equal(trace3, trace) and torch.equal(cur3, cur) and int(v3.item()) == int(visited.item()), (blocks_env, table_env)
+        cur4 = cur.clone()
+        trace4 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+        plain.walk(cur4, rev, commit=True, trace=trace4)
+        assert torch.equal(trace4, trace2) and torch.equal(cur4, cur2)
 
 
 def test_static_walk_empty_and_ragged():
