@@ -156,8 +156,10 @@ def synth_request_summarization(rng, docs, vocab=VOCAB, prompt_range=SUMM_PROMPT
                       (stock phrases the static automaton knows; geometric, mean `article_copy_mean`)
       continuation  = `new_range` tokens: with probability `p_span` a span copied from the prompt (geometric, mean `span_mean`; the judge's
                       12-24), else glue -- a few tokens (geometric, mean `glue_mean`) of noise or of a copied corpus span
-    Returns (prompt, prompt + continuation, max_new_tokens).  Nothing here is tuned to an accept length; tests/test_bench_workloads_cpu.py
-    records what the reference's rule (oracle) does with it."""
+    Returns (prompt, prompt + continuation, max_new_tokens).  The GENERATOR has no accept-length knob, but the two parameter sets it is run
+    with (SUMM_PROFILES) do: `readme_mat`'s copy rate was CHOSEN so that the reference's rule accepts the ~3.1 tokens per step README.md's
+    published speed-ups imply (a calibrated synthetic source -- its speed-up is a consequence of that choice); `copy_heavy` follows the verdict's
+    wording.  tests/test_bench_workloads_cpu.py records what the reference's rule (oracle) does with both."""
     n_docs, doc_len = docs.shape
     P = int(rng.integers(prompt_range[0], prompt_range[1] + 1))
     new = int(rng.integers(new_range[0], new_range[1] + 1))
@@ -736,6 +738,11 @@ def summarization_leg(model, ar, lm, docs, breakdown, n_requests, seed=2000, max
             "source": dict(params, prompt_tokens=list(SUMM_PROMPT_RANGE), max_new_tokens=list(SUMM_NEW_RANGE), requests=n_requests, seed=seed),
             "speculative": sp, "autoregressive": arr,
             # BOTH sides include their prefill, as the reference's tokens/s does (new_tokens / wall_time per turn)
+            # readme_mat: a CALIBRATED synthetic source (see SUMM_PROFILES) -- the speed-up follows from the accept length it was tuned to; what is
+            # MEASURED is the step-cost ratio, the request-start share and the accept lengths by draft type beside it
+            "calibrated_synthetic_source": name == "readme_mat",
+            "oracle_accept_length_target": 3.1 if name == "readme_mat" else None,
+            "step_cost_ratio_vs_ar": round(sp["decode_ms_per_step"] / arr["decode_ms_per_step"], 4),
             "speedup_vs_ar": round(sp["tokens_per_s"] / arr["tokens_per_s"], 3),
             "speedup_vs_ar_decode_only": round((sp["new_tokens"] / (sp["wall_ms"] * (1 - sp["request_start_share_of_timed_region"])))
                                                / (arr["new_tokens"] / (arr["wall_ms"] * (1 - arr["request_start_share_of_timed_region"]))), 3),
@@ -746,6 +753,8 @@ def summarization_leg(model, ar, lm, docs, breakdown, n_requests, seed=2000, max
         }
     out["north_star_target"] = ">= 2.5x over autoregressive on Spec-Bench summarization (BASELINE.json); the reference publishes 2.43x on an A6000 (README.md:53)"
     out["quoted_profile"] = "readme_mat"
+    out["how_to_read"] = ("readme_mat is calibrated to the accept length README.md's speed-ups imply (speedup_vs_ar is then a projection through measured step "
+                          "costs); copy_heavy is the verdict's wording; measured in both: step_cost_ratio_vs_ar, request_start_share_of_timed_region, draft_steps")
     r = getattr(lm, "runner", lm)
     if hasattr(r, "prefill_plan_summary"):
         out["prefill"] = {"projection_row_splits": r.prefill_plan_summary(), "attention_rows_padded_to": getattr(r, "PF_ATTN_PAD", None)}
@@ -908,6 +917,14 @@ def main():
     auto = parallel.broadcast_static(auto, src=0) if world > 1 else auto.upload()
     torch.cuda.synchronize()
     broadcast_ms = (time.perf_counter() - t_bc) * 1e3          # world > 1: RCCL broadcast of the image + adopt; world 1: host -> HBM upload
+    # the part of it that is NOT moving the image: re-deriving the walk tables on this rank.  world > 1: clocked inside
+    # broadcast_static around the adopt; world 1: the walk tables derived once more, clocked (the upload made them once already)
+    dist_split = getattr(auto, "distribution", None)
+    if dist_split is None:
+        t_rd = time.perf_counter()
+        auto.set_bigram_slots(0)
+        torch.cuda.synchronize()
+        dist_split = {"broadcast_ms": None, "derive_ms": round((time.perf_counter() - t_rd) * 1e3, 2)}
     sam_info = auto.info()
     derived_decode = auto.derived_info()                       # what the decode loop runs on: the default table (4 slots per pair)
     sam = SO.sam.StaticSAM._from_automaton(auto)
@@ -1056,7 +1073,8 @@ def main():
             ("eval_posterior_us", "dyn_update_us", "static_transfer_us", "lookup_draft_buffers_us"))})
 
     # SUM of tokens, MAX of time over ranks; every rank's own wait for the static automaton (broadcast + adopt) travels along
-    tokens_total, dt_max, per_rank = parallel.reduce_throughput(tokens, dt, extra={"static_sam_distribution_ms": broadcast_ms})
+    tokens_total, dt_max, per_rank = parallel.reduce_throughput(tokens, dt, extra={"static_sam_distribution_ms": broadcast_ms,
+                                                                                   "static_sam_derive_ms": dist_split["derive_ms"]})
 
     # context, outside the timed region: a short timed window (the driver's 20 steps = ~46 tokens inside one request) samples the
     # accepted-token process with +-20 % noise; the same request stream continued for LONG_RUN_STEPS more steps gives the rate the
@@ -1129,6 +1147,10 @@ def main():
                 roof["traffic"] = live
         request_rate(roof)
         roof["corpus_sweep"] = corpus_sweep(walk_source_sha16())
+        # the same launch at the PRODUCT's table size (4 slots per entry: what a request's own walks run on); VERDICT r05 #3c
+        roof_default, _ = walk_roofline(auto, docs, np.random.default_rng(7), args.walk_streams, args.walk_tokens, 20, args.corpus_tokens, slots_per_pair=0)
+        roof["at_default_slots"] = {k: roof_default[k] for k in ("frac", "achieved", "launch_ms", "derived_bytes", "visited_states")}
+        auto.set_bigram_slots(0)
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(flat, off, docs, cfg, toks_walk)    # rank 0 at N = 1 only
 
         n_steps = sum(v[0] for v in stats.values())
@@ -1159,6 +1181,9 @@ def main():
             "step_accounting": step_accounting(dt, args.steps, turnover_timed, bucket_hist, breakdown),
             "static_sam_distribution": {"how": "RCCL broadcast from rank 0 + samd_static_adopt_device" if world > 1 else "host image -> HBM upload",
                                         "ms": round(broadcast_ms, 2), "ms_per_rank": [r["static_sam_distribution_ms"] for r in per_rank],
+                                        # of which (world > 1) / beside which (world 1): re-deriving the walk tables from the image, per rank
+                                        "derive_tables_ms_per_rank": [r.get("static_sam_derive_ms") for r in per_rank],
+                                        "broadcast_only_ms": dist_split["broadcast_ms"],
                                         "bytes": int(sam_info["device_bytes"])},
             # samd[EAGLE2] / samd[EAGLE] run a RANDOM-INIT draft head (no EAGLE weights exist on the box): its drafts are noise, so
             # `value` and `speedup_vs_ar` of such a run price the plugin PATH (head forwards + 63-node verify), they are not a result of
@@ -1201,6 +1226,30 @@ def main():
                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(runner.weight_bytes() / (breakdown["8"]["step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                "alg_bytes_per_step": int(runner.weight_bytes()), "step_ms": breakdown["8"]["step_ms"]} if "8" in breakdown else None),
             "setup": {"static_build_s": round(build_s, 2), "host": f"{os.cpu_count()} cores"},
+        }
+        # LAST, so that the driver's stored tail keeps it: the claims of the line in one compact object
+        def _sweep_frac(dist, tokens, slots):
+            rows = (roof.get("corpus_sweep") or {}).get("rows") or []
+            m = [r for r in rows if r["dist"] == dist and r["tokens"] == tokens and r["slots_per_pair"] == slots]
+            return m[0]["frac"] if m else None
+        rm, ch = (summ or {}).get("readme_mat"), (summ or {}).get("copy_heavy")
+        out["summary"] = {
+            "tokens_per_s": out["value"], "speedup_vs_ar": out["speedup_vs_ar"], "mean_accepted_tokens": out["mean_accepted_tokens"],
+            "step_ms_8": breakdown.get("8", {}).get("step_ms"), "step_ms_16": breakdown.get("16", {}).get("step_ms"),
+            "step_ms_32": breakdown.get("32", {}).get("step_ms"), "step_ms_64": breakdown.get("64", {}).get("step_ms"),
+            "walk_frac": roof["frac"], "walk_frac_default_slots": roof["at_default_slots"]["frac"], "walk_req_per_visit": roof.get("requests_per_visited_state"),
+            "walk_frac_zipf_2p22": _sweep_frac("zipf", 1 << 22, 16), "walk_frac_zipf_2p22_default_slots": _sweep_frac("zipf", 1 << 22, 4),
+            "walk_frac_markov_2p24_default_slots": _sweep_frac("markov", 1 << 24, 4), "sweep_matches_this_tree": (roof.get("corpus_sweep") or {}).get("matches_this_tree"),
+            "lm_frac_rows16": out["roofline_lm"]["frac"] if out.get("roofline_lm") else None,
+            "lm_frac_rows64": out["roofline_lm_rows64"]["frac"] if out.get("roofline_lm_rows64") else None,
+            "summ_readme_mat": None if not rm else {"calibrated": True, "speedup": rm["speedup_vs_ar"], "step_cost_ratio": rm["step_cost_ratio_vs_ar"],
+                                                    "request_start_ms": rm["speculative"]["request_start_ms_each"],
+                                                    "request_start_share": rm["speculative"]["request_start_share_of_timed_region"],
+                                                    "mat": rm["speculative"]["mean_accepted_tokens"]},
+            "summ_copy_heavy": None if not ch else {"speedup": ch["speedup_vs_ar"], "step_cost_ratio": ch["step_cost_ratio_vs_ar"],
+                                                    "request_start_ms": ch["speculative"]["request_start_ms_each"],
+                                                    "mat": ch["speculative"]["mean_accepted_tokens"]},
+            "cpu_baseline_us_per_step": (cpu or {}).get("us_per_step"), "n_gpus": world,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -91,7 +91,7 @@ __device__ __forceinline__ int st_transfer(const StaticDev &S, int &idx, int &le
 // its next transition probes the table without looking at the node
 // ptok = the token of the transition that brought the cursor to its state (-1: unknown): what the flagged climb keys the bigram table with.  It
 // lives IN the cursor's word so that it cannot go stale: st_transfer_chain sets it after every transition, a fresh cursor (chain_none) has none.
-// hub also carries, on the EDGE BLOCK path (round 6, samd_common.h), the cursor's state's BLOCK REFERENCE (never 0) instead of a plain 1
+// hub carries, on the EDGE BLOCK path (round 6, samd_common.h), the cursor's state's BLOCK REFERENCE (never 0) instead of a plain 1
 struct ChainWord { unsigned long long lo, hi, nlo, nhi; int used, have_next; unsigned hub; int ptok; };
 __device__ __forceinline__ ChainWord chain_none() { ChainWord c; c.lo = c.hi = c.nlo = c.nhi = ~0ull; c.used = 0; c.have_next = 0; c.hub = 0; c.ptok = -1; return c; }
 __device__ __forceinline__ ChainWord chain_load(const StaticDev &S, int state) {
@@ -351,7 +351,7 @@ __device__ __forceinline__ FailHdr fail_of_hot(const uint4 &h) {
     return f;
 }
 // probe the block `ref` for tok: e = the slot already loaded at position p (relative to the block).  On return e is the slot that ended the
-// probe -- the hit, or the empty slot -- and carries the block's fail header either way.
+// probe -- the hit, an empty slot, or a home slot that says none of its keys lives elsewhere -- and carries the block's fail header either way.
 __device__ __forceinline__ bool block_find(const StaticDev &S, unsigned ref, int tok, uint32_t p, uint4 &e) {
     const unsigned tmask = (1u << S.eb_tok_bits) - 1u, base = samd_eb_base(ref), bmask = samd_eb_mask(ref);
     const bool in_range = (unsigned)tok < tmask;
@@ -359,10 +359,15 @@ __device__ __forceinline__ bool block_find(const StaticDev &S, unsigned ref, int
         const unsigned t = e.x & tmask;
         if (in_range && t == (unsigned)tok) return true;
         if (t == tmask) return false;
+        if (probes == 0 && !(e.y & SAMD_EB_DISPLACED)) return false;      // no key of this home slot lives elsewhere: conclusive (samd_common.h)
         p = (p + 1) & bmask; e = S.blocks[base + p];
     }
     return false;
 }
+// Built, measured and not kept (profiles/r06_walk.md): (a) requesting a state's hot word one token early (the compiler waits for every
+// outstanding load at the top of a token, so the early request became a round of its own: 0.412 vs 0.367 ms on the Zipf corpus); (b) the whole
+// non-register path as ONE loop with one load instruction per iteration and a mode per lane (0.378 vs 0.349 ms: the launch is bound by the
+// instructions a wave issues for ANY lane's path as much as by its dependent rounds, and the mode machine adds to every iteration).
 template <int W>
 __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw) {
     constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
@@ -394,7 +399,12 @@ __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const
     const bool probing = climbing || st_on_child(idx);
     if (!probing && idx == 0) { st_from_root(S, bits, tok, idx, len); return 1; }
 
-    // what a hit in a block / the bigram table installs
+    // landing on `d` through a state's most frequent edge: its chain word when it starts a run
+    auto land_e0 = [&](int d, bool run) {
+        idx = d; len += 1;
+        if (run) cw = chain_load(S, idx);
+    };
+    // what a hit in a block installs
     auto follow_block = [&](const uint4 &e) {
         len += 1;
         if (e.y & SAMD_EB_ROOTCHILD) { idx = st_child_of(tok); return; }           // its edges live in the bigram table
@@ -408,6 +418,7 @@ __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const
             if (W == 8) hit = (e.x & 0x3FFFFFFFu) == ((unsigned)a | ((unsigned)tok << 15)) && tok < 0x8000;
             else hit = (e.x & 0x7FFFFFFFu) == (unsigned)a && (e.y & 0x7FFFFFFFu) == (unsigned)tok;
             if (hit || e.x == 0xFFFFFFFFu) break;
+            if (probes == 0 && !((W == 8 ? e.y : e.z) & SAMD_BG_DISPLACED)) break;       // conclusive miss at the home slot (samd_common.h)
             h = (h + 1) & S.bigram_mask; e = S.bigram[h];
         }
         if (hit) {
@@ -432,7 +443,7 @@ __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const
     const int a0 = climbing ? ptok : -2 - idx;
     const uint32_t hb = probing ? samd_bigram_hash(a0, tok) & S.bigram_mask : 0u;
     const uint32_t p0 = my_ref ? samd_eb_hash(tok) & samd_eb_mask(my_ref) : 0u;
-    const uint4 *addr = probing ? S.bigram + hb : (my_ref ? S.blocks + samd_eb_base(my_ref) + p0 : S.hot + idx);
+    const uint4 *addr = probing ? S.bigram + hb : (my_ref ? S.blocks + samd_eb_base(my_ref) + p0 : S.hot + (idx > 0 ? idx : 0));
     const uint4 first = *addr;
     if (probing) {
         visited += 1;                                          // the root child itself
@@ -447,21 +458,19 @@ __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const
     } else {
         const uint4 h = first;
         f = fail_of_hot(h);
-        if (h.y & SAMD_SINGLE) {
-            if ((int)h.z == tok) {                             // its only edge
-                idx = (int)h.w; len += 1;
-                if (h.y & SAMD_RUN) cw = chain_load(S, idx);
-                return visited;
+        // its most frequent edge (a single state's only one) is in the word: one round for it, as through node word 0
+        if ((int)h.z == tok) { land_e0((int)h.w, (h.y & SAMD_RUN) != 0); return visited; }
+        if (!(h.y & SAMD_SINGLE)) {
+            if (f.kind == SAMD_FK_ROOT) {                      // a branching ROOT CHILD met by index: its edges are in the bigram table
+                const int a = (int)h.x;
+                const uint32_t h2 = samd_bigram_hash(a, tok) & S.bigram_mask;
+                return visited + bigram(a, S.bigram[h2], h2, false);
             }
-        } else if (f.kind == SAMD_FK_ROOT) {                   // a branching ROOT CHILD met by index: its edges are in the bigram table
-            const int a = (int)h.x;
-            const uint32_t h2 = samd_bigram_hash(a, tok) & S.bigram_mask;
-            return visited + bigram(a, S.bigram[h2], h2, false);
-        } else {                                               // a hub met by index: its hot word names its block
-            const unsigned ref = h.z;
+            const unsigned ref = h.x;                          // a hub met by index: its word names its block, whose slots carry its fail header
             const uint32_t p = samd_eb_hash(tok) & samd_eb_mask(ref);
             uint4 e = S.blocks[samd_eb_base(ref) + p];
             if (block_find(S, ref, tok, p, e)) { follow_block(e); return visited; }
+            f = fail_of_slot(S, e);
         }
     }
     // ---- the climb (static_sam.py:99-101): f describes the suffix link of the state just examined; one request per hop --------------
@@ -487,19 +496,14 @@ __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const
         const int p_idx = (int)f.ref;
         const uint4 h = S.hot[p_idx];
         if (!f.len_ok) len = S.nodes[p_idx].length & SAMD_LEN_MASK;
-        if (h.y & SAMD_SINGLE) {
-            if ((int)h.z == tok) {
-                idx = (int)h.w; len += 1;
-                if (h.y & SAMD_RUN) cw = chain_load(S, idx);
-                return visited;
-            }
-            f = fail_of_hot(h);
-        } else {
-            const unsigned ref = h.z;
+        if ((int)h.z == tok) { land_e0((int)h.w, (h.y & SAMD_RUN) != 0); return visited; }
+        if (h.y & SAMD_SINGLE) f = fail_of_hot(h);
+        else {                                                 // (a hub the derivation demoted to STATE kind: its word names its block)
+            const unsigned ref = h.x;
             const uint32_t p = samd_eb_hash(tok) & samd_eb_mask(ref);
             uint4 e = S.blocks[samd_eb_base(ref) + p];
             if (block_find(S, ref, tok, p, e)) { follow_block(e); return visited; }
-            f = fail_of_hot(h);
+            f = fail_of_slot(S, e);
         }
     }
 }

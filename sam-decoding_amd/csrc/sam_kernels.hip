@@ -492,6 +492,18 @@ __global__ __launch_bounds__(256) void k_bg_fill(const SamNode *__restrict__ nod
     }
 }
 
+// SAMD_BG_DISPLACED (samd_common.h): after the fill, every entry that does not sit in its home slot marks that slot.  A separate launch: the
+// fill claims slots by compare-and-swap and writes the other words plainly, so the bit can only be OR-ed in once every entry is complete.
+__global__ __launch_bounds__(256) void k_bg_displaced(uint4 *__restrict__ table, uint32_t mask, int W) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > mask) return;
+    const uint4 e = table[p];
+    if (e.x == 0xFFFFFFFFu) return;
+    const int a = W == 8 ? (int)(e.x & 0x7FFFu) : (int)(e.x & 0x7FFFFFFFu), b = W == 8 ? (int)((e.x >> 15) & 0x7FFFu) : (int)(e.y & 0x7FFFFFFFu);
+    const uint32_t h = samd_bigram_hash(a, b) & mask;
+    if (h != p) atomicOr(reinterpret_cast<unsigned *>(table + h) + (W == 8 ? 1 : 2), SAMD_BG_DISPLACED);
+}
+
 // top-k counts (samd_common.h): one thread per (state, rank)
 __global__ __launch_bounds__(256) void k_topk_counts(const SamNode *__restrict__ nodes, const SamEdge *__restrict__ spill, long long n_states, int32_t *__restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -589,7 +601,8 @@ __global__ __launch_bounds__(256) void k_eb_fill(const SamNode *__restrict__ nod
     eb_fail(nodes, bref, rctok, s, SAMD_EB_IDX_MASK, kind, ref, len);
     const bool single = (w[1] & SAMD_SINGLE) != 0;
     const unsigned flags = (unsigned)w[1] & (unsigned)(SAMD_SINGLE | SAMD_RUN);
-    hot[s] = make_uint4(kind == SAMD_FK_ROOT ? (unsigned)rctok[s] : ref, len | (kind << 27) | flags, single ? (unsigned)w[2] : bref[s], (unsigned)w[3]);
+    // (samd_common.h: a branching state's word names its own block -- its fail header rides in that block's slots; a root child's its token)
+    hot[s] = make_uint4(kind == SAMD_FK_ROOT ? (unsigned)rctok[s] : (single ? ref : bref[s]), (single ? len : 0u) | (kind << 27) | flags, (unsigned)w[2], (unsigned)w[3]);
     const uint32_t my = bref[s];
     if (!my) return;
     const unsigned tmask = (1u << tok_bits) - 1u, lmax = (1u << (32 - tok_bits)) - 1u;
@@ -607,7 +620,9 @@ __global__ __launch_bounds__(256) void k_eb_fill(const SamNode *__restrict__ nod
             if (cur == tmask) {
                 const unsigned dref = bref[d];
                 unsigned y = ((unsigned)d & SAMD_EB_IDX_MASK) | y_hdr | (dref ? SAMD_EB_HUB : 0u) | (nodes[d].link == 0 && d > 0 ? SAMD_EB_ROOTCHILD : 0u);
+                y |= blk[p].y & SAMD_EB_DISPLACED;                                    // (a bit an earlier, displaced key of this home slot set)
                 blk[p] = make_uint4((unsigned)t | (len << tok_bits), y, dref ? dref : chain[d].x, ref);
+                if (probes) blk[samd_eb_hash(t) & bmask].y |= SAMD_EB_DISPLACED;      // stored away from its home slot: the home slot says so
                 return;
             }
             p = (p + 1) & bmask;
@@ -788,6 +803,8 @@ static int derive_root_hash(samd_static_t *s, hipStream_t st, int per_pair_arg =
         if (rc == SAMD_OK) {
             hipLaunchKernelGGL(k_bg_fill, dim3(blocks), dim3(256), 0, st, s->d_nodes, s->d_spill, s->d_root, vocab, (const uint4 *)s->d_chain, (uint4 *)s->d_root16,
                                (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), (uint32_t *)s->d_rc_bits, samd_chain_w(vocab), s->d_ehash ? 1 : 0, d_bref);
+            // (only the block path reads the bit, and only a handle with blocks may carry it: the edge-table path takes the dst word's low 31 bits as the index)
+            if (d_bref) hipLaunchKernelGGL(k_bg_displaced, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, (uint4 *)s->d_d1hash, (uint32_t)(slots - 1), samd_chain_w(vocab));
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = SAMD_E_HIP;
         }
         if (rc == SAMD_OK) s->n_d1hash = slots;

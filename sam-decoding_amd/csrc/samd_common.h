@@ -79,6 +79,12 @@ enum { SAMD_FK_ROOT = 0, SAMD_FK_ROOTCHILD = 1, SAMD_FK_HUB = 2, SAMD_FK_STATE =
 #define SAMD_EB_HUB 0x08000000u               // slot.y: dst owns a block (slot.z = its reference)
 #define SAMD_EB_KIND_SHIFT 28                 // slot.y / hot.y >> 27: kind(link)  (slot.y uses bits 28-29, hot.y bits 27-28)
 #define SAMD_EB_ROOTCHILD 0x40000000u         // slot.y / bigram entry: dst is the root child of the probed token
+// DISPLACED (block slots: bit 31 of y; bigram entries of a handle with blocks: bit 29 of the dst word): some key whose HOME is this slot was
+// stored further along the probe sequence.  A lookup whose home slot holds another key (or nothing) and does NOT carry the bit is a
+// conclusive miss after ONE probe -- without it a miss probes on to the first empty slot, a second dependent round in a quarter of the
+// cases at 4 slots per entry, and a lock-step wave pays it whenever any of its lanes does (profiles/r06_walk.md)
+#define SAMD_EB_DISPLACED 0x80000000u
+#define SAMD_BG_DISPLACED 0x20000000u
 SAMD_HD static inline uint32_t samd_eb_base(uint32_t ref) { return ref & SAMD_EB_IDX_MASK; }
 SAMD_HD static inline uint32_t samd_eb_mask(uint32_t ref) { return (1u << (ref >> 27)) - 1u; }
 SAMD_HD static inline uint32_t samd_eb_hash(int32_t tok) { uint32_t h = (uint32_t)tok * 0x9E3779B1u; return h ^ (h >> 15); }
@@ -139,10 +145,12 @@ struct StaticDev {
     // the hop target is.  rootchild(dst): dst is the root child of the probed token (its edges live in the bigram table; the cursor takes
     // the unresolved form idx = -2 - tok).  Root children own no block.
     // hot[s] (16 B per state) replaces node word 0 on this path:
-    //   hot.x = ref(link(s)) as above -- for a root child (kind ROOT) its own TOKEN instead: a branching root child met by index probes the
-    //           bigram table under it
-    //   hot.y = len(link(s)) (27 bits) | kind(link) << 27 | SAMD_RUN | SAMD_SINGLE (the node's flag bits, same positions)
-    //   hot.z = e0.tok (SAMD_SINGLE) or the state's own block reference (branching; 0 for a root child)      hot.w = e0.dst
+    //   a SINGLE state:  hot.x = ref(link(s)) as above, hot.y = len(link(s)) (27 bits) | kind(link) << 27 | SAMD_RUN | SAMD_SINGLE
+    //   a branching one: hot.x = its OWN block reference (its fail header comes with whatever slot ends the probe of that block), hot.y =
+    //                    kind(link) << 27 | SAMD_RUN; a root child (kind ROOT, single or branching): hot.x = its own TOKEN -- a branching
+    //                    root child met by index probes the bigram table under it
+    //   hot.z = e0.tok, hot.w = e0.dst: the most frequent edge (rank 0 of the top-k order; a single state's only one; -1 without edges) --
+    //           met by index, a state answers its rank-0 token in one round, as node word 0 did
     // Derivation needs every length < 2^27, every state index < 2^27 and all blocks within 2^27 slots (2 GB); otherwise -- or when the
     // device cannot spare the memory, or with SAMD_EDGE_BLOCKS=0 -- the walks keep the edge table.  Results are identical by construction
     // and by test (tests/test_gpu_sam.py: traces, cursors and visited-state counts against the oracle and against the other two paths).

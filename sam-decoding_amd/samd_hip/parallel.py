@@ -45,7 +45,9 @@ def broadcast_static(auto, src=0, device=None):
     dist.broadcast(info, src)
     info_h = info.cpu().numpy()
     sizes = [int(info_h[0]) * 64, int(info_h[3]) * 4, int(info_h[2]) * 8, int(info_h[6]) * 4]
+    import time
     regions = []
+    t_bc = time.perf_counter()
     host = auto.host_image() if rank == src else None
     for i, nbytes in enumerate(sizes):
         if rank == src:
@@ -56,8 +58,16 @@ def broadcast_static(auto, src=0, device=None):
             dist.broadcast(t, src)
         regions.append(t)
     if use_gpu:
-        return StaticAutomaton.adopt_device(info_h, regions)
-    out = StaticAutomaton.from_host_image(info_h, [r.numpy() for r in regions])
+        torch.cuda.synchronize()
+    t_adopt = time.perf_counter()
+    # what a rank pays AFTER the image has arrived: the derived walk tables (chain words, hot words + edge blocks or the edge table, the
+    # bigram table, top-k counts) are re-made per rank from the adopted image -- 4-14 GB of table fill at 2^24 corpus tokens -- and are
+    # reported separately from the broadcast (`distribution` attribute; bench.py static_sam_distribution)
+    out = StaticAutomaton.adopt_device(info_h, regions) if use_gpu else StaticAutomaton.from_host_image(info_h, [r.numpy() for r in regions])
+    if use_gpu:
+        torch.cuda.synchronize()
+    t_end = time.perf_counter()
+    out.distribution = {"broadcast_ms": round((t_adopt - t_bc) * 1e3, 2), "derive_ms": round((t_end - t_adopt) * 1e3, 2)}
     return out
 
 

@@ -49,7 +49,9 @@ for dist in args.dists.split(","):
             d = roof["derived_bytes"]
             pairs = None
             row = {"tokens": n_tok, "dist": dist, "states": int(info["n_states"]), "image_bytes": int(info["device_bytes"]),
-                   "slots_per_pair_asked": slots, "bigram_slots": int(d["bigram_slots"]), "derived_bytes": int(d["chain_bytes"] + d["bigram_bytes"] + d["topk_count_bytes"] + d.get("edge_table_bytes", 0)), "edge_table_bytes": int(d.get("edge_table_bytes", 0)),
+                   "slots_per_pair_asked": slots, "bigram_slots": int(d["bigram_slots"]), "derived_bytes": int(d["chain_bytes"] + d["bigram_bytes"] + d["topk_count_bytes"] + d.get("edge_table_bytes", 0) + d.get("hot_word_bytes", 0) + d.get("edge_block_bytes", 0)),
+                   "edge_table_bytes": int(d.get("edge_table_bytes", 0)), "hot_word_bytes": int(d.get("hot_word_bytes", 0)), "edge_block_bytes": int(d.get("edge_block_bytes", 0)),
+                   "edge_block_states": int(d.get("edge_block_states", 0)),
                    "bigram_bytes": int(d["bigram_bytes"]), "launch_ms": roof["launch_ms"], "frac": roof["frac"], "achieved_gbps": roof["achieved"],
                    "visited_states": roof["visited_states"], "visits_per_token": round(roof["visited_states"] / (args.streams * args.tokens), 3),
                    "transitions_per_s": roof["transitions_per_s"], "degree_profile": profile, "build_s": round(build_s, 1)}
