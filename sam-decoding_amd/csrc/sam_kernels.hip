@@ -38,7 +38,7 @@ static inline StaticDev static_view(const samd_static_t *s) {
 // first loads in flight together (r02: 0.383 ms, 6 % more requests from chain words fetched for tokens that then mismatch).
 // ================================================================================================
 template <int W, bool CHAIN>
-__global__ __launch_bounds__(256) void k_static_walk(StaticDev S, const int32_t *cursors, int32_t *cursors_out,
+__global__ __launch_bounds__(256, 8) void k_static_walk(StaticDev S, const int32_t *cursors, int32_t *cursors_out,
                                                      const int32_t *__restrict__ tokens, int B, int T,
                                                      int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total, int lds_words) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void k_eb_ref(const uint32_t *__restrict__ siz
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const uint32_t m = sizes[s];
-    off_to_ref[s] = m ? (off_to_ref[s] | ((uint32_t)(31 - __clz(m)) << 27)) : 0u;
+    off_to_ref[s] = m ? ((off_to_ref[s] >> 2) | ((uint32_t)(31 - __clz(m)) << 27)) : 0u;       // first slot in units of 4 (samd_common.h)
 }
 __global__ __launch_bounds__(256) void k_eb_rctok(const int32_t *__restrict__ root_next, int vocab, int32_t *__restrict__ rctok) {
     const int tok = blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,10 +724,10 @@ static int derive_edge_blocks(samd_static_t *s, hipStream_t st, int per_arg, uin
         if (hipMemcpyAsync(total, d_total, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) return none();
         if (bad) return none();
-        if (((long long)total[0] * 16 > budget || total[0] > (unsigned long long)SAMD_EB_IDX_MASK) && per > 2) { per = per / 2 < 2 ? 2 : per / 2; continue; }
+        if (((long long)total[0] * 16 > budget || total[0] > (4ull * SAMD_EB_IDX_MASK)) && per > 2) { per = per / 2 < 2 ? 2 : per / 2; continue; }
         break;
     }
-    if ((long long)total[0] * 16 > budget || total[0] > (unsigned long long)SAMD_EB_IDX_MASK) return none();
+    if ((long long)total[0] * 16 > budget || total[0] > (4ull * SAMD_EB_IDX_MASK)) return none();
     size_t tmp_bytes = 0;
     if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes, d_bref, (int)n, st) != hipSuccess) return none();
     if (hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) return none();

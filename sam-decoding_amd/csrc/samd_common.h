@@ -85,7 +85,7 @@ enum { SAMD_FK_ROOT = 0, SAMD_FK_ROOTCHILD = 1, SAMD_FK_HUB = 2, SAMD_FK_STATE =
 // cases at 4 slots per entry, and a lock-step wave pays it whenever any of its lanes does (profiles/r06_walk.md)
 #define SAMD_EB_DISPLACED 0x80000000u
 #define SAMD_BG_DISPLACED 0x20000000u
-SAMD_HD static inline uint32_t samd_eb_base(uint32_t ref) { return ref & SAMD_EB_IDX_MASK; }
+SAMD_HD static inline uint32_t samd_eb_base(uint32_t ref) { return (ref & SAMD_EB_IDX_MASK) << 2; }     // stored in units of 4 slots (every block is a power of two >= 4)
 SAMD_HD static inline uint32_t samd_eb_mask(uint32_t ref) { return (1u << (ref >> 27)) - 1u; }
 SAMD_HD static inline uint32_t samd_eb_hash(int32_t tok) { uint32_t h = (uint32_t)tok * 0x9E3779B1u; return h ^ (h >> 15); }
 // bits of a block slot's x word that hold the token: the smallest width whose all-ones value is not a token id
@@ -140,7 +140,8 @@ struct StaticDev {
     //   slot.w = ref(link): by kind -- 0 ROOT: nothing; 1 ROOTCHILD: the child's token a (the hop is one bigram probe (a, tok), conclusive);
     //            2 HUB: the link's block reference (the hop is one probe of that block: hit, or its header names the next hop);
     //            3 STATE: the link's index (the hop reads hot[link]: its only edge + its own fail header)
-    //   block reference = first slot (27 bits) | log2(slots) << 27   (never 0: a block has >= 4 slots)
+    //   block reference = first slot / 4 (27 bits: blocks are powers of two >= 4, so every first slot is a multiple of 4 -- 2^29 slots, 8 GB)
+    //                     | log2(slots) << 27   (never 0: a block has >= 4 slots)
     // so a probe -- hit or miss -- is ONE 16-byte request that also answers "where next", and a climb costs one request per hop whatever
     // the hop target is.  rootchild(dst): dst is the root child of the probed token (its edges live in the bigram table; the cursor takes
     // the unresolved form idx = -2 - tok).  Root children own no block.
@@ -151,7 +152,7 @@ struct StaticDev {
     //                    root child met by index probes the bigram table under it
     //   hot.z = e0.tok, hot.w = e0.dst: the most frequent edge (rank 0 of the top-k order; a single state's only one; -1 without edges) --
     //           met by index, a state answers its rank-0 token in one round, as node word 0 did
-    // Derivation needs every length < 2^27, every state index < 2^27 and all blocks within 2^27 slots (2 GB); otherwise -- or when the
+    // Derivation needs every length < 2^27, every state index < 2^27 and all blocks within 2^29 slots (8 GB); otherwise -- or when the
     // device cannot spare the memory, or with SAMD_EDGE_BLOCKS=0 -- the walks keep the edge table.  Results are identical by construction
     // and by test (tests/test_gpu_sam.py: traces, cursors and visited-state counts against the oracle and against the other two paths).
     const uint4 *hot;
