@@ -469,7 +469,7 @@ def lm_roofline(runner, iters=10, rows=16):
     import torch
     import samd_hip
     from samd_hip import _ptr, check, current_stream
-    if runner.wp is None or not runner.fused_mlp or any(l[k] is None for l in runner.wp["layers"] for k in ("wo", "wgu", "wdown")) \
+    if runner.wp is None or not runner.fused_mlp or any(l["wgu"] is None or (l.get(k) is None and l.get(k + "_g") is None) for l in runner.wp["layers"] for k in ("wo", "wdown")) \
             or any(l.get("wqkv") is None and l.get("wqkv64") is None for l in runner.wp["layers"]):      # (q|k|v: 128-column tiles OR the fused tile form)
         return None
     L, s, b = samd_hip.lib(), runner.shape, runner._buffers(rows)
@@ -499,8 +499,10 @@ def lm_roofline(runner, iters=10, rows=16):
                 if key == "wqkv" and p.get("wqkv64") is not None:          # the launch the runner makes: RoPE + K/V write in the epilogue
                     check(L.samd_gemm_qkv_rope(_ptr(a), _ptr(p["wqkv64"]), RP, k, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n), _ptr(b["q"]), _ptr(runner.kv[li, 0]),
                                                _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
-                else:
+                elif p.get(key) is not None:
                     check(L.samd_gemm_skinny(_ptr(a), _ptr(p[key]), RP, n, k, L.samd_gemm_splits(n, k, RP), _ptr(part), _ptr(out), dt, st))
+                else:                                                      # round 6: o / down stream their one group-major copy at every row bucket
+                    check(L.samd_gemm_skinny_groups(_ptr(a), _ptr(p[key + "_g"]), RP, n, k, L.samd_gemm_splits(n, k, RP), _ptr(part), _ptr(out), dt, st))
                 nbytes[0] += n * k * w[key].element_size()
             n, k = w["wgu"].shape
             check(L.samd_gemm_pairs_silu(_ptr(b["h"]), _ptr(p["wgu"]), RP, n // 2, k, _ptr(b["act"]), dt, st))

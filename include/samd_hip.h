@@ -583,6 +583,11 @@ int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int
                        int32_t head_dim, int64_t max_len, int32_t dtype, void *stream);
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
                      void *d_out, int32_t dtype, void *stream);
+/* round 6: the same product over a GROUP-MAJOR matrix (samd_gemm_pack_groups, the layout samd_gemm_cs_residual streams): o_proj / down_proj keep ONE
+ * packed copy for every row bucket instead of a 128-column-tile copy for the split-K kernel next to the 16-column-group copy of the norm-fold
+ * forward (-4 GB of a 7B replica).  Results are bit-identical to samd_gemm_skinny's. */
+int samd_gemm_skinny_groups(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
+                            void *d_out, int32_t dtype, void *stream);
 
 /* ---- scripted verifier (tests, smoke and bench only): replaces the LM arg-max of every draft node by
  * the next token of a target stream while the node's context (committed history + root->node path) is a

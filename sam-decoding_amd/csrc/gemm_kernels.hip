@@ -58,7 +58,11 @@ __device__ int samd_abl_flag;
 // interleaved in groups of 64 (tile t = gate columns 64t.. | up columns 64t..), and the epilogue writes
 // silu(gate) * up [rows][N/2] -- LlamaMLP's activation without a launch, a 2N-wide intermediate or its re-read.
 // DEPTH = weight chunks (+ their A tiles) in flight whenever a wave waits; DEPTH + 1 LDS buffers (dynamic LDS: 128 KiB at 64 rows).
-template <typename TT, int RT, int EPI, int DEPTH>
+// GM (round 6): W is GROUP-MAJOR (samd_gemm_pack_groups: column group gi = 16 columns, chunk c = 8 KiB contiguous at (gi * K/256 + c) * 512 units,
+// unit (2b + j) * 64 + lane -- the layout k_gemm_cs_residual and k_gemm_pairs_silu stream) instead of 128-column tiles: wave w of tile t reads
+// group 8 t + w as its own 1 KiB-per-instruction stream.  o_proj / down_proj then need ONE packed copy for every row bucket (the complete-sum
+// kernels of <= 16 rows and this split-K kernel above them) instead of two: -4 GB of a 7B replica.
+template <typename TT, int RT, int EPI, int DEPTH, bool GM = false>
 __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WAVES / 2) void k_gemm_skinny(const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W,
                                                         float *__restrict__ partial, typename TT::elem *__restrict__ out,
                                                         int K, int N, int n_chunks, int n_splits) {
@@ -79,8 +83,10 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     const int n0 = blockIdx.x * GEMM_COLS + 16 * w;
     const int split = blockIdx.y;
     const int c0 = (int)((long long)split * n_chunks / n_splits), c1 = (int)((long long)(split + 1) * n_chunks / n_splits);
-    const char *wtile = reinterpret_cast<const char *>(W) + (size_t)blockIdx.x * n_chunks * 65536;           // packed: see header
-    const uint32_t wlane = (uint32_t)tid * 16;
+    constexpr size_t WCH = GM ? 8192 : 65536, WU = GM ? 1024 : 8192;      // bytes of one (stream, chunk) block; of one (b, j) unit row inside it
+    const int ws = GM ? __builtin_amdgcn_readfirstlane(GEMM_WAVES * (int)blockIdx.x + w) : (int)blockIdx.x;      // this wave's stream: its group / the tile
+    const char *wtile = reinterpret_cast<const char *>(W) + (size_t)ws * n_chunks * WCH;           // packed: see header
+    const uint32_t wlane = (uint32_t)(GM ? l : tid) * 16;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lptr_t)&xs[0][0][0];
 
     floatx4 acc[RT];
@@ -94,10 +100,10 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || DEPTH > 2 ? 2 : GEMM_WA
     // has landed, chunk c+1 may still fly" is vmcnt(8 + XV).  scripts/stream_probe.hip: 18.3 vs 20.2 us for the QKV matrix.
     u32x4 wr[DEPTH][4][2];
     auto load_wb = [&](u32x4 (&dst)[4][2], int c, int b) {
-        const char *p = wtile + (size_t)c * 65536;                   // wave-uniform -> SGPR base, one offset VGPR
+        const char *p = wtile + (size_t)c * WCH;                     // wave-uniform -> SGPR base, one offset VGPR
 #pragma unroll
         for (int j = 0; j < 2; j++)        // nt: every weight byte is read once, by one CU -- streamed past the caches (13.7 vs 15.1 us, 30.1 vs 33.3)
-            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + 8192 * (2 * b + j)) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst[b][j]) : "v"(wlane), "s"(p + WU * (2 * b + j)) : "memory");
     };
     auto stage_xi = [&](int c, int buf, int i) {   // asynchronous: lands in LDS, counted by vmcnt
         const int slot = tid + NT * i, row = slot >> 5, pos = slot & 31, unit = pos ^ (row & 15);
@@ -846,23 +852,23 @@ __global__ __launch_bounds__(256) void k_gemm_pack(const uint4 *__restrict__ W, 
 
 // DEPTH = 2 chunks in flight at every row tile.  Three (128 KiB of LDS at 64 rows) measured SLOWER: gate|up 40.3 vs 38.8 us at 64
 // rows, 34.9 vs 34.5 at 32 -- the launch is not short of requests in flight (profiles/r02_gemm_rows64.md).
-template <typename TT, int RT, int EPI, int DEPTH>
+template <typename TT, int RT, int EPI, int DEPTH, bool GM = false>
 static hipError_t gemm_launch(dim3 grid, hipStream_t st, const void *A, const void *W, float *partial, void *out, int K, int N, int chunks, int splits) {
     constexpr int lds = (DEPTH + 1) * 16 * RT * GEMM_KC * 2;
     if constexpr (lds > 65536) {
         static unsigned long long done = 0ull;                     // per-device (samd_common.h)
-        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_skinny<TT, RT, EPI, DEPTH>, lds, &done);
+        const hipError_t attr = samd_reserve_lds((const void *)k_gemm_skinny<TT, RT, EPI, DEPTH, GM>, lds, &done);
         if (attr != hipSuccess) return attr;
     }
-    hipLaunchKernelGGL((k_gemm_skinny<TT, RT, EPI, DEPTH>), grid, dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, partial,
+    hipLaunchKernelGGL((k_gemm_skinny<TT, RT, EPI, DEPTH, GM>), grid, dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, partial,
                        (typename TT::elem *)out, K, N, chunks, splits);
     return hipSuccess;
 }
 
-template <int EPI>
+template <int EPI, bool GM = false>
 static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t st, const void *A, const void *W, float *partial, void *out, int K, int N, int chunks,
                                 int splits) {
-#define GO(TT, RT, D) return gemm_launch<TT, RT, EPI, D>(grid, st, A, W, partial, out, K, N, chunks, splits)
+#define GO(TT, RT, D) return gemm_launch<TT, RT, EPI, D, GM>(grid, st, A, W, partial, out, K, N, chunks, splits)
 #define ROWS(TT) do { if (rows_pad == 16) GO(TT, 1, 2); else if (rows_pad == 32) GO(TT, 2, 2); else if (rows_pad == 48) GO(TT, 3, 2); else GO(TT, 4, 2); } while (0)
     if (dtype == SAMD_F16) ROWS(GF16); else ROWS(GBF16);
 #undef ROWS
@@ -1125,6 +1131,22 @@ int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t
     const hipError_t e = gemm_dispatch<0>(dtype, rows_pad, dim3(N / GEMM_COLS, splits), (hipStream_t)stream, d_A, d_W, d_partial, splits == 1 ? d_out : nullptr, K, N,
                                           K / GEMM_KC, splits);
     if (e != hipSuccess) { samd_set_error("samd_gemm_skinny: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
+    LAUNCHCHK();
+    return SAMD_OK;
+}
+
+/* samd_gemm_skinny over a GROUP-MAJOR matrix (samd_gemm_pack_groups of the plain [N][K] weight: the layout samd_gemm_cs_residual reads), so that
+ * o_proj / down_proj keep one packed copy for every row bucket.  Same arguments, same results bit for bit (the lanes multiply the same values in
+ * the same order; only where a wave finds its 16 columns differs). */
+int samd_gemm_skinny_groups(const void *d_A, const void *d_Wg, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
+                            void *d_out, int32_t dtype, void *stream) {
+    if (!d_A || !d_Wg || (rows_pad != 16 && rows_pad != 32 && rows_pad != 48 && rows_pad != 64) || N < GEMM_COLS || N % GEMM_COLS != 0 || K < GEMM_KC ||
+        K % GEMM_KC != 0 || splits < 1 || splits > K / GEMM_KC || (splits == 1 ? !d_out : !d_partial) || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
+        samd_set_error("samd_gemm_skinny_groups: unsupported shape (rows 16/32/48/64, N %% 128 == 0, K %% 256 == 0) or null pointer"); return SAMD_E_INVALID;
+    }
+    const hipError_t e = gemm_dispatch<0, true>(dtype, rows_pad, dim3(N / GEMM_COLS, splits), (hipStream_t)stream, d_A, d_Wg, d_partial, splits == 1 ? d_out : nullptr, K, N,
+                                                K / GEMM_KC, splits);
+    if (e != hipSuccess) { samd_set_error("samd_gemm_skinny_groups: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
 }

@@ -165,6 +165,7 @@ _PROTOS = {
     "samd_gemm_pack_weights": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
     "samd_gemm_skinny_silu": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_skinny": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
+    "samd_gemm_skinny_groups": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "samd_gemm_pack_qkv64": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
     "samd_gemm_pack_groups": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
     "samd_gemm_pairs_silu": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),

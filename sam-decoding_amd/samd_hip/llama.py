@@ -160,13 +160,21 @@ class LlamaRunner:
         # packed_lm_head: a draft head shares the base model's lm_head, packed copy included
         layers = []
         for l in weights["layers"]:
-            lp = dict({k: pack(l[k]) for k in ("wo", "wdown")}, wgu=pack_gate_up(l["wgu"]), wqkv64=pack_qkv64(l["wqkv"]))
+            lp = dict(wgu=pack_gate_up(l["wgu"]), wqkv64=pack_qkv64(l["wqkv"]))
             # the 128-column packed q|k|v (split-K projection + samd_rope_kv_write_cs) only where the fused tile form does not exist:
             # with it, no launch of this runner ever reads the other (3.2 GB of a 7B model)
             lp["wqkv"] = pack(l["wqkv"]) if lp["wqkv64"] is None else None
             # the norm-fold forward (include/samd_hip.h: samd_gemm_cs_residual ...) needs the fused q|k|v and gate|up forms
             fold = (lp["wqkv64"] is not None and lp["wgu"] is not None and s.hidden <= 8192 and os.environ.get("SAMD_NORM_FOLD", "1") != "0")
             lp["wo_g"], lp["wdown_g"] = pack_groups(l["wo"], fold), pack_groups(l["wdown"], fold)
+            # o_proj / down_proj: the split-K kernel of the 32 / 48 / 64-row buckets can stream the norm-fold forward's group-major copy as well
+            # (samd_gemm_skinny_groups, round 6; bit-identical), which makes the 128-column-tile copy redundant: -4 GB of a 7B replica for
+            # +1.2 us per layer at 32 / 48 rows, +0.2 at 64 (scripts/gemm_groups_ab.py: 26.2 -> 27.4, 27.7 -> 28.9, 30.1 -> 30.4 us for o + down).
+            # Speed is the default; SAMD_GEMM_ONE_COPY=1 -- and release_row_major(), the memory-first mode -- keep only the group-major copy.
+            both = os.environ.get("SAMD_GEMM_ONE_COPY", "0") != "1"
+            for k in ("wo", "wdown"):
+                gm_ok = lp[k + "_g"] is not None and l[k].shape[0] % 128 == 0
+                lp[k] = pack(l[k]) if (both or not gm_ok) else None
             layers.append(lp)
         self.wp = dict(lm_head=packed_lm_head if packed_lm_head is not None else pack(weights["lm_head"]), layers=layers)
         self.native_gemm = self.wp["lm_head"] is not None or any(v is not None for l in self.wp["layers"] for v in l.values())
@@ -206,13 +214,16 @@ class LlamaRunner:
         if self.native_gemm_max_rows < TILE_ROWS:
             return False                                   # (a row bucket would fall back to the library GEMM, which reads the row-major matrices;
                                                            #  the 128-row bucket always does: drafts above 64 nodes then raise, see forward_rows)
-        need = ("wo", "wdown", "wgu")
-        if self.wp["lm_head"] is None or any(l.get(k) is None for l in self.wp["layers"] for k in need) or \
+        if self.wp["lm_head"] is None or any(l.get("wgu") is None or (l.get(k) is None and l.get(k + "_g") is None) for l in self.wp["layers"] for k in ("wo", "wdown")) or \
                 any(l.get("wqkv") is None and l.get("wqkv64") is None for l in self.wp["layers"]):
             return False
         for l in self.w["layers"]:
             for k in ("wqkv", "wo", "wgu", "wdown"):
                 l[k] = torch.empty(l[k].shape, dtype=l[k].dtype, device="meta")
+        for lp in self.wp["layers"]:                             # memory first: o / down keep ONE packed copy (the group-major one serves every bucket)
+            for k in ("wo", "wdown"):
+                if lp.get(k) is not None and lp.get(k + "_g") is not None:
+                    lp[k] = None
         self.row_major_released = True                           # (lm_head stays: draft heads and the granular API read it)
         torch.cuda.empty_cache()
         return True
@@ -407,16 +418,20 @@ class LlamaRunner:
             sp = 1 if (fused or is_head) else L.samd_gemm_splits(n, k, RP)
             return C.byref(Warm(wp.data_ptr(), n, k, sp, self.warm_kb, self.warm_delay, self.warm_where))
 
-        def gemm(a, w, wp, out):
-            """out = a @ w.T (wp = w in the packed layout); returns (operand for the consumer, n_partials, partial_stride)."""
+        def gemm(a, w, wp, out, wg=None):
+            """out = a @ w.T (wp = w in the packed 128-column-tile layout, wg = w group-major: whichever exists); returns
+            (operand for the consumer, n_partials, partial_stride)."""
             n, k = w.shape
             # measured on MI355X (scripts/forward_ablation.py, whole forward incl. the consumers' partial-sum reads), ours vs
             # the library GEMM: 3.46 vs 4.75 ms at <= 16 rows, 3.74 vs 4.62 at 32, 4.72 vs 5.15 at 64
-            if wp is None or RP > self.native_gemm_max_rows:
+            if (wp is None and wg is None) or RP > self.native_gemm_max_rows:
                 torch.mm(a[:R], w.t(), out=out[:R])
                 return out, 0, 0
             sp = L.samd_gemm_splits(n, k, RP) if out is not b["logits"] else 1
-            check(L.samd_gemm_skinny(_ptr(a), _ptr(wp), RP, n, k, sp, _ptr(part), _ptr(out), dt, st))
+            if wp is not None and os.environ.get("SAMD_GEMM_PREFER_GROUPS", "0") != "1":
+                check(L.samd_gemm_skinny(_ptr(a), _ptr(wp), RP, n, k, sp, _ptr(part), _ptr(out), dt, st))
+            else:
+                check(L.samd_gemm_skinny_groups(_ptr(a), _ptr(wg if wg is not None else wp), RP, n, k, sp, _ptr(part), _ptr(out), dt, st))
             return (out, 0, 0) if sp == 1 else (part, sp, RP * n)
 
         if x_in is None:
@@ -472,7 +487,7 @@ class LlamaRunner:
                 check(L.samd_tree_attention_warm(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
                                                  s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
                                                  _ptr(b["ws"]), b["ws_bytes"], hint(w["wo"], wp.get("wo")), st))
-            src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"])
+            src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"], wg=wp.get("wo_g"))
             check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride,
                                       None, st))           # (no warm-up hint: gate|up is packed group-major, the hint describes 128-column tiles)
             if self.fused_mlp and RP <= self.native_gemm_max_rows:
@@ -480,7 +495,7 @@ class LlamaRunner:
             else:
                 src, n_p, stride = gemm(b["h"], w["wgu"], None, b["gu"])           # wgu is only ever packed for the fused form
                 check(L.samd_silu_mul(_ptr(src), _ptr(b["act"]), R, s.inter, dt, n_p, stride, st))
-            delta, dn, dstride = gemm(b["act"], w["wdown"], wp.get("wdown"), b["d"])
+            delta, dn, dstride = gemm(b["act"], w["wdown"], wp.get("wdown"), b["d"], wg=wp.get("wdown_g"))
         check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(delta), _ptr(self.w["norm"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, dn, dstride,
                                   hint(self.w["lm_head"], self.wp["lm_head"] if self.wp else None, is_head=True), st))
         # (for a draft head the call above only folds the last projection into the residual stream; its norm output is unused)

@@ -41,6 +41,35 @@ def test_gemm_matches_fp32_reference(dtype, tol, rows_pad, N, K, splits):
     assert err <= tol * max(1.0, want.abs().max().item()), err
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows_pad,N,K,splits", [(16, 128, 256, 1), (32, 4096, 4096, 8), (48, 4096, 11008, 8), (64, 4096, 11008, 8), (64, 4096, 4096, 8), (64, 1024, 768, 3),
+                                                 (16, 4096, 4096, 4), (64, 256, 512, 1)])
+def test_gemm_over_the_group_major_copy_is_bit_identical(dtype, rows_pad, N, K, splits):
+    """samd_gemm_skinny_groups (round 6): the split-K product of the 32 / 48 / 64-row buckets streamed from the GROUP-MAJOR copy of o_proj /
+    down_proj that the norm-fold forward keeps anyway -- every output (or fp32 partial) equal bit for bit to samd_gemm_skinny over the
+    128-column-tile copy, which the runner no longer makes."""
+    L = samd_hip.lib()
+    g = torch.Generator(device="cuda").manual_seed(3 * N + K + rows_pad)
+    A = torch.randn((rows_pad, K), generator=g, device="cuda").to(dtype)
+    W = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(dtype)
+    Wt, Wg = torch.empty_like(W), torch.empty_like(W)
+    samd_hip.check(L.samd_gemm_pack_weights(samd_hip._ptr(W), samd_hip._ptr(Wt), N, K, samd_hip.current_stream()))
+    samd_hip.check(L.samd_gemm_pack_groups(samd_hip._ptr(W), samd_hip._ptr(Wg), N, K, samd_hip.current_stream()))
+    dt = samd_hip.torch_dtype_code(dtype)
+    res = []
+    for fn, w in ((L.samd_gemm_skinny, Wt), (L.samd_gemm_skinny_groups, Wg)):
+        if splits == 1:
+            out = torch.full((rows_pad, N), float("nan"), device="cuda", dtype=dtype)
+            samd_hip.check(fn(samd_hip._ptr(A), samd_hip._ptr(w), rows_pad, N, K, 1, None, samd_hip._ptr(out), dt, samd_hip.current_stream()))
+        else:
+            out = torch.full((splits, rows_pad, N), float("nan"), device="cuda", dtype=torch.float32)
+            samd_hip.check(fn(samd_hip._ptr(A), samd_hip._ptr(w), rows_pad, N, K, splits, samd_hip._ptr(out), None, dt, samd_hip.current_stream()))
+        torch.cuda.synchronize()
+        res.append(out)
+    assert torch.isfinite(res[1].float()).all() and torch.equal(res[0], res[1])
+    assert L.samd_gemm_skinny_groups(samd_hip._ptr(A), samd_hip._ptr(Wg), 24, N, K, 1, None, samd_hip._ptr(res[1]), dt, None) == -1      # SAMD_E_INVALID
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("rows_pad,inter,K", [(16, 64, 256), (16, 11008, 4096), (32, 1408, 768), (64, 2816, 1024), (48, 11008, 4096), (48, 192, 256)])
 def test_gemm_silu_epilogue_matches_reference(dtype, tol, rows_pad, inter, K):

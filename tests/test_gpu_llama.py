@@ -496,7 +496,9 @@ def test_release_row_major_keeps_the_forward(monkeypatch):
     cfg = dict(hidden_size=1024, intermediate_size=2816, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=8, vocab_size=4096,
                max_position_embeddings=1024, rms_norm_eps=1e-6)
     monkeypatch.setenv("SAMD_PREFILL", "chunked")
-    runner = LlamaRunner.random_init(cfg, 1024, torch.float16, seed=2)
+    monkeypatch.setenv("SAMD_QKV_FUSED", "force")                    # (a 1024-wide model has too few q|k|v tiles for the fused forms by default: the
+    runner = LlamaRunner.random_init(cfg, 1024, torch.float16, seed=2)   #  norm-fold forward and its group-major o / down copies are what a 7B runner has)
+    assert runner.norm_fold
     before = runner.memory_report()
     prompt = torch.tensor([np.random.default_rng(8).integers(3, 4096, 300).tolist()], device="cuda")
 
@@ -512,7 +514,19 @@ def test_release_row_major_keeps_the_forward(monkeypatch):
     assert runner.release_row_major() and runner.row_major_released
     after = runner.memory_report()
     keep = 2 * 4096 * 1024 * 2 + 2 * 2 * 1024 * 2                    # the embedding table, lm_head and the layers' norm weights stay
-    assert after["row_major"] == keep and before["row_major"] > 4 * keep and after["total"] == before["total"] - (before["row_major"] - keep)
+    # round 6: the memory-first mode also keeps ONE packed copy of o_proj / down_proj (the group-major one streams at every row bucket)
+    dropped = before["packed_wo"] + before["packed_wdown"]
+    assert dropped > 0 and after["packed_wo"] == 0 and after["packed_wdown"] == 0 and after["packed_wo_g"] == before["packed_wo_g"] > 0
+    assert after["row_major"] == keep and before["row_major"] > 4 * keep and after["total"] == before["total"] - (before["row_major"] - keep) - dropped
     monkeypatch.delenv("SAMD_PREFILL")
     b_last, b_tree = run()
     assert torch.equal(a_last, b_last) and torch.equal(a_tree, b_tree)
+    # ... and it says so where drafts are sized: 64 nodes, not 128 (the 128-row bucket is a library GEMM on the row-major matrices)
+    assert runner.max_draft_rows() == 64
+    wide = 40                                                         # a 33..48-node draft: the split-K kernel over the group-major copy
+    sess = samd_hip.Session(1024)
+    runner.prefill(sess, prompt)
+    sess.set_draft(torch.arange(5, 5 + wide, dtype=torch.int32, device="cuda"), torch.tensor([-1] + list(range(wide - 1)), dtype=torch.int32, device="cuda"), wide, type_=1)
+    got = runner.verify(sess, runner.bucket(wide))["logits"][:wide].float().clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and (got[:11] - b_tree).abs().max().item() < 0.05 * max(1.0, b_tree.abs().max().item())
