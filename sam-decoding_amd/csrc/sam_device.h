@@ -170,6 +170,14 @@ __device__ __forceinline__ int st_transfer_chain(const StaticDev &S, const uint3
     cw.ptok = tok;                                           // (the word may have been replaced inside: set last)
     return visited;
 }
+// the block path alone, for a kernel that is instantiated for handles WITH blocks (k_static_walk<.., 2>): without the run-time choice the
+// other path's code, its pointers (scalar registers: the kernel runs 8 waves per SIMD on 96 of them) and its branches are not compiled in
+template <int W>
+__device__ __forceinline__ int st_transfer_blocks(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, ChainWord &cw) {
+    const int visited = st_transfer_blocks_impl<W>(S, bits, idx, len, tok, cw.ptok, cw);
+    cw.ptok = tok;
+    return visited;
+}
 template <int W>
 __device__ __forceinline__ int st_transfer_chain_impl(const StaticDev &S, const uint32_t *bits, int &idx, int &len, int tok, int ptok, ChainWord &cw) {
     constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;

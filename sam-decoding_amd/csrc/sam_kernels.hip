@@ -37,7 +37,9 @@ static inline StaticDev static_view(const samd_static_t *s) {
 // iteration state machine with LDS-staged tokens, a lane-quad variant (4 lanes x 16 B per node), two cursors per lane with both
 // first loads in flight together (r02: 0.383 ms, 6 % more requests from chain words fetched for tokens that then mismatch).
 // ================================================================================================
-template <int W, bool CHAIN>
+// PATH: 0 = through the nodes only; 1 = chain words + whatever tables the handle has (chosen per transition, uniformly); 2 = a handle with
+// EDGE BLOCKS: that path alone (round 6)
+template <int W, int PATH>
 __global__ __launch_bounds__(256, 8) void k_static_walk(StaticDev S, const int32_t *cursors, int32_t *cursors_out,
                                                      const int32_t *__restrict__ tokens, int B, int T,
                                                      int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total, int lds_words) {
@@ -46,6 +48,7 @@ __global__ __launch_bounds__(256, 8) void k_static_walk(StaticDev S, const int32
     // which tokens have a root child: vocab bits, in LDS when the launch reserved room for them (samd_common.h, BIGRAM TABLE)
     extern __shared__ uint32_t walk_bits[];
     const uint32_t *bits = S.rc_bits;
+    constexpr bool CHAIN = PATH != 0;
     if (CHAIN && lds_words > 0) {
         for (int k = threadIdx.x; k < lds_words; k += blockDim.x) walk_bits[k] = S.rc_bits[k];
         __syncthreads();
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(256, 8) void k_static_walk(StaticDev S, const int32
         ChainWord cw = chain_none();
         for (int t = 0; t < T; t++) {
             const int nxt = (t + 1 < T) ? tokens[(size_t)(t + 1) * B + b] : 0;
-            if (CHAIN) visited += st_transfer_chain<W>(S, bits, idx, len, tok, cw);
+            if (PATH == 2) visited += st_transfer_blocks<W>(S, bits, idx, len, tok, cw);
+            else if (CHAIN) visited += st_transfer_chain<W>(S, bits, idx, len, tok, cw);
             else visited += st_transfer(S, idx, len, tok);
             if (trace) reinterpret_cast<int2 *>(trace)[(size_t)t * B + b] = make_int2(CHAIN ? st_resolve(S, idx) : idx, len);
             tok = nxt;
@@ -427,9 +431,11 @@ static void launch_walk(const samd_static_t *sam, int blocks, int threads, hipSt
     // the child bitmap rides in LDS when it is small enough to leave the occupancy alone (8 workgroups of 256 per CU: 160 KiB / 8)
     const int bit_words = v.rc_bits ? (int)((v.vocab + 31) / 32) : 0;
     const int lds_words = bit_words * 4 <= 20480 ? bit_words : 0;
-    if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, false>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, 0);
-    else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
-    else hipLaunchKernelGGL((k_static_walk<4, true>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
+    if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, 0>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, 0);
+    else if (v.blocks && v.bigram && v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, 2>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
+    else if (v.blocks && v.bigram) hipLaunchKernelGGL((k_static_walk<4, 2>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
+    else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, 1>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
+    else hipLaunchKernelGGL((k_static_walk<4, 1>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
 }
 
 // bigram table (samd_common.h): count the root children's edges, then fill.  One thread per vocabulary id.
