@@ -481,36 +481,37 @@ __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const
             f = fail_of_slot(S, e);
         }
     }
-    // ---- the climb (static_sam.py:99-101): f describes the suffix link of the state just examined; one request per hop, and ONE load
-    //      instruction per hop for the whole wave whatever the kinds of its lanes' hops are (a bigram slot, a block slot, a hot word) ----------
-    const uint32_t tok_home = samd_eb_hash(tok);
+    // ---- the climb (static_sam.py:99-101): f describes the suffix link of the state just examined; one request per hop --------------
     for (;;) {
         visited++;
         if (f.kind == SAMD_FK_ROOT) { len = 0; st_from_root(S, bits, tok, idx, len); return visited; }
-        const bool k_rc = f.kind == SAMD_FK_ROOTCHILD, k_hub = f.kind == SAMD_FK_HUB;
-        const unsigned ref = f.ref;
-        const uint32_t h2 = samd_bigram_hash((int)ref, tok) & S.bigram_mask, p = tok_home & samd_eb_mask(ref);
-        const uint4 *addr = k_rc ? S.bigram + h2 : (k_hub ? S.blocks + samd_eb_base(ref) + p : S.hot + ref);
-        uint4 e = *addr;
-        if (k_rc) return visited + bigram((int)ref, e, h2, true);
+        if (f.kind == SAMD_FK_ROOTCHILD) {
+            const int a = (int)f.ref;
+            const uint32_t h2 = samd_bigram_hash(a, tok) & S.bigram_mask;
+            return visited + bigram(a, S.bigram[h2], h2, true);
+        }
         len = (int)f.len;                                      // length <- states[link].length (a HUB header's always fits: the derivation
-        if (k_hub) {                                           //  demotes a hub whose length overflows the slot field to STATE kind)
+        if (f.kind == SAMD_FK_HUB) {                           //  demotes a hub whose length overflows the slot field to STATE kind)
+            const unsigned ref = f.ref;
+            const uint32_t p = samd_eb_hash(tok) & samd_eb_mask(ref);
+            uint4 e = S.blocks[samd_eb_base(ref) + p];
             if (block_find(S, ref, tok, p, e)) { follow_block(e); return visited; }
             f = fail_of_slot(S, e);
             continue;
         }
-        // SAMD_FK_STATE: a plain state index -- its hot word is its most frequent edge + its own fail header (or, for a hub the derivation
-        // demoted to this kind, its block reference)
-        const uint4 h = e;
-        if (!f.len_ok) len = S.nodes[ref].length & SAMD_LEN_MASK;
+        // SAMD_FK_STATE: a plain state index -- its hot word is its only edge + its own fail header (or, for a hub the derivation demoted
+        // to this kind, its block reference)
+        const int p_idx = (int)f.ref;
+        const uint4 h = S.hot[p_idx];
+        if (!f.len_ok) len = S.nodes[p_idx].length & SAMD_LEN_MASK;
         if ((int)h.z == tok) { land_e0((int)h.w, (h.y & SAMD_RUN) != 0); return visited; }
         if (h.y & SAMD_SINGLE) f = fail_of_hot(h);
         else {                                                 // (a hub the derivation demoted to STATE kind: its word names its block)
-            const unsigned ref2 = h.x;
-            const uint32_t p2 = tok_home & samd_eb_mask(ref2);
-            uint4 e2 = S.blocks[samd_eb_base(ref2) + p2];
-            if (block_find(S, ref2, tok, p2, e2)) { follow_block(e2); return visited; }
-            f = fail_of_slot(S, e2);
+            const unsigned ref = h.x;
+            const uint32_t p = samd_eb_hash(tok) & samd_eb_mask(ref);
+            uint4 e = S.blocks[samd_eb_base(ref) + p];
+            if (block_find(S, ref, tok, p, e)) { follow_block(e); return visited; }
+            f = fail_of_slot(S, e);
         }
     }
 }
