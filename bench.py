@@ -327,7 +327,7 @@ def walk_source_sha16():
 WALK_BIGRAM_SLOTS_PER_PAIR = 16       # the batched walk's table sparsity (profiles/r04_walk.md); the product default is 4 (include/samd_hip.h)
 
 
-def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=WALK_BIGRAM_SLOTS_PER_PAIR, vocab=VOCAB, noise_cdf=None):
+def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=WALK_BIGRAM_SLOTS_PER_PAIR, vocab=VOCAB, noise_cdf=None, noise_p=0.10):
     """the SAM traversal kernel in batched-streams form: B independent cursors x T tokens per launch.  The launch asks for the bigram
     table at `slots_per_pair` (samd_static_set_bigram_slots: a lock-step wave pays for any lane's collision; a request's one-cursor
     walks do not care, so the decode loop above ran on the 4-per-pair default) and the bytes that costs are reported with it."""
@@ -339,7 +339,7 @@ def walk_roofline(sam, docs, rng, B, T, iters, sam_tokens=None, slots_per_pair=W
     d = rng.integers(0, n_docs, B)
     s = rng.integers(0, doc_len - T, B)
     toks = docs[d[None, :], (s[None, :] + np.arange(T)[:, None])]
-    noise = rng.random((T, B)) < 0.10
+    noise = rng.random((T, B)) < noise_p
     if noise_cdf is None:
         noise_tok = rng.integers(3, vocab, (T, B))
     else:                                               # a Zipf corpus gets Zipf noise (a uniform draw would almost always be a rare token)
