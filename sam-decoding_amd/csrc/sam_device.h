@@ -516,6 +516,152 @@ __device__ __forceinline__ int st_transfer_blocks_impl(const StaticDev &S, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6, last: the block path with DECOUPLED LANES (k_static_walk_async).  A lock-step wave pays, at every token, the climb of its slowest
+// lane -- own state, one or two hubs, the bigram probe: three to four dependent rounds -- and with a few per cent of mismatching tokens
+// nearly every wave-token has such a lane (scripts/walk_noise_probe.py: Zipf 0.135 ms per launch without mismatches, 0.220 at 2 %, 0.305 at
+// 10 %).  Here a lane keeps its OWN token index: every trip of the loop is one dependent round for the whole wave -- a lane whose load is
+// pending works on its result (hit: the token is done; miss: the next slot / the next hop is requested), a lane that is free starts its
+// next token (register path: done in the same trip) -- so a wave needs max over lanes of (sum of a lane's rounds) trips instead of
+// sum over tokens of (max over lanes of rounds).  The per-lane state machine below is st_transfer_blocks_impl taken apart at its loads;
+// states visited, their order, lengths and the count are unchanged (same tests, same traces).
+// ------------------------------------------------------------------------------------------------
+enum { WM_READY = 0, WM_BIGRAM = 1, WM_BLOCK = 2, WM_HOT = 3 };
+struct WalkLane {
+    int idx, len, tok, mode, a, vtok;
+    unsigned ref, pos, probes;
+    bool set_len;
+    ChainWord cw;
+};
+// the address of a lane's pending load
+__device__ __forceinline__ const uint4 *wl_addr(const StaticDev &S, const WalkLane &L) {
+    return L.mode == WM_BIGRAM ? S.bigram + L.pos : (L.mode == WM_BLOCK ? S.blocks + samd_eb_base(L.ref) + L.pos : S.hot + L.ref);
+}
+// start the token L.tok at the cursor: true = the transition is complete (register path, root, negative token); false = L.mode / ref / pos
+// name the first load
+template <int W>
+__device__ __forceinline__ bool wl_start(const StaticDev &S, const uint32_t *bits, WalkLane &L) {
+    constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu, HI = LOW + 1u;
+    ChainWord &cw = L.cw;
+    const int tok = L.tok;
+    L.vtok = 1;
+    if (tok < 0) { L.idx = 0; L.len = 0; cw = chain_none(); return true; }
+    const unsigned ent = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+    const bool is_tok = (ent & LOW) != LOW;
+    if (is_tok && (ent & LOW) == (unsigned)tok) {            // register path: identical to st_transfer_blocks_impl
+        L.idx += 1; L.len += 1; cw.hub = 0;
+        if (W == 8) { cw.lo = (cw.lo >> 16) | (cw.hi << 48); cw.hi = (cw.hi >> 16) | (0xFFFFull << 48); }
+        else { cw.lo = (cw.lo >> 32) | (cw.hi << 32); cw.hi = (cw.hi >> 32) | (0xFFFFFFFFull << 32); }
+        if (++cw.used == W) {
+            if (cw.have_next) { cw.lo = cw.nlo; cw.hi = cw.nhi; cw.nlo = cw.nhi = ~0ull; cw.used = 0; cw.have_next = 0; }
+            else { const int ptok = cw.ptok; cw = chain_load(S, L.idx); cw.ptok = ptok; return true; }
+        }
+        const unsigned e2 = W == 8 ? (unsigned)(cw.lo & 0xFFFFull) : (unsigned)(cw.lo & 0xFFFFFFFFull);
+        if (cw.used == W - 1 && (e2 & LOW) != LOW) {
+            const uint4 c = S.chain[L.idx + 1];
+            cw.nlo = (unsigned long long)c.x | ((unsigned long long)c.y << 32);
+            cw.nhi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
+            cw.have_next = 1;
+        }
+        return true;
+    }
+    const int ptok = cw.ptok;
+    const bool climbing = is_tok && !(ent & HI) && ptok >= 0;
+    const unsigned my_ref = L.idx > 0 ? cw.hub : 0u;
+    cw = chain_none();
+    if (!climbing && L.idx == 0) { st_from_root(S, bits, tok, L.idx, L.len); return true; }
+    L.probes = 0u;
+    if (climbing || st_on_child(L.idx)) {
+        L.vtok = (climbing ? 1 : 0) + 1;                       // (the flagged state,) the root child
+        L.mode = WM_BIGRAM; L.a = climbing ? ptok : -2 - L.idx; L.set_len = climbing;
+        L.pos = samd_bigram_hash(L.a, tok) & S.bigram_mask;
+    } else if (my_ref) {
+        L.mode = WM_BLOCK; L.ref = my_ref; L.pos = samd_eb_hash(tok) & samd_eb_mask(my_ref);
+    } else {
+        L.mode = WM_HOT; L.ref = (unsigned)L.idx;
+    }
+    return false;
+}
+// the pending load of L has landed in e: true = the transition is complete; false = the next load is named
+template <int W>
+__device__ __forceinline__ bool wl_step(const StaticDev &S, const uint32_t *bits, WalkLane &L, const uint4 &e) {
+    constexpr unsigned LOW = W == 8 ? 0x7FFFu : 0x7FFFFFFFu;
+    ChainWord &cw = L.cw;
+    const int tok = L.tok;
+    const unsigned tmask = (1u << S.eb_tok_bits) - 1u;
+    FailHdr f;
+    if (L.mode == WM_BIGRAM) {
+        bool hit;
+        if (W == 8) hit = (e.x & 0x3FFFFFFFu) == ((unsigned)L.a | ((unsigned)tok << 15)) && tok < 0x8000;
+        else hit = (e.x & 0x7FFFFFFFu) == (unsigned)L.a && (e.y & 0x7FFFFFFFu) == (unsigned)tok;
+        const unsigned d = W == 8 ? e.y : e.z, extra = W == 8 ? e.z : e.w;
+        if (hit) {
+            if (L.set_len) {
+                const unsigned lb = W == 8 ? e.x >> 30 : (e.x >> 31) | ((e.y >> 31) << 1);
+                L.len = lb < 3 ? (int)lb + 1 : (int)S.root16[L.a].w;
+            }
+            L.len += 1;
+            if (d & SAMD_EB_ROOTCHILD) { L.idx = st_child_of(tok); return true; }
+            L.idx = (int)(d & SAMD_EB_IDX_MASK);
+            if (d & 0x80000000u) cw.hub = extra;
+            else if (W == 8) cw = chain_half<W>(e.z, e.w);
+            else cw = chain_first<W>(e.w);
+            return true;
+        }
+        if (e.x == 0xFFFFFFFFu || (L.probes == 0 && !(d & SAMD_BG_DISPLACED)) || L.probes >= S.bigram_mask) {
+            st_from_root(S, bits, tok, L.idx, L.len);          // no such edge: the child's link is the root -- visited too
+            L.vtok += 1;
+            return true;
+        }
+        L.pos = (L.pos + 1) & S.bigram_mask; L.probes++;
+        return false;
+    }
+    if (L.mode == WM_BLOCK) {
+        const unsigned t = e.x & tmask;
+        if ((unsigned)tok < tmask && t == (unsigned)tok) {     // the edge
+            L.len += 1;
+            if (e.y & SAMD_EB_ROOTCHILD) { L.idx = st_child_of(tok); return true; }
+            L.idx = (int)(e.y & SAMD_EB_IDX_MASK);
+            if (e.y & SAMD_EB_HUB) cw.hub = e.z; else cw = chain_from_edge<W>(e.z);
+            return true;
+        }
+        if (!(t == tmask || (L.probes == 0 && !(e.y & SAMD_EB_DISPLACED)) || L.probes >= samd_eb_mask(L.ref))) {
+            L.pos = (L.pos + 1) & samd_eb_mask(L.ref); L.probes++;
+            return false;
+        }
+        f = fail_of_slot(S, e);
+    } else {                                                   // WM_HOT: the word of state L.ref
+        if ((int)e.z == tok) {                                 // its most frequent edge (a single state's only one)
+            L.idx = (int)e.w; L.len += 1;
+            if (e.y & SAMD_RUN) cw = chain_load(S, L.idx);
+            return true;
+        }
+        f = fail_of_hot(e);
+        if (!(e.y & SAMD_SINGLE)) {
+            L.probes = 0u;
+            if (f.kind == SAMD_FK_ROOT) {                      // a branching ROOT CHILD met by index: its edges are in the bigram table
+                L.mode = WM_BIGRAM; L.a = (int)e.x; L.set_len = false; L.pos = samd_bigram_hash(L.a, tok) & S.bigram_mask;
+            } else {                                           // a hub: its word names its block (same state: nothing new visited)
+                L.mode = WM_BLOCK; L.ref = e.x; L.pos = samd_eb_hash(tok) & samd_eb_mask(L.ref);
+            }
+            return false;
+        }
+    }
+    // ---- the state just examined has no edge on tok: hop to its suffix link (static_sam.py:99-101), which f describes --------------------
+    L.vtok += 1;
+    if (f.kind == SAMD_FK_ROOT) { L.len = 0; st_from_root(S, bits, tok, L.idx, L.len); return true; }
+    L.probes = 0u;
+    if (f.kind == SAMD_FK_ROOTCHILD) {
+        L.mode = WM_BIGRAM; L.a = (int)f.ref; L.set_len = true; L.pos = samd_bigram_hash(L.a, tok) & S.bigram_mask;
+    } else if (f.kind == SAMD_FK_HUB) {
+        L.len = (int)f.len; L.mode = WM_BLOCK; L.ref = f.ref; L.pos = samd_eb_hash(tok) & samd_eb_mask(L.ref);
+    } else {
+        L.len = f.len_ok ? (int)f.len : (int)(S.nodes[f.ref].length & SAMD_LEN_MASK);
+        L.mode = WM_HOT; L.ref = f.ref;
+    }
+    return false;
+}
+
 // n committed transitions of one cursor (transfer_tokens, static_sam.py:118-120) -- the single-wavefront kernels' form: all lanes
 // run the same cursor (uniform addresses: one request per load), with the chain words and the root-child hash when the automaton
 // has them, so that a run of tokens that follows the corpus costs one load per 8 (4) tokens instead of one per token

@@ -77,6 +77,65 @@ __global__ __launch_bounds__(256, 8) void k_static_walk(StaticDev S, const int32
     }
 }
 
+// ================================================================================================
+// the same walk with DECOUPLED LANES (sam_device.h, "Round 6, last"): every lane keeps its own token index; one trip of the loop = one
+// dependent round for the whole wave.  The lanes' tokens sit in LDS, 16 per lane at a time ([k][lane]: a lane reads only what it wrote, and the
+// bank follows the lane, so the per-lane index costs no conflict), next to the child bitmap.
+// ================================================================================================
+#define WALK_TCHUNK 16
+template <int W>
+__global__ __launch_bounds__(256, 8) void k_static_walk_async(StaticDev S, const int32_t *cursors, int32_t *cursors_out,
+                                                           const int32_t *__restrict__ tokens, int B, int T,
+                                                           int32_t *__restrict__ trace, unsigned long long *__restrict__ visited_total, int lds_words) {
+    extern __shared__ uint32_t walk_bits[];
+    const int tid = threadIdx.x, b = blockIdx.x * blockDim.x + tid;
+    const uint32_t *bits = S.rc_bits;
+    if (lds_words > 0) {
+        for (int k = tid; k < lds_words; k += blockDim.x) walk_bits[k] = S.rc_bits[k];
+        __syncthreads();
+        bits = walk_bits;
+    }
+    int32_t *tokbuf = reinterpret_cast<int32_t *>(walk_bits + lds_words);       // [WALK_TCHUNK][256]
+    const bool live = b < B;
+    WalkLane L;
+    L.idx = 0; L.len = 0; L.tok = 0; L.mode = WM_READY; L.a = 0; L.vtok = 0; L.ref = L.pos = L.probes = 0u; L.set_len = false;
+    L.cw = chain_none();
+    if (live) { const int2 c = reinterpret_cast<const int2 *>(cursors)[b]; L.idx = c.x; L.len = c.y; }
+    unsigned long long visited = 0;
+    for (int t0 = 0; t0 < T; t0 += WALK_TCHUNK) {
+        const int tn = live ? (T - t0 < WALK_TCHUNK ? T - t0 : WALK_TCHUNK) : 0;
+#pragma unroll
+        for (int k = 0; k < WALK_TCHUNK; k++) if (k < tn) tokbuf[k * 256 + tid] = tokens[(size_t)(t0 + k) * B + b];
+        int t = 0;
+        uint4 e = make_uint4(0u, 0u, 0u, 0u);
+        for (;;) {
+            bool done = false;
+            if (L.mode != WM_READY) done = wl_step<W>(S, bits, L, e);             // the pending load has landed
+            if (done) {
+                visited += (unsigned)L.vtok; L.cw.ptok = L.tok; L.mode = WM_READY;
+                if (trace) reinterpret_cast<int2 *>(trace)[(size_t)(t0 + t) * B + b] = make_int2(st_resolve(S, L.idx), L.len);
+                t++;
+            }
+            if (L.mode == WM_READY && t < tn) {                                   // a free lane starts its next token
+                L.tok = tokbuf[t * 256 + tid];
+                if (wl_start<W>(S, bits, L)) {
+                    visited += (unsigned)L.vtok; L.cw.ptok = L.tok;
+                    if (trace) reinterpret_cast<int2 *>(trace)[(size_t)(t0 + t) * B + b] = make_int2(st_resolve(S, L.idx), L.len);
+                    t++;
+                }
+            }
+            const bool pending = L.mode != WM_READY;
+            if (pending) e = *wl_addr(S, L);                                       // ONE load instruction per trip for the whole wave
+            if (!__any(pending || t < tn)) break;
+        }
+    }
+    if (live && cursors_out) reinterpret_cast<int2 *>(cursors_out)[b] = make_int2(st_resolve(S, L.idx), L.len);
+    if (visited_total) {
+        for (int o = 32; o > 0; o >>= 1) visited += __shfl_xor(visited, o);
+        if ((threadIdx.x & 63) == 0 && visited) atomicAdd(visited_total, visited);
+    }
+}
+
 // chain words from the node image: one thread per state (samd_common.h, CHAIN WORDS)
 template <int W>
 __global__ __launch_bounds__(256) void k_build_chain(const SamNode *__restrict__ nodes, long long n, uint4 *__restrict__ chain) {
@@ -427,11 +486,23 @@ int samd_device_info(int64_t out[4]) {
 static void launch_walk(const samd_static_t *sam, int blocks, int threads, hipStream_t st, const int32_t *d_cursors, int32_t *d_out, const int32_t *d_tokens, int B, int T,
                         int32_t *d_trace, unsigned long long *d_visited) {
     static const bool use_chain = [] { const char *e = getenv("SAMD_WALK_CHAIN"); return !(e && e[0] == '0'); }();
+    // the decoupled-lane form (k_static_walk_async) is an experiment, OFF by default: -39 % load instructions, +39 % vector instructions, 0.335 vs
+    // 0.301 ms on the Zipfian corpus, 0.171 vs 0.151 on the headline one (profiles/r06_walk.md section 4b).  Read per launch: tests run both forms.
+    const char *env_async = getenv("SAMD_WALK_ASYNC");
+    const bool use_async = env_async && env_async[0] == '1';
     const StaticDev v = static_view(sam);
     // the child bitmap rides in LDS when it is small enough to leave the occupancy alone (8 workgroups of 256 per CU: 160 KiB / 8)
     const int bit_words = v.rc_bits ? (int)((v.vocab + 31) / 32) : 0;
     const int lds_words = bit_words * 4 <= 20480 ? bit_words : 0;
     if (!use_chain || !v.chain) hipLaunchKernelGGL((k_static_walk<8, 0>), dim3(blocks), dim3(threads), 0, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, 0);
+    else if (v.blocks && v.bigram && use_async && threads == 256) {
+        // decoupled lanes (k_static_walk_async): the lanes' tokens ride in LDS beside the child bitmap (16 KiB + <= 4 KiB: 8 workgroups per CU);
+        // a bitmap too large for that stays in memory
+        const int lw = (size_t)lds_words * 4 + WALK_TCHUNK * 256 * 4 <= 20480 ? lds_words : 0;
+        const size_t lds = (size_t)lw * 4 + WALK_TCHUNK * 256 * 4;
+        if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk_async<8>), dim3(blocks), dim3(threads), lds, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lw);
+        else hipLaunchKernelGGL((k_static_walk_async<4>), dim3(blocks), dim3(threads), lds, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lw);
+    }
     else if (v.blocks && v.bigram && v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, 2>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
     else if (v.blocks && v.bigram) hipLaunchKernelGGL((k_static_walk<4, 2>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);
     else if (v.chain_w == 8) hipLaunchKernelGGL((k_static_walk<8, 1>), dim3(blocks), dim3(threads), (size_t)lds_words * 4, st, v, d_cursors, d_out, d_tokens, B, T, d_trace, d_visited, lds_words);

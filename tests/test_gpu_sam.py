@@ -389,7 +389,8 @@ def test_bigram_table_size_changes_nothing_but_bytes(vocab):
 
 
 @pytest.mark.parametrize("vocab,n_tok", [(300, 1 << 14), (2000, 1 << 16), (70000, 1 << 15)])
-def test_static_walk_zipf_corpus_with_deep_hubs(vocab, n_tok, monkeypatch):
+@pytest.mark.parametrize("lanes", ["lockstep", "decoupled"])
+def test_static_walk_zipf_corpus_with_deep_hubs(vocab, n_tok, lanes, monkeypatch):
     """a natural-language-like corpus (bench.synth_corpus_zipf: Zipfian vocabulary, hubs of degree >> 5 at depth 1-4): the EDGE TABLE path of
     the walk (round 5: one probe per transition out of a branching state, node word 0 + probe together on every hop of a climb) against the
     oracle -- every (index, length) of every stream, the visited-state count state for state, cursors carried over a second pass -- and
@@ -399,6 +400,9 @@ def test_static_walk_zipf_corpus_with_deep_hubs(vocab, n_tok, monkeypatch):
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
+    # lanes = "decoupled": the batched launches of a handle with blocks run k_static_walk_async (every lane its own token index; an experiment,
+    # off by default, SAMD_WALK_ASYNC=1) -- the same traces, cursors and visited-state counts
+    monkeypatch.setenv("SAMD_WALK_ASYNC", "1" if lanes == "decoupled" else "0")
     flat, off, docs2d = bench.synth_corpus_zipf(n_tok, vocab=vocab, doc_len=128, max_succ=256)
     docs = [flat[off[i]:off[i + 1]].tolist() for i in range(len(off) - 1)]
     ora = O.StaticSAM.build(docs, 2)
