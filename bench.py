@@ -487,7 +487,8 @@ def lm_roofline(runner, iters=10, rows=16):
         nbytes[0] = 0
         for li, (w, p) in enumerate(zip(runner.w["layers"], runner.wp["layers"])):
             if fold:
-                check(L.samd_gemm_qkv_rope_norm(_ptr(b["x"]), _ptr(b["ssq"]), _ptr(w["ln1"]), s.eps, _ptr(p["wqkv64"]), 16, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
+                check((L.samd_gemm_qkv_rope_norm_vt if runner.v_transposed else L.samd_gemm_qkv_rope_norm)(
+                    _ptr(b["x"]), _ptr(b["ssq"]), _ptr(w["ln1"]), s.eps, _ptr(p["wqkv64"]), 16, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
                                                 _ptr(b["q"]), _ptr(runner.kv[li, 0]), _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
                 check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(p["wo_g"]), 16, s.hidden, attn2d.shape[1], _ptr(b["x"]), _ptr(b["ssq"]), dt, st))
                 check(L.samd_gemm_pairs_silu_norm(_ptr(b["x"]), _ptr(b["ssq"]), _ptr(w["ln2"]), s.eps, _ptr(p["wgu"]), 16, s.inter, s.hidden, _ptr(b["act"]), dt, st))
@@ -497,7 +498,8 @@ def lm_roofline(runner, iters=10, rows=16):
             for a, key, out in ((b["h"], "wqkv", b["qkv"]), (attn2d, "wo", b["o"]), (b["act"], "wdown", b["d"])):
                 n, k = w[key].shape
                 if key == "wqkv" and p.get("wqkv64") is not None:          # the launch the runner makes: RoPE + K/V write in the epilogue
-                    check(L.samd_gemm_qkv_rope(_ptr(a), _ptr(p["wqkv64"]), RP, k, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n), _ptr(b["q"]), _ptr(runner.kv[li, 0]),
+                    check((L.samd_gemm_qkv_rope_vt if runner.v_transposed else L.samd_gemm_qkv_rope)(
+                        _ptr(a), _ptr(p["wqkv64"]), RP, k, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n), _ptr(b["q"]), _ptr(runner.kv[li, 0]),
                                                _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
                 elif p.get(key) is not None:
                     check(L.samd_gemm_skinny(_ptr(a), _ptr(p[key]), RP, n, k, L.samd_gemm_splits(n, k, RP), _ptr(part), _ptr(out), dt, st))

@@ -394,6 +394,16 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                         int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
                         const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
+/* round 6: the same over a cache whose V half is kept TRANSPOSED, d_vt_cache [H_kv][D][max_len] (the layout samd_attention_block reads);
+ * max_len a multiple of 8.  Same sums in the same order as samd_tree_attention: bit-identical output.  At n_q_pad <= 16 one wave per (head,
+ * KV split) reads its V^T operands straight from memory (no LDS staging, no workgroup barrier): 11.9 -> 11.0 us per layer at 8 rows over 800
+ * cached keys (profiles/r06_attention.md).  `next` as in samd_tree_attention_warm (may be NULL).  The cache is maintained by
+ * samd_gemm_qkv_rope_vt / samd_gemm_qkv_rope_norm_vt / samd_rope_kv_write_vt / samd_rope_kv_write_cs_vt (new rows), samd_kv_compact*_vt (accepted
+ * rows) and read by samd_prefill_attention_vt (the prompt). */
+int samd_tree_attention_vt(const void *d_q, const void *d_k_cache, const void *d_vt_cache, void *d_out, int32_t dtype,
+                           int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                           const uint64_t *d_mask, const int32_t *d_cache_length, const int32_t *d_n, float scale,
+                           void *d_workspace, int64_t workspace_bytes, const samd_warm_t *next, void *stream);
 /* the same; its merge launch also warms the L2 for the output projection that follows (next may be NULL) */
 int samd_tree_attention_warm(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype,
                              int32_t n_q_pad, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
@@ -425,6 +435,11 @@ int samd_rope_kv_write_cs(const void *d_qkv, const int32_t *d_rel_pos, const int
                           const float *d_cs, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t rows,
                           int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype,
                           int32_t n_partials, int64_t partial_stride, void *stream);
+/* round 6: the same writing V into a TRANSPOSED cache, d_vt_cache [H_kv][D][max_len] (samd_tree_attention_vt) */
+int samd_rope_kv_write_cs_vt(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                             const float *d_cs, void *d_q_out, void *d_k_cache, void *d_vt_cache, int32_t rows,
+                             int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype,
+                             int32_t n_partials, int64_t partial_stride, void *stream);
 /* samd_rope_kv_write + samd_tree_attention in TWO launches instead of three (row-major V cache, csrc/verify_kernels.hip
  * k_tree_attention_rope): the 16 KV splits rotate their Q rows themselves, one more workgroup per head owns the n new keys (rotates
  * k, writes the K / V rows at [L, L + n), attends to them), k_attn_combine_slots merges the 17 slots.  d_qkv / n_partials /
@@ -514,6 +529,10 @@ int samd_rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int32_
  * the PV product (as fused SDPA kernels do).  head_dim must be 128, pos0 + rows <= max_len.  One launch, no workspace. */
 int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
                            int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream);
+/* round 6: the same over a transposed V cache, d_vt_cache [n_kv_heads][128][max_len] (max_len a multiple of 8 below 2^24): the V^T tile is copied into
+ * LDS (one 16-byte load + one 16-byte LDS store per 8 keys of a column) instead of transposed on the way */
+int samd_prefill_attention_vt(const void *d_q, const void *d_k_cache, const void *d_vt_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
+                              int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream);
 /* LlamaMLP activation: silu(gate) * up with gate|up concatenated per row */
 int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,
                   int64_t partial_stride, void *stream);
@@ -581,6 +600,13 @@ int samd_gemm_cs_residual(const void *d_A, const void *d_Wg, int32_t rows_pad, i
 int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length,
                        const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t n_heads, int32_t n_kv_heads,
                        int32_t head_dim, int64_t max_len, int32_t dtype, void *stream);
+/* round 6: the two above with the V rows written into a TRANSPOSED cache, d_vt_cache [H_kv][128][max_len] (samd_tree_attention_vt) */
+int samd_gemm_qkv_rope_norm_vt(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,
+                               const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_vt_cache,
+                               int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream);
+int samd_gemm_qkv_rope_vt(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length,
+                          const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_vt_cache, int32_t n_heads, int32_t n_kv_heads,
+                          int32_t head_dim, int64_t max_len, int32_t dtype, void *stream);
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,
                      void *d_out, int32_t dtype, void *stream);
 /* round 6: the same product over a GROUP-MAJOR matrix (samd_gemm_pack_groups, the layout samd_gemm_cs_residual streams): o_proj / down_proj keep ONE

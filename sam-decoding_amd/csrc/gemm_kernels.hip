@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES /
         const typename TT::elem *__restrict__ A, const typename TT::elem *__restrict__ W, int K, int n_chunks,
         const float *__restrict__ cs, const int *__restrict__ d_L, const int *__restrict__ d_n,
         typename TT::elem *__restrict__ q_out, typename TT::elem *__restrict__ k_cache, typename TT::elem *__restrict__ v_cache,
-        int H, int Hkv, long long max_len, NormArgs na) {
+        int H, int Hkv, long long max_len, NormArgs na, int v_t) {
     typedef typename TT::elem E;
     typedef typename TT::vec8 V8;
     constexpr int R = 16 * RT;
@@ -465,14 +465,22 @@ __global__ __launch_bounds__(64 * GEMM_WAVES, RT >= 3 || NORM ? 2 : GEMM_WAVES /
             for (int r = 0; r < 4; r++) ex[(kh * R + 16 * mt + 4 * g + r) * TW + 16 * cg + n] = acc[mt][r];     // C layout: lane holds rows 4g + r of column n
     }
     __syncthreads();
+    // v_t (round 6): the V cache is transposed ([H_kv][128][max_len], samd_tree_attention_vt); a tile of V columns then walks its (row, pair)
+    // items row-fastest, so that neighbouring lanes write neighbouring keys of one V^T row
+    const bool vt_tile = v_t && ((PP * (int)blockIdx.x) >> 6) >= H + Hkv;
     for (int i = tid; i < R * PP; i += NT) {
-        const int row = i / PP, p = i % PP;
+        const int row = vt_tile ? i % R : i / PP, p = vt_tile ? i / R : i % PP;
         if (row >= n_rows || L + row >= max_len) continue;                     // rows past the draft / past the cache are not written (k_rope_kv)
         // sums rounded to the model dtype first, as the projection's own output would have been (k_rope_kv does the same on partials)
         const float x1 = (float)(E)(ex[row * TW + p] + ex[(R + row) * TW + p]);
         const float x2 = (float)(E)(ex[row * TW + PP + p] + ex[(R + row) * TW + PP + p]);
         const int pair = PP * (int)blockIdx.x + p, head = pair >> 6, j = pair & 63;   // global pair index -> head, position inside it (j and j + 64)
         if (head >= H + Hkv) {                                                    // V: plain rows
+            if (v_t) {
+                E *dst = v_cache + (size_t)(head - H - Hkv) * max_len * 128 + L + row;
+                dst[(size_t)j * max_len] = (E)x1; dst[(size_t)(j + 64) * max_len] = (E)x2;
+                continue;
+            }
             E *dst = v_cache + ((size_t)(head - H - Hkv) * max_len + L + row) * 128;
             dst[j] = (E)x1; dst[j + 64] = (E)x2;
             continue;
@@ -877,7 +885,7 @@ static hipError_t gemm_dispatch(int dtype, int rows_pad, dim3 grid, hipStream_t 
 
 template <typename TT, int RT, int DEPTH, int CG, bool NORM = false, int AR = 16>
 static hipError_t qkv_rope_launch(hipStream_t st, const void *A, const void *W, int K, int tiles, const float *cs, const int *d_L, const int *d_n, void *q, void *k, void *v,
-                                  int H, int Hkv, long long max_len, NormArgs na = NormArgs{nullptr, nullptr, 0, 0.f, 0.f}) {
+                                  int H, int Hkv, long long max_len, int v_t, NormArgs na = NormArgs{nullptr, nullptr, 0, 0.f, 0.f}) {
     constexpr int lds_a = (DEPTH + 1) * 16 * RT * GEMM_KC * 2, lds_e = 2 * 16 * RT * 16 * CG * 4, lds = lds_a > lds_e ? lds_a : lds_e;
     if constexpr (lds > 60000) {
         static unsigned long long done = 0ull;
@@ -885,7 +893,7 @@ static hipError_t qkv_rope_launch(hipStream_t st, const void *A, const void *W, 
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL((k_gemm_qkv_rope<TT, RT, DEPTH, CG, NORM, AR>), dim3(tiles), dim3(64 * GEMM_WAVES), lds, st, (const typename TT::elem *)A, (const typename TT::elem *)W, K, K / GEMM_KC,
-                       cs, d_L, d_n, (typename TT::elem *)q, (typename TT::elem *)k, (typename TT::elem *)v, H, Hkv, max_len, na);
+                       cs, d_L, d_n, (typename TT::elem *)q, (typename TT::elem *)k, (typename TT::elem *)v, H, Hkv, max_len, na, v_t);
     return hipSuccess;
 }
 
@@ -1070,9 +1078,9 @@ int samd_gemm_pack_qkv64(const void *d_W, void *d_packed, int32_t n_heads_total,
     return SAMD_OK;
 }
 
-int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n,
-                       void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
-                       int32_t dtype, void *stream) {
+static int gemm_qkv_rope_impl(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n,
+                              void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                              int32_t dtype, void *stream, int v_t) {
     if (!d_A || !d_W64 || !d_cs || !d_cache_length || !d_n || !d_q_out || !d_k_cache || !d_v_cache || head_dim != 128 || n_heads < 1 || n_kv_heads < 1 ||
         (rows_pad != 16 && rows_pad != 32 && rows_pad != 48 && rows_pad != 64) || K < GEMM_KC || K % GEMM_KC != 0 || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
         samd_set_error("samd_gemm_qkv_rope: unsupported shape (rows 16/32/48/64, head_dim 128, K %% 256 == 0, f16/bf16) or null pointer"); return SAMD_E_INVALID;
@@ -1082,7 +1090,7 @@ int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int
     const int tiles = (n_heads + 2 * n_kv_heads) * 128 / (16 * groups);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-#define GO(TT, RT, D, CG) e = qkv_rope_launch<TT, RT, D, CG>(st, d_A, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len)
+#define GO(TT, RT, D, CG) e = qkv_rope_launch<TT, RT, D, CG>(st, d_A, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len, v_t)
 #define ROWS(TT, CG) do { if (rows_pad == 16) { if (depth_env == 2) GO(TT, 1, 2, CG); else if (depth_env == 3) GO(TT, 1, 3, CG); else GO(TT, 1, 4, CG); } \
                           else if (rows_pad == 32) { if (depth_env == 2) GO(TT, 2, 2, CG); else GO(TT, 2, 4, CG); } \
                           else if (rows_pad == 48) GO(TT, 3, 3, CG); else GO(TT, 4, 3, CG); } while (0)
@@ -1095,9 +1103,22 @@ int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int
     return SAMD_OK;
 }
 
-int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,
-                            const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache,
-                            int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream) {
+int samd_gemm_qkv_rope(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n,
+                       void *d_q_out, void *d_k_cache, void *d_v_cache, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                       int32_t dtype, void *stream) {
+    return gemm_qkv_rope_impl(d_A, d_W64, rows_pad, K, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, head_dim, max_len, dtype, stream, 0);
+}
+
+/* round 6: the same with the V rows written into a TRANSPOSED cache, d_vt_cache [H_kv][128][max_len] (what samd_tree_attention_vt reads) */
+int samd_gemm_qkv_rope_vt(const void *d_A, const void *d_W64, int32_t rows_pad, int32_t K, const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n,
+                          void *d_q_out, void *d_k_cache, void *d_vt_cache, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len,
+                          int32_t dtype, void *stream) {
+    return gemm_qkv_rope_impl(d_A, d_W64, rows_pad, K, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_vt_cache, n_heads, n_kv_heads, head_dim, max_len, dtype, stream, 1);
+}
+
+static int gemm_qkv_rope_norm_impl(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,
+                                   const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache,
+                                   int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream, int v_t) {
     if (!d_x || !d_ssq || !d_norm_weight || !d_W64 || !d_cs || !d_cache_length || !d_n || !d_q_out || !d_k_cache || !d_v_cache || head_dim != 128 || n_heads < 1 ||
         n_kv_heads < 1 || (rows_pad != 16 && rows_pad != 8) || K < GEMM_KC || K % GEMM_KC != 0 || K / 16 > 32 * NORM_NS || (dtype != SAMD_F16 && dtype != SAMD_BF16)) {
         samd_set_error("samd_gemm_qkv_rope_norm: unsupported shape (8 or 16 rows, head_dim 128, K %% 256 == 0, K <= 8192, f16/bf16) or null pointer"); return SAMD_E_INVALID;
@@ -1107,7 +1128,7 @@ int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_n
     const NormArgs na{d_ssq, d_norm_weight, K / 16, 1.f / (float)K, eps};
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-#define GO(TT, CG, AR) e = qkv_rope_launch<TT, 1, 4, CG, true, AR>(st, d_x, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len, na)
+#define GO(TT, CG, AR) e = qkv_rope_launch<TT, 1, 4, CG, true, AR>(st, d_x, d_W64, K, tiles, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, (long long)max_len, v_t, na)
     // rows_pad 8: a draft of <= 8 nodes -- only rows 0..7 of x are fetched (the tile stays 16 rows)
     if (rows_pad == 8) {
         if (groups == 3) { if (dtype == SAMD_F16) GO(GF16, 3, 8); else GO(GBF16, 3, 8); }
@@ -1120,6 +1141,20 @@ int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_n
     if (e != hipSuccess) { samd_set_error("samd_gemm_qkv_rope_norm: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     LAUNCHCHK();
     return SAMD_OK;
+}
+
+int samd_gemm_qkv_rope_norm(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,
+                            const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_v_cache,
+                            int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream) {
+    return gemm_qkv_rope_norm_impl(d_x, d_ssq, d_norm_weight, eps, d_W64, rows_pad, K, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_v_cache, n_heads, n_kv_heads, head_dim,
+                                   max_len, dtype, stream, 0);
+}
+
+int samd_gemm_qkv_rope_norm_vt(const void *d_x, const float *d_ssq, const void *d_norm_weight, float eps, const void *d_W64, int32_t rows_pad, int32_t K,
+                               const float *d_cs, const int32_t *d_cache_length, const int32_t *d_n, void *d_q_out, void *d_k_cache, void *d_vt_cache,
+                               int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype, void *stream) {
+    return gemm_qkv_rope_norm_impl(d_x, d_ssq, d_norm_weight, eps, d_W64, rows_pad, K, d_cs, d_cache_length, d_n, d_q_out, d_k_cache, d_vt_cache, n_heads, n_kv_heads, head_dim,
+                                   max_len, dtype, stream, 1);
 }
 
 int samd_gemm_skinny(const void *d_A, const void *d_W, int32_t rows_pad, int32_t N, int32_t K, int32_t splits, float *d_partial,

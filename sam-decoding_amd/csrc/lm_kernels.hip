@@ -406,6 +406,16 @@ int samd_rope_kv_write_vt(const void *d_qkv, const int32_t *d_rel_pos, const int
                          max_pos, dtype, n_partials, partial_stride, 1, nullptr, stream);
 }
 
+// samd_rope_kv_write_cs over the transposed V cache (round 6: the >= 32-row buckets of the runner whose verify attention is samd_tree_attention_vt)
+int samd_rope_kv_write_cs_vt(const void *d_qkv, const int32_t *d_rel_pos, const int32_t *d_cache_length, const int32_t *d_n,
+                             const float *d_cs, void *d_q_out, void *d_k_cache, void *d_vt_cache, int32_t rows,
+                             int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, int32_t dtype,
+                             int32_t n_partials, int64_t partial_stride, void *stream) {
+    if (!d_vt_cache) { samd_set_error("samd_rope_kv_write_cs_vt: null pointer"); return SAMD_E_INVALID; }
+    return rope_kv_write(d_qkv, d_rel_pos, d_cache_length, d_n, nullptr, nullptr, d_q_out, d_k_cache, d_vt_cache, rows, n_heads, n_kv_heads, head_dim, max_len,
+                         1, dtype, n_partials, partial_stride, 1, d_cs, stream);
+}
+
 int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inter, int32_t dtype, int32_t n_partials,
                   int64_t partial_stride, void *stream) {
     if (!d_gate_up || !d_out || rows < 1 || inter % 8 != 0) { samd_set_error("samd_silu_mul: invalid argument"); return SAMD_E_INVALID; }
@@ -419,9 +429,15 @@ int samd_silu_mul(const void *d_gate_up, void *d_out, int32_t rows, int32_t inte
 }
 
 // causal attention of the prompt's rows (csrc/prefill_attn_device.h)
-int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
-                           int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream) {
+}  // extern "C"
+
+template <bool VTS>
+static int prefill_attention_impl(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
+                                  int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream) {
     using namespace prefillattn;
+    if (VTS && (max_len < 8 || max_len % 8 != 0 || max_len >= (1ll << 24))) {
+        samd_set_error("samd_prefill_attention_vt: max_len must be a multiple of 8 below 2^24"); return SAMD_E_INVALID;
+    }
     if (!d_q || !d_k_cache || !d_v_cache || !d_out || rows < 1 || pos0 < 0 || head_dim != 128 || n_heads < 1 || n_kv_heads < 1 || n_heads % n_kv_heads != 0 ||
         (int64_t)pos0 + rows > max_len || (dtype != SAMD_F16 && dtype != SAMD_BF16) || !(scale > 0.f)) {
         samd_set_error("samd_prefill_attention: invalid argument (head_dim 128, pos0 + rows <= max_len, f16/bf16, scale > 0)"); return SAMD_E_INVALID;
@@ -429,8 +445,8 @@ int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d
     // one-time, per-device setup through samd_reserve_lds / samd_device_cus (atomic bookkeeping: first calls from several host threads may race)
     {
         static unsigned long long done_f16 = 0ull, done_bf16 = 0ull;
-        const hipError_t e = dtype == SAMD_F16 ? samd_reserve_lds((const void *)k_prefill_attention<prefillattn::F16, 4, 2, 2>, 2 * LDS_BYTES, &done_f16)
-                                               : samd_reserve_lds((const void *)k_prefill_attention<prefillattn::BF16, 4, 2, 2>, 2 * LDS_BYTES, &done_bf16);
+        const hipError_t e = dtype == SAMD_F16 ? samd_reserve_lds((const void *)k_prefill_attention<prefillattn::F16, 4, 2, 2, VTS>, 2 * LDS_BYTES, &done_f16)
+                                               : samd_reserve_lds((const void *)k_prefill_attention<prefillattn::BF16, 4, 2, 2, VTS>, 2 * LDS_BYTES, &done_bf16);
         if (e != hipSuccess) { samd_set_error("samd_prefill_attention: %s", hipGetErrorString(e)); return SAMD_E_HIP; }
     }
     hipStream_t st = (hipStream_t)stream;
@@ -439,10 +455,23 @@ int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d
     const int pair = n_blocks * n_heads > cus ? 1 : 0;                    // a heavy + a light row block per workgroup once the blocks outnumber the CUs
     const dim3 grid(pair ? (n_blocks + 1) / 2 : n_blocks, n_heads), block(512);                    // two key groups of 4 waves
     const float scale_log2 = scale * 1.4426950408889634f;
-    if (dtype == SAMD_F16) hipLaunchKernelGGL((k_prefill_attention<prefillattn::F16, 4, 2, 2>), grid, block, 2 * LDS_BYTES, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache, (const _Float16 *)d_v_cache, (_Float16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
-    else hipLaunchKernelGGL((k_prefill_attention<prefillattn::BF16, 4, 2, 2>), grid, block, 2 * LDS_BYTES, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache, (const __bf16 *)d_v_cache, (__bf16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
+    if (dtype == SAMD_F16) hipLaunchKernelGGL((k_prefill_attention<prefillattn::F16, 4, 2, 2, VTS>), grid, block, 2 * LDS_BYTES, st, (const _Float16 *)d_q, (const _Float16 *)d_k_cache, (const _Float16 *)d_v_cache, (_Float16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
+    else hipLaunchKernelGGL((k_prefill_attention<prefillattn::BF16, 4, 2, 2, VTS>), grid, block, 2 * LDS_BYTES, st, (const __bf16 *)d_q, (const __bf16 *)d_k_cache, (const __bf16 *)d_v_cache, (__bf16 *)d_out, rows, pos0, n_heads, n_kv_heads, (long long)max_len, scale_log2, pair);
     LAUNCHCHK();
     return SAMD_OK;
+}
+
+extern "C" {
+
+int samd_prefill_attention(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
+                           int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream) {
+    return prefill_attention_impl<false>(d_q, d_k_cache, d_v_cache, d_out, dtype, rows, pos0, n_heads, n_kv_heads, head_dim, max_len, scale, stream);
+}
+
+// the same over a transposed V cache, d_vt_cache [n_kv_heads][128][max_len] (round 6)
+int samd_prefill_attention_vt(const void *d_q, const void *d_k_cache, const void *d_vt_cache, void *d_out, int32_t dtype, int32_t rows, int32_t pos0,
+                              int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, float scale, void *stream) {
+    return prefill_attention_impl<true>(d_q, d_k_cache, d_vt_cache, d_out, dtype, rows, pos0, n_heads, n_kv_heads, head_dim, max_len, scale, stream);
 }
 
 }  // extern "C"

@@ -85,7 +85,10 @@ constexpr int LDS_BYTES = 2 * (K_BYTES + VT_BYTES);       // per key group
 // is half as long, for one in-workgroup merge (no global partials, no second launch).  8 waves, 136 KiB of LDS: one workgroup per CU.
 // NW waves x NF query fragments of 16 rows each = 128 query rows per workgroup: (4, 2) = fewer LDS reads per MFMA, (8, 1) = half the work per
 // wave and tile, i.e. a shorter chain for the long row blocks (which bound the launch) and four waves per SIMD to hide it behind
-template <typename TT, int NW, int NF, int NG = 1>
+// VTS (round 6): the V half of the cache is TRANSPOSED ([n_kv_heads][128][max_len], the layout samd_tree_attention_vt reads).  The LDS image of a
+// V tile is the same (Vt[d][key], same XOR of the key-pair column); it is then COPIED there -- one 16-byte load and one 16-byte LDS store per
+// 8 keys of a column -- where the row-major cache needs eight v_perm + eight 4-byte stores per pair of 16-byte loads.
+template <typename TT, int NW, int NF, int NG = 1, bool VTS = false>
 #ifndef PA_MINW8
 #define PA_MINW8 4
 #endif
@@ -120,6 +123,12 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
     for (int c = 0; c < KC; c++) { const int u = tid + NT * c; k_off[c] = (uint32_t)((u >> 4) * 256 + 16 * (u & 15)); }
 #pragma unroll
     for (int it = 0; it < VC; it++) { const int item = tid + NT * it; v_off[it] = (uint32_t)((2 * ((item >> 3) & 31)) * 256 + 16 * ((item & 7) + 8 * (item >> 8))); }
+    // VTS: piece u = tid + NT i (i < KC) = column d = u >> 3, keys 8 (u & 7) .. + 8 of the tile; byte offset d max_len 2 + 16 (u & 7) (the host checks max_len < 2^24)
+    uint32_t vt_off[VTS ? KC : 1];
+    if constexpr (VTS) {
+#pragma unroll
+        for (int c = 0; c < KC; c++) { const int u = tid + NT * c; vt_off[c] = (uint32_t)(u >> 3) * (uint32_t)max_len * 2u + 16u * (uint32_t)(u & 7); }
+    }
     auto load_stage = [&](int key0) {
         // A tile that lies inside the cache (every tile but the last one of a cache whose length is not a multiple of 64, and the never-used
         // request past the last tile) takes the precomputed offsets.  The cache's LAST, partial tile clamps every ROW to max_len - 1 instead
@@ -145,6 +154,24 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
         }
         st_k0 = *reinterpret_cast<const uint4 *>(kt + ko[0]); st_k1 = *reinterpret_cast<const uint4 *>(kt + ko[1]);
         if (KC == 4) { st_k2 = *reinterpret_cast<const uint4 *>(kt + ko[2]); st_k3 = *reinterpret_cast<const uint4 *>(kt + ko[3]); }
+        if constexpr (VTS) {
+            const char *vcol = reinterpret_cast<const char *>(vbase);
+            uint32_t vo[KC];
+            if (kc0 + KT <= max_len) {                              // wave-uniform: the whole tile lies inside the cache
+#pragma unroll
+                for (int c = 0; c < KC; c++) vo[c] = vt_off[c] + (uint32_t)kc0 * 2u;
+            } else {                                                // the cache's last, partial tile: 8-key pieces clamped into it (max_len % 8 == 0)
+#pragma unroll
+                for (int c = 0; c < KC; c++) {
+                    const uint32_t ch = (uint32_t)((tid + NT * c) & 7);
+                    long long k0 = kc0 + 8 * ch; k0 = k0 + 8 <= max_len ? k0 : max_len - 8;
+                    vo[c] = vt_off[c] - 16u * ch + (uint32_t)k0 * 2u;
+                }
+            }
+            st_va0 = *reinterpret_cast<const uint4 *>(vcol + vo[0]); st_vb0 = *reinterpret_cast<const uint4 *>(vcol + vo[1]);
+            if (KC == 4) { st_va1 = *reinterpret_cast<const uint4 *>(vcol + vo[KC - 2]); st_vb1 = *reinterpret_cast<const uint4 *>(vcol + vo[KC - 1]); }
+            return;
+        }
         st_va0 = *reinterpret_cast<const uint4 *>(vtb + va[0]); st_vb0 = *reinterpret_cast<const uint4 *>(vtb + vb[0]);
         if (VC == 2) { st_va1 = *reinterpret_cast<const uint4 *>(vtb + va[VC - 1]); st_vb1 = *reinterpret_cast<const uint4 *>(vtb + vb[VC - 1]); }
     };
@@ -173,6 +200,23 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
                 *reinterpret_cast<unsigned int *>(&vt[(d0 + j) * VT_STRIDE + 2 * (p ^ vx)]) = __builtin_amdgcn_perm(wb[j >> 1], wa[j >> 1], (j & 1) ? 0x07060302u : 0x05040100u);
             }
         };
+        if constexpr (VTS) {
+            auto vt_put = [&](int c, uint4 v) {
+                const int u = tid + NT * c, d = u >> 3, ch = u & 7;
+                const int live = total - key0 - 8 * ch;                    // keys of this piece that exist: the others are zero (P = 0 there, but 0 x garbage could be NaN)
+                if (live < 8) {
+                    unsigned m[4];
+#pragma unroll
+                    for (int d2 = 0; d2 < 4; d2++) m[d2] = (2 * d2 < live ? 0xFFFFu : 0u) | (2 * d2 + 1 < live ? 0xFFFF0000u : 0u);
+                    v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+                }
+                // key pairs 4 ch .. 4 ch + 3 of column d; the pair column XORed with 4 x (d chunk & 7) as v_put does (a multiple of 4: the four pairs stay together)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(vt) + d * (VT_STRIDE * 2) + 16 * (ch ^ ((d >> 3) & 7))) = v;
+            };
+            vt_put(0, st_va0); vt_put(1, st_vb0);
+            if (KC == 4) { vt_put(KC - 2, st_va1); vt_put(KC - 1, st_vb1); }
+            return;
+        }
         v_put(0, st_va0, st_vb0);
         if (VC == 2) v_put(1, st_va1, st_vb1);
     };

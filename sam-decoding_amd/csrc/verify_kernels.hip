@@ -145,7 +145,10 @@ __device__ __forceinline__ int att_head_of_block(int bx, int n_heads) {
 // BASELINE configuration -- is the round-4 kernel again: one mask word, no second word to select (round 5 ran ONE generic kernel whose
 // `rel < 64 ? lo >> rel : hi >> (rel - 64)` the compiler turned into exec-mask branches per score in the one computing wave's softmax:
 // 8.81 -> 9.32 us per launch across the bench, +0.5 % on every row bucket's step)
-template <typename TT, bool WIDE>
+// VT (round 6): the V half of the cache is TRANSPOSED ([H_kv][D][max_len], the layout samd_attention_block keeps): a tile's V^T image in LDS is then
+// a straight copy -- four 16-byte loads + four 16-byte LDS stores per thread where the row-major cache needs sixteen 4-byte stores of repacked key
+// pairs (4-way bank-conflicted) in front of the barrier every wave waits at.
+template <typename TT, bool WIDE, bool VT = false>
 __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
                                                         const typename TT::elem *__restrict__ vc, float *__restrict__ ws,
                                                         int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
     const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
     const E *vbase = vc + (size_t)kvh * max_len * ATT_D;
     const bool may_be_active = row_base < n_q_pad;     // n <= n_q_pad: waves beyond the row bucket never compute
-    uint4 kraw[4][4], vra[2], vrb[2];
+    uint4 kraw[4][4], vra[2], vrb[2];                  // (VT: vra[0..1], vrb[0..1] = this thread's four 16-byte pieces of the V^T tile)
     auto load_k = [&](int key0) {
 #pragma unroll
         for (int st = 0; st < 4; st++) {
@@ -204,6 +207,17 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
         }
     };
     auto load_v = [&](int key0) {                      // thread handles key pair (2p, 2p+1) x one 8-wide d chunk, twice
+        if constexpr (VT) {                            // V^T: piece u = tid + 256 i: column d = u >> 3, keys key0 + 8 (u & 7) .. + 8 -- 128 contiguous bytes per d row
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int u = tid + 256 * i, d = u >> 3;
+                int k0 = key0 + 8 * (u & 7);
+                k0 = k0 + 8 <= (int)max_len ? k0 : (int)max_len - 8;              // max_len is a multiple of 8 (checked by the host); such keys lie beyond L + n
+                const uint4 v = *reinterpret_cast<const uint4 *>(vbase + (size_t)d * max_len + k0);
+                if (i == 0) vra[0] = v; else if (i == 1) vra[1] = v; else if (i == 2) vrb[0] = v; else vrb[1] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int p = tid >> 3, ch = (tid & 7) + 8 * it, d0 = 8 * ch;      // a wave's instruction = 8 key rows x 128 contiguous bytes
@@ -243,6 +257,21 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
         //      A wave's load instruction covers 8 key rows x 128 contiguous bytes (round 4: 32 rows x 32 bytes before -- four times the
         //      requests for the same lines; 13.55 -> 13.25 us per layer at L = 800).  The LDS writes below are 4-way bank-conflicted in this
         //      order; an XOR swizzle of the key-pair index that removes the conflicts costs more in address arithmetic than it saves (13.5)
+        if constexpr (VT) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int u = tid + 256 * i, d = u >> 3, kc8 = 8 * (u & 7);
+                uint4 v = i == 0 ? vra[0] : (i == 1 ? vra[1] : (i == 2 ? vrb[0] : vrb[1]));
+                const int live = total - key0 - kc8;                               // keys of this piece that exist (< 8: the context's last tile only)
+                if (live < 8) {
+                    unsigned m[4];
+#pragma unroll
+                    for (int d2 = 0; d2 < 4; d2++) m[d2] = (2 * d2 < live ? 0xFFFFu : 0u) | (2 * d2 + 1 < live ? 0xFFFF0000u : 0u);
+                    v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+                }
+                *reinterpret_cast<uint4 *>(&Vt[d * VT_STRIDE + kc8]) = v;
+            }
+        } else
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int p = tid >> 3, ch = (tid & 7) + 8 * it, d0 = 8 * ch;      // a wave's instruction = 8 key rows x 128 contiguous bytes
@@ -334,6 +363,154 @@ __global__ __launch_bounds__(256) void k_tree_attention(const typename TT::elem 
                 for (int dt = 0; dt < 8; dt++) dst[16 * dt + lr] = o[dt][r];
                 if (lr == 0) { dst[ATT_D] = m_run[r]; dst[ATT_D + 1] = l_run[r]; }
             }
+        }
+    }
+}
+
+// <= 16 draft rows over a TRANSPOSED V cache (round 6): ONE wave per (head, split) -- the row-major kernel above keeps three more waves per
+// workgroup whose only work is to repack the V tile into LDS in front of a barrier.  V^T in memory IS the B operand of P V (column d = 16 dt + lr,
+// keys 32 kcx + 8 lg .. + 8: one 16-byte load per MFMA), so nothing is staged and no workgroup barrier exists; the only LDS traffic is the wave's
+// own 16 x 64 P tile (C layout -> A layout).  Same MFMAs over the same key order as k_tree_attention: bit-identical partials.
+template <typename TT>
+__global__ __launch_bounds__(64) void k_tree_attention_direct(const typename TT::elem *__restrict__ q, const typename TT::elem *__restrict__ kc,
+                                                               const typename TT::elem *__restrict__ vt, float *__restrict__ ws,
+                                                               int n_q_pad, int n_heads, int n_kv_heads, long long max_len,
+                                                               const unsigned long long *__restrict__ mask, const int *__restrict__ d_L,
+                                                               const int *__restrict__ d_n, float scale_log2, WarmArgs warm) {
+    typedef typename TT::elem E;
+    typedef typename TT::vec8 V8;
+    __shared__ __attribute__((aligned(16))) E Pw[16 * P_STRIDE];
+    const int h = att_head_of_block(blockIdx.x, n_heads), split = blockIdx.y;
+    if (split >= ATT_SPLITS) {
+        const unsigned a = warm_next_projection(warm, (split - ATT_SPLITS) * n_heads + h);
+        if (a == 0x9E3779B9u && n_q_pad < 0) ws[0] = 0.f;
+        return;
+    }
+    const int l = threadIdx.x, lr = l & 15, lg = l >> 4;
+    V8 qa[4];
+    {
+        const E *qp = q + ((size_t)lr * n_heads + h) * ATT_D + 8 * lg;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (lr < n_q_pad) raw = *reinterpret_cast<const uint4 *>(qp + 32 * kk);
+            qa[kk] = __builtin_bit_cast(V8, raw);
+        }
+    }
+    unsigned long long mrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) mrow[r] = 4 * lg + r < n_q_pad ? mask[4 * lg + r] : 0ull;
+    const int kvh = h / (n_heads / n_kv_heads);
+    const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
+    const E *vbase = vt + (size_t)kvh * max_len * ATT_D;
+    uint4 kraw[4][4], vraw[8][2];
+    auto load_kv = [&](int key0) {
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            int key = key0 + 16 * st + lr;
+            key = key < (int)max_len ? key : (int)max_len - 1;
+            const E *kp = kbase + (size_t)key * ATT_D + 8 * lg;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) kraw[st][kk] = *reinterpret_cast<const uint4 *>(kp + 32 * kk);
+        }
+#pragma unroll
+        for (int kcx = 0; kcx < 2; kcx++) {
+            int k0 = key0 + 32 * kcx + 8 * lg;
+            k0 = k0 + 8 <= (int)max_len ? k0 : (int)max_len - 8;                  // max_len % 8 == 0 (host check); such keys lie beyond L + n
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++) vraw[dt][kcx] = *reinterpret_cast<const uint4 *>(vbase + (size_t)(16 * dt + lr) * max_len + k0);
+        }
+    };
+    load_kv(split * ATT_TILE);
+    const int L = d_L[0];
+    int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
+    const int total = L + n;
+    const int ntiles = (total + ATT_TILE - 1) / ATT_TILE;
+    if (split >= ntiles) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (4 * lg + r >= n) mrow[r] = 0ull;
+    float m_run[4], l_run[4];
+    floatx4 o[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+#pragma unroll
+    for (int dt = 0; dt < 8; dt++) o[dt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    for (int t = split; t < ntiles; t += ATT_SPLITS) {
+        const int key0 = t * ATT_TILE;
+        if (t != split) load_kv(key0);
+        floatx4 s[4];
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            floatx4 acc = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc = Mfma<TT>::run(qa[kk], __builtin_bit_cast(V8, kraw[st][kk]), acc);
+            s[st] = acc;
+        }
+        float tmax[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) tmax[r] = -INFINITY;
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+            const int key = key0 + 16 * st + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rel = key - L;
+                const bool ok = (key < L) | ((key < total) & (bool)((mrow[r] >> (rel & 63)) & 1ull));
+                const float v = ok ? s[st][r] * scale_log2 : -INFINITY;
+                s[st][r] = v;
+                tmax[r] = fmaxf(tmax[r], v);
+            }
+        }
+        if (t != split) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the previous tile's P reads are done
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float v = row16_max(tmax[r]);
+            const float m_new = fmaxf(m_run[r], v);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[r] - m_use);
+            float psum = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                const float p = __builtin_amdgcn_exp2f(s[st][r] - m_use);
+                psum += p;
+                Pw[(4 * lg + r) * P_STRIDE + 16 * st + lr] = (E)p;
+            }
+            psum = row16_sum(psum);
+            l_run[r] = l_run[r] * alpha + psum;
+            m_run[r] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++) o[dt][r] *= alpha;
+        }
+        // keys past L + n: P is 0 there, but 0 x garbage could be NaN -- zero those V^T elements (the context's last tile only)
+        if (key0 + ATT_TILE > total) {
+#pragma unroll
+            for (int kcx = 0; kcx < 2; kcx++) {
+                const int live = total - key0 - 32 * kcx - 8 * lg;
+                unsigned m[4];
+#pragma unroll
+                for (int d2 = 0; d2 < 4; d2++) m[d2] = (2 * d2 < live ? 0xFFFFu : 0u) | (2 * d2 + 1 < live ? 0xFFFF0000u : 0u);
+#pragma unroll
+                for (int dt = 0; dt < 8; dt++) { vraw[dt][kcx].x &= m[0]; vraw[dt][kcx].y &= m[1]; vraw[dt][kcx].z &= m[2]; vraw[dt][kcx].w &= m[3]; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();                           // the wave's own P tile is written
+        V8 pa[2];
+#pragma unroll
+        for (int kcx = 0; kcx < 2; kcx++) pa[kcx] = __builtin_bit_cast(V8, *reinterpret_cast<const uint4 *>(&Pw[lr * P_STRIDE + 32 * kcx + 8 * lg]));
+#pragma unroll
+        for (int dt = 0; dt < 8; dt++) {
+#pragma unroll
+            for (int kcx = 0; kcx < 2; kcx++) o[dt] = Mfma<TT>::run(pa[kcx], __builtin_bit_cast(V8, vraw[dt][kcx]), o[dt]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * lg + r;
+        float *dst = ws + (((size_t)split * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
+        if (row < n) {
+#pragma unroll
+            for (int dt = 0; dt < 8; dt++) dst[16 * dt + lr] = o[dt][r];
+            if (lr == 0) { dst[ATT_D] = m_run[r]; dst[ATT_D + 1] = l_run[r]; }
         }
     }
 }
@@ -1054,10 +1231,16 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                                     scale, d_workspace, workspace_bytes, nullptr, stream);
 }
 
+static bool att_direct_on() {                  // SAMD_ATT_DIRECT=0: the four-wave kernel also at <= 16 rows of a transposed-V cache (A/B switch)
+    static const bool on = [] { const char *e = getenv("SAMD_ATT_DIRECT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int tree_attention_impl(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
                                int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
                                const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
-                               const samd_warm_t *next, int *d_arrive, void *stream) {
+                               const samd_warm_t *next, int *d_arrive, void *stream, int v_transposed = 0) {
+    if (v_transposed && (max_len < 8 || max_len % 8 != 0)) { samd_set_error("samd_tree_attention_vt: max_len must be a multiple of 8"); return SAMD_E_INVALID; }
     // the output projection's warm-up rides on the split launch (the longest glue launch of a layer) or on the merge launch
     const WarmArgs none = warm_args(nullptr);
     const WarmArgs wa_split = next && next->where == 0 ? warm_args(next) : none, wa = next && next->where != 0 ? warm_args(next) : none;
@@ -1073,14 +1256,21 @@ static int tree_attention_impl(const void *d_q, const void *d_k_cache, const voi
     hipStream_t st = (hipStream_t)stream;
     const float scale_log2 = scale * 1.4426950408889634f;
     float *ws = (float *)d_workspace;
-#define ATT_GO(TT, ET, W) hipLaunchKernelGGL((k_tree_attention<TT, W>), dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const ET *)d_q, \
+#define ATT_GO(TT, ET, W) if (v_transposed && n_q_pad <= 16 && att_direct_on()) \
+                          hipLaunchKernelGGL((k_tree_attention_direct<TT>), dim3(n_heads, ATT_SPLITS + warm_splits), dim3(64), 0, st, (const ET *)d_q, \
+                           (const ET *)d_k_cache, (const ET *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len, \
+                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split); \
+                      else if (v_transposed) hipLaunchKernelGGL((k_tree_attention<TT, W, true>), dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const ET *)d_q, \
+                           (const ET *)d_k_cache, (const ET *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len, \
+                           (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split); \
+                      else hipLaunchKernelGGL((k_tree_attention<TT, W>), dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const ET *)d_q, \
                            (const ET *)d_k_cache, (const ET *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len, \
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split)
     if (dtype == SAMD_F16) {
-        if (row_tiles > 1) ATT_GO(F16, _Float16, true); else ATT_GO(F16, _Float16, false);
+        if (row_tiles > 1) { ATT_GO(F16, _Float16, true); } else { ATT_GO(F16, _Float16, false); }
         hipLaunchKernelGGL(k_attn_combine<_Float16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (_Float16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     } else {
-        if (row_tiles > 1) ATT_GO(BF16, __bf16, true); else ATT_GO(BF16, __bf16, false);
+        if (row_tiles > 1) { ATT_GO(BF16, __bf16, true); } else { ATT_GO(BF16, __bf16, false); }
         hipLaunchKernelGGL(k_attn_combine<__bf16>, dim3(n_heads, n_q_pad + warm_rows), dim3(ATT_D), 0, st, ws, (__bf16 *)d_out, n_q_pad, n_heads, d_cache_length, d_n, wa, d_arrive);
     }
 #undef ATT_GO
@@ -1094,6 +1284,17 @@ int samd_tree_attention_warm(const void *d_q, const void *d_k_cache, const void 
                              const samd_warm_t *next, void *stream) {
     return tree_attention_impl(d_q, d_k_cache, d_v_cache, d_out, dtype, n_q_pad, n_heads, n_kv_heads, head_dim, max_len, d_mask, d_cache_length, d_n, scale,
                                d_workspace, workspace_bytes, next, nullptr, stream);
+}
+
+/* round 6: the same attention (samd_tree_attention_warm: `next` may be NULL) over a cache whose V half is TRANSPOSED ([H_kv][D][max_len], as
+ * samd_attention_block keeps it; samd_gemm_qkv_rope*_vt, samd_rope_kv_write*_vt and samd_kv_compact*_vt maintain it): at <= 16 rows ONE wave per (head, split) feeds
+ * its MFMAs straight from the V^T rows (k_tree_attention_direct: no LDS staging, no barrier); wider drafts copy the V^T tile into LDS instead of repacking it. */
+int samd_tree_attention_vt(const void *d_q, const void *d_k_cache, const void *d_vt_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
+                           int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, int64_t max_len, const uint64_t *d_mask,
+                           const int32_t *d_cache_length, const int32_t *d_n, float scale, void *d_workspace, int64_t workspace_bytes,
+                           const samd_warm_t *next, void *stream) {
+    return tree_attention_impl(d_q, d_k_cache, d_vt_cache, d_out, dtype, n_q_pad, n_heads, n_kv_heads, head_dim, max_len, d_mask, d_cache_length, d_n, scale,
+                               d_workspace, workspace_bytes, next, nullptr, stream, 1);
 }
 
 int samd_tree_attention_signal(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,

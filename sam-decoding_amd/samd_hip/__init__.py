@@ -112,6 +112,7 @@ _PROTOS = {
     "samd_embed_rows_ssq": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "samd_embed_rows_ssq_rope": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "samd_gemm_qkv_rope_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
+    "samd_gemm_qkv_rope_norm_vt": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
     "samd_gemm_pairs_silu_norm": (C.c_int, [_VP, _VP, _VP, C.c_float, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_cs_residual": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _I32, _VP]),
     "samd_gemm_cs_residual_early": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _I32, _VP, _VP, _I32, _VP]),
@@ -136,6 +137,8 @@ _PROTOS = {
     "samd_tree_attention_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_tree_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
                                       _VP, _I64, _VP]),
+    "samd_tree_attention_vt": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
+                                         _VP, _I64, _VP, _VP]),
     "samd_tree_attention_warm": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32,
                                            _VP, _I64, _VP, _VP]),
     "samd_rope_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
@@ -143,6 +146,7 @@ _PROTOS = {
     "samd_tree_attention_rope_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_tree_attention_rope": (C.c_int, [_VP, _I32, _I64, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I64, _VP, _VP, _VP, _F32, _VP, _I64, _VP]),
     "samd_rope_kv_write_cs": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I64, _VP]),
+    "samd_rope_kv_write_cs_vt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I64, _VP]),
     "samd_rope_kv_write_vt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
     "samd_kv_compact_vt": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I64, _I32, _I32, _VP]),
     "samd_kv_compact_indices_vt": (C.c_int, [_VP, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _VP, _I32, _VP]),
@@ -160,6 +164,7 @@ _PROTOS = {
     "samd_rope_kv_write": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I64, _I32, _I32, _I32, _I64, _VP]),
     "samd_silu_mul": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I64, _VP]),
     "samd_prefill_attention": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I64, C.c_float, _VP]),
+    "samd_prefill_attention_vt": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I64, C.c_float, _VP]),
     "samd_gemm_splits": (C.c_int, [_I32, _I32, _I32]),
     "samd_gemm_workspace": (_I64, [_I32, _I32, _I32]),
     "samd_gemm_pack_weights": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
@@ -170,6 +175,7 @@ _PROTOS = {
     "samd_gemm_pack_groups": (C.c_int, [_VP, _VP, _I32, _I32, _VP]),
     "samd_gemm_pairs_silu": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _I32, _VP]),
     "samd_gemm_qkv_rope": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
+    "samd_gemm_qkv_rope_vt": (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I64, _I32, _VP]),
     "samd_recycle_create": (C.c_int, [_I32, _VP, _VP, _I32, _VP]),
     "samd_recycle_free": (None, [_VP]),
     "samd_recycle_update": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _VP, _I64, _I64, _VP]),

@@ -114,7 +114,12 @@ class LlamaRunner:
         self.attention = attention or os.environ.get("SAMD_ATTENTION", "split")
         if self.attention not in ("split", "split2", "split3", "block"):
             raise SamdError(f"unknown attention mode '{self.attention}'")
-        self.v_transposed = self.attention == "block"
+        # round 6: "split" / "split3" keep V TRANSPOSED too ([H_kv][D][max_len]) wherever the cache length allows 16-byte loads along it: at <= 16 rows
+        # samd_tree_attention_vt then runs one wave per (head, KV split) that feeds its MFMAs straight from the V^T rows -- no LDS staging, no
+        # workgroup barrier, 11.9 -> 11.0 us per layer at 8 rows (profiles/r06_attention.md).  SAMD_V_LAYOUT=rows keeps the row-major cache (A/B).
+        self.v_layout_t = self.attention == "block" or (self.attention in ("split", "split3") and s.head_dim == 128
+                                                        and os.environ.get("SAMD_V_LAYOUT", "t") != "rows")
+        self.v_transposed = self.v_layout_t
         # second copy of the projection weights in the streaming kernel's packed layout (samd_gemm_pack_weights): the
         # row-major originals stay for the wide prefill's library GEMMs.  2 x 13.5 GB for a 7B model -- HBM capacity
         # (288 GB) is not what this path is short of, bandwidth is.
@@ -233,8 +238,11 @@ class LlamaRunner:
         (row-major + packed) do not, so a different max_cache_len between generate() calls re-runs only this."""
         s, dtype = self.shape, self.dtype
         self.max_len = int(max_cache_len)
+        self.v_transposed = self.v_layout_t
         if self.v_transposed and (self.max_len < 8 or self.max_len % 8 != 0):
-            raise SamdError(f"max_cache_len {self.max_len} must be a multiple of 8 (16-byte loads along the transposed V cache)")
+            if self.attention == "block":
+                raise SamdError(f"max_cache_len {self.max_len} must be a multiple of 8 (16-byte loads along the transposed V cache)")
+            self.v_transposed = False                 # the split launches also read a row-major cache: an odd cache length takes that form
         # KV cache: SamdStaticCache's [1, H_kv, max_cache_len, D] per layer (SO/cache.py:75-84), one allocation
         self.kv = self.kv_ptrs = None
         self.bind_cache(kv if kv is not None else
@@ -442,6 +450,7 @@ class LlamaRunner:
                 b["x"][:rows_in].copy_(x_in[:rows_in])            # rows past d_n are never consumed
         head = getattr(self, "draft_head", False)
         block = self.attention == "block"
+        vt = self.v_transposed and not block          # the split launches over a transposed V cache (round 6)
         if self.attention != "split3":
             # cos / sin of every row's position (visible length + relative position), once per forward: the attention launches of all
             # layers read them without first having to wait for L
@@ -462,8 +471,9 @@ class LlamaRunner:
             fused_qkv = wp.get("wqkv64") is not None and self.attention == "split" and RP <= self.native_gemm_max_rows and d_vis is None
             if fused_qkv:
                 # q|k|v projection + RoPE + K/V row write in one launch (csrc/gemm_kernels.hip: k_gemm_qkv_rope)
-                check(L.samd_gemm_qkv_rope(_ptr(b["x"] if raw_in else b["h"]), _ptr(wp["wqkv64"]), RP, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
-                                           _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, self.max_len, dt, st))
+                check((L.samd_gemm_qkv_rope_vt if vt else L.samd_gemm_qkv_rope)(
+                    _ptr(b["x"] if raw_in else b["h"]), _ptr(wp["wqkv64"]), RP, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
+                    _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, self.max_len, dt, st))
             else:
                 src, n_p, stride = gemm(b["x"] if raw_in else b["h"], w["wqkv"], wp.get("wqkv"), b["qkv"])
             if block:
@@ -478,15 +488,18 @@ class LlamaRunner:
                 if fused_qkv:
                     pass
                 elif self.attention == "split":
-                    check(L.samd_rope_kv_write_cs(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(b["cs"]), _ptr(b["q"]), _ptr(self.kv[li, 0]),
-                                                  _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads, s.head_dim, self.max_len, dt, n_p, stride, st))
+                    check((L.samd_rope_kv_write_cs_vt if vt else L.samd_rope_kv_write_cs)(
+                        _ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(b["cs"]), _ptr(b["q"]), _ptr(self.kv[li, 0]),
+                        _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads, s.head_dim, self.max_len, dt, n_p, stride, st))
                 else:
-                    check(L.samd_rope_kv_write(_ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
-                                               _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
-                                               s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
-                check(L.samd_tree_attention_warm(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
-                                                 s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
-                                                 _ptr(b["ws"]), b["ws_bytes"], hint(w["wo"], wp.get("wo")), st))
+                    check((L.samd_rope_kv_write_vt if vt else L.samd_rope_kv_write)(
+                        _ptr(src), _ptr(d_relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin),
+                        _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), R, s.heads, s.kv_heads,
+                        s.head_dim, self.max_len, self.rope_rows, dt, n_p, stride, st))
+                check((L.samd_tree_attention_vt if vt else L.samd_tree_attention_warm)(
+                    _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
+                    s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                    _ptr(b["ws"]), b["ws_bytes"], hint(w["wo"], wp.get("wo")), st))
             src, n_p, stride = gemm(b["attn"].view(b["attn"].shape[0], -1), w["wo"], wp.get("wo"), b["o"], wg=wp.get("wo_g"))
             check(L.samd_rmsnorm_warm(_ptr(b["x"]), _ptr(src), _ptr(w["ln2"]), _ptr(b["h"]), R, s.hidden, s.eps, dt, n_p, stride,
                                       None, st))           # (no warm-up hint: gate|up is packed group-major, the hint describes 128-column tiles)
@@ -520,14 +533,17 @@ class LlamaRunner:
             check(L.samd_embed_rows_ssq(_ptr(d_tokens), _ptr(self.w["embed"]), _ptr(x), _ptr(ssq), 16, s.hidden, s.vocab, dt, st))
             check(L.samd_rope_rows(_ptr(d_relpos), _ptr(d_L), _ptr(self.cos), _ptr(self.sin), _ptr(b["cs"]), R, s.head_dim, self.rope_rows, st))
         attn2d = b["attn"].view(b["attn"].shape[0], -1)
+        # round 6: over a transposed V cache the projection's epilogue writes V^T columns and the attention is the one-wave-per-split launch
+        qkv_launch = L.samd_gemm_qkv_rope_norm_vt if self.v_transposed else L.samd_gemm_qkv_rope_norm
+        attn_launch = L.samd_tree_attention_vt if self.v_transposed else L.samd_tree_attention_warm
         for li, (w, wp) in enumerate(zip(self.w["layers"], self.wp["layers"])):
             if self.layer_hook is not None:
                 self.layer_hook(li)
-            check(L.samd_gemm_qkv_rope_norm(_ptr(x), _ptr(ssq), _ptr(w["ln1"]), s.eps, _ptr(wp["wqkv64"]), rows_a, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
-                                            _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, self.max_len, dt, st))
-            check(L.samd_tree_attention_warm(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
-                                             s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
-                                             _ptr(b["ws"]), b["ws_bytes"], None, st))
+            check(qkv_launch(_ptr(x), _ptr(ssq), _ptr(w["ln1"]), s.eps, _ptr(wp["wqkv64"]), rows_a, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
+                             _ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, self.max_len, dt, st))
+            check(attn_launch(_ptr(b["q"]), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(b["attn"]), dt, R, s.heads,
+                              s.kv_heads, s.head_dim, self.max_len, _ptr(d_mask), _ptr(d_L), _ptr(d_n), self.scale,
+                              _ptr(b["ws"]), b["ws_bytes"], None, st))
             check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(wp["wo_g"]), rows_cs, s.hidden, attn2d.shape[1], _ptr(x), _ptr(ssq), dt, st))
             check(L.samd_gemm_pairs_silu_norm(_ptr(x), _ptr(ssq), _ptr(w["ln2"]), s.eps, _ptr(wp["wgu"]), rows_a, s.inter, s.hidden, _ptr(b["act"]), dt, st))
             check(L.samd_gemm_cs_residual(_ptr(b["act"]), _ptr(wp["wdown_g"]), rows_cs, s.hidden, s.inter, _ptr(x), _ptr(ssq), dt, st))
@@ -647,7 +663,7 @@ class LlamaRunner:
 
     def _prefill_wide(self, session: Session, ids, on_chunk=None):
         """the whole prompt in one pass: compute-bound, so the GEMMs go to the library (N x K x N_out at full MFMA rate) and
-        the causal attention to samd_prefill_attention (round 5; PyTorch's fused SDPA before, and still for a transposed V cache); norm /
+        the causal attention to samd_prefill_attention / samd_prefill_attention_vt (round 5; PyTorch's fused SDPA before); norm /
         RoPE + K/V write / SiLU*up / arg-max are our kernels as well.  A
         per-chunk consumer (Token Recycle: the prompt's logits, EAGLE: its last hidden states) gets them afterwards in
         64-row slices of one [N, V] lm_head product.  Round 5: a projection whose row count sits just past a tile-quantisation step of
@@ -658,8 +674,8 @@ class LlamaRunner:
         z = lambda *sz: torch.empty(sz, dtype=ty, device=dev)
         x, h = z(N, s.hidden), z(N, s.hidden)
         # the prompt's causal attention: our kernel (samd_prefill_attention: any row count, nothing behind the prompt is read) on the row-major
-        # cache; PyTorch's fused SDPA otherwise (transposed V cache of a draft head's runner, head_dim != 128, SAMD_PREFILL_ATTENTION=sdpa)
-        own_attn = ((not self.v_transposed) and s.head_dim == 128 and os.environ.get("SAMD_PREFILL_ATTENTION", "own") != "sdpa"
+        # or the transposed cache; PyTorch's fused SDPA otherwise (head_dim != 128, SAMD_PREFILL_ATTENTION=sdpa, not a gfx950)
+        own_attn = (s.head_dim == 128 and os.environ.get("SAMD_PREFILL_ATTENTION", "own") != "sdpa"
                     and self._is_gfx950())             # the kernel needs 136 KiB of LDS and gfx950's permlane swaps: any other device takes SDPA
         Np = N if own_attn else -(-N // self.PF_ATTN_PAD) * self.PF_ATTN_PAD
         if Np > self.max_len:
@@ -695,8 +711,9 @@ class LlamaRunner:
                                            self.rope_rows, dt, 0, 0, st))
                 vv = self.kv[li, 1][:, :Np]
             if own_attn:
-                check(L.samd_prefill_attention(_ptr(q), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(ao), dt, N, 0, s.heads, s.kv_heads,
-                                               s.head_dim, self.max_len, self.scale, st))
+                check((L.samd_prefill_attention_vt if self.v_transposed else L.samd_prefill_attention)(
+                    _ptr(q), _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), _ptr(ao), dt, N, 0, s.heads, s.kv_heads,
+                    s.head_dim, self.max_len, self.scale, st))
                 self._pf_mm(ao, w["wo"], o, "wo")
             else:
                 kk = self.kv[li, 0][:, :Np]

@@ -12,6 +12,8 @@ H, D, layers, max_len = 32, 128, 32, 2048
 Hkv = 8 if "gqa" in sys.argv[1:] else H          # "gqa": Llama-3-8B geometry (4 query heads per KV head)
 Lib = lib()
 kv = (torch.randn((layers, 2, Hkv, max_len, D), device="cuda") * 0.5).half()
+VT = "vt" in sys.argv[1:] and hasattr(Lib, "samd_tree_attention_vt")          # "vt": also time the transposed-V variant (and compare its output bit for bit)
+vt = kv[:, 1].transpose(-1, -2).contiguous() if VT else None
 s0 = torch.cuda.Stream()
 st = samd_hip.C.c_void_p(s0.cuda_stream)
 mask = torch.tensor([(1 << (i + 1)) - 1 if i < 63 else -1 for i in range(64)], dtype=torch.int64, device="cuda")
@@ -27,15 +29,33 @@ for L0 in Ls:
             for li in range(layers):
                 check(Lib.samd_tree_attention(_ptr(q), _ptr(kv[li, 0]), _ptr(kv[li, 1]), _ptr(out), samd_hip.F16, R, H, Hkv, D, max_len, _ptr(mask), _ptr(d_L), _ptr(d_n),
                                               1.0 / math.sqrt(D), _ptr(ws), ws.numel(), st))
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(s0):
-            run(); s0.synchronize()
-            with torch.cuda.graph(g, stream=s0):
-                run()
-            g.replay(); s0.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(40):
-                g.replay()
-            s0.synchronize()
-        row.append((time.perf_counter() - t0) / 40 * 1e6 / layers)
-    print(f"H={H} Hkv={Hkv} L={L0}: 8 rows {row[0]:.2f} us/layer, 16 rows {row[1]:.2f}, 32 rows {row[2]:.2f}, 64 rows {row[3]:.2f}")
+        out_t = torch.zeros_like(out)
+
+        def run_vt():
+            for li in range(layers):
+                check(Lib.samd_tree_attention_vt(_ptr(q), _ptr(kv[li, 0]), _ptr(vt[li]), _ptr(out_t), samd_hip.F16, R, H, Hkv, D, max_len, _ptr(mask), _ptr(d_L), _ptr(d_n),
+                                                 1.0 / math.sqrt(D), _ptr(ws), ws.numel(), None, st))
+
+        def timed(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s0):
+                fn(); s0.synchronize()
+                with torch.cuda.graph(g, stream=s0):
+                    fn()
+                g.replay(); s0.synchronize()
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for _ in range(40):
+                        g.replay()
+                    s0.synchronize()
+                    best = min(best, (time.perf_counter() - t0) / 40 * 1e6 / layers)
+            return best
+        t = timed(run)
+        if VT:
+            tv = timed(run_vt)
+            same = bool(torch.equal(out, out_t))
+            row.append(f"{t:.2f} | vt {tv:.2f}{'' if same else ' MISMATCH ' + str((out.float() - out_t.float()).abs().max().item())}")
+        else:
+            row.append(f"{t:.2f}")
+    print(f"H={H} Hkv={Hkv} L={L0}: 8 rows {row[0]} us/layer, 16 rows {row[1]}, 32 rows {row[2]}, 64 rows {row[3]}")

@@ -394,18 +394,21 @@ def test_token_recycle_on_real_logits_is_lossless():
 
 
 def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
-    """prompts of >= 128 tokens go through the one-pass prefill (library GEMMs + samd_prefill_attention, or fused causal SDPA on a transposed V
-    cache / with SAMD_PREFILL_ATTENTION=sdpa); K/V cache, last logits and the following decode must agree with the chunked path and with HF
-    (fp16 tolerance 3e-2); the transposed V cache must hold exactly what the row-major one holds when both run the same attention."""
+    """prompts of >= 128 tokens go through the one-pass prefill (library GEMMs + samd_prefill_attention / samd_prefill_attention_vt, or fused
+    causal SDPA with SAMD_PREFILL_ATTENTION=sdpa); K/V cache, last logits and the following decode must agree with the chunked path and with HF
+    (fp16 tolerance 3e-2); the transposed V cache (round 6: the default of "split" as well as "block") must hold exactly what the row-major one
+    (SAMD_V_LAYOUT=rows) holds when both run the same attention."""
     lm = tiny_llama(2, seed=13)
     rng = np.random.default_rng(13)
     prompt = rng.integers(3, 512, 200).tolist()
     ids = torch.tensor([prompt], device="cuda")
     outs = {}
-    for mode in ("wide", "chunked", "wide-block", "wide-sdpa"):
+    for mode in ("wide", "chunked", "wide-block", "wide-sdpa", "wide-rows", "wide-rows-sdpa"):
         monkeypatch.setenv("SAMD_PREFILL", mode.split("-")[0])
         monkeypatch.setenv("SAMD_PREFILL_ATTENTION", "sdpa" if mode.endswith("sdpa") else "own")
+        monkeypatch.setenv("SAMD_V_LAYOUT", "rows" if "rows" in mode else "t")
         runner = LlamaRunner.from_hf(lm, max_cache_len=512, dtype=torch.float16, attention="block" if mode.endswith("block") else "split")
+        assert runner.v_transposed == ("rows" not in mode)
         sess = samd_hip.Session(1024)
         last = runner.prefill(sess, ids)
         torch.cuda.synchronize()
@@ -421,11 +424,12 @@ def test_wide_prefill_matches_chunked_and_hf(monkeypatch):
     assert outs["wide"][2] == outs["chunked"][2] == 200
     assert (outs["wide"][0] - ref).abs().max().item() < TOL and (outs["chunked"][0] - ref).abs().max().item() < TOL
     assert (outs["wide"][1] - outs["chunked"][1]).abs().max().item() < 2e-2          # same K/V rows up to fp16 GEMM rounding
-    assert torch.equal(outs["wide-sdpa"][1], outs["wide-block"][1])                   # the transposed V cache holds the same values
+    assert torch.equal(outs["wide-rows"][1], outs["wide"][1]) and torch.equal(outs["wide-rows"][0], outs["wide"][0])     # the transposed V cache holds the same values
+    assert torch.equal(outs["wide-rows-sdpa"][1], outs["wide-sdpa"][1]) and torch.equal(outs["wide-block"][1], outs["wide"][1])
     assert (outs["wide"][1] - outs["wide-sdpa"][1]).abs().max().item() < 2e-2         # our attention kernel / fused SDPA: fp16 roundings
     with torch.no_grad():
         full = lm(input_ids=ids, output_hidden_states=True)
-    for mode in ("wide", "chunked", "wide-block", "wide-sdpa"):
+    for mode in outs:
         toks, logits, hidden = outs[mode][3:]
         assert toks.tolist() == prompt and logits.shape == (200, 512) and hidden.shape == (200, 256)
         assert (logits - full.logits[0]).abs().max().item() < TOL

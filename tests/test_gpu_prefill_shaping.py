@@ -32,7 +32,7 @@ def test_padded_attention_and_split_projections_leave_the_prefill_unchanged(N, m
         sess.reset()
         logits = runner.prefill(sess, ids).float().clone()
         torch.cuda.synchronize()
-        return logits, runner.kv[:, :, :, :N].float().clone()
+        return logits, torch.stack(runner.kv_rows(N), 1).float().clone()      # [layers, K | V, H_kv, N, D] whatever the V layout
 
     plain_logits, plain_kv = run({}, 1)
     shaped_logits, shaped_kv = run(all_splits(), 128)
@@ -210,7 +210,7 @@ def test_prefill_with_own_attention_matches_the_sdpa_form(N, monkeypatch):
         monkeypatch.setenv("SAMD_PREFILL_ATTENTION", mode)
         runner.kv.fill_(float("nan"))
         sess.reset()
-        res[mode] = (runner.prefill(sess, ids).float().clone(), runner.kv[:, :, :, :N].float().clone())
+        res[mode] = (runner.prefill(sess, ids).float().clone(), torch.stack(runner.kv_rows(N), 1).float().clone())
         torch.cuda.synchronize()
     with torch.no_grad():
         want = lm(input_ids=ids, logits_to_keep=1).logits[0, -1].float()

@@ -168,7 +168,7 @@ def test_generate_with_128_node_drafts_on_a_real_decoder():
         out = model.generate(torch.tensor([prompt], dtype=torch.long, device="cuda"), generation_config=gcfg)
         torch.cuda.synchronize()
         outs[mp] = (out.output_ids[0], out.accepet_length_per_step, dict(model.engine.bucket_steps))
-        kv[mp] = runner.kv[:, :, :, :len(prompt) + 380].float().clone()
+        kv[mp] = torch.stack(runner.kv_rows(len(prompt) + 380), 1).float().clone()
         del model, sa, runner
         torch.cuda.empty_cache()
     ar, spec = outs[1], outs[128]
