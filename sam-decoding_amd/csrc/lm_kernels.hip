@@ -267,6 +267,48 @@ __global__ __launch_bounds__(64) void k_rope_kv_wide(const T *__restrict__ qkv, 
     *reinterpret_cast<V8 *>(dst + j) = o1; *reinterpret_cast<V8 *>(dst + 64 + j) = o2;
 }
 
+// The prompt's V rows into a TRANSPOSED cache (round 6): vt_cache[kvh][d][L + r] <- qkv[r][H + Hkv + kvh][d] for r < n.  One workgroup = one KV head x
+// 64 rows: the rows are read as 16-byte pieces (a wave's load = 4 rows x 256 contiguous bytes), turned in LDS, and leave as 16-byte pieces of 8 keys
+// of one column (a wave's store = 8 columns x 128 contiguous bytes) -- where k_rope_kv's transposed form writes one 2-byte element per lane and a
+// strided torch copy (what the prefill did before) takes 17-40 us per layer at 0.5-1.5 k rows.  L % 8 != 0 or the prompt's last, partial piece of 8
+// keys: element stores.  16-bit elements of either dtype (a copy).
+__global__ __launch_bounds__(256) void k_v_rows_to_vt(const unsigned short *__restrict__ qkv, const int *__restrict__ d_L, const int *__restrict__ d_n,
+                                                      unsigned short *__restrict__ vt_cache, int rows, int H, int Hkv, long long max_len) {
+    constexpr int RS = 128 + 8;                                  // halfs per staged row: 272 B (16-byte aligned, rows 8 apart fall on different banks)
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * RS];
+    const int tid = threadIdx.x, kvh = blockIdx.y, r0 = 64 * blockIdx.x;
+    int n = d_n[0]; n = n < rows ? n : rows;
+    const int L = d_L[0];
+    const size_t row_elems = (size_t)(H + 2 * Hkv) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = tid + 256 * i, r = u >> 4, sl = u & 15;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < n) v = *reinterpret_cast<const uint4 *>(qkv + (size_t)(r0 + r) * row_elems + (size_t)(H + Hkv + kvh) * 128 + 8 * sl);
+        *reinterpret_cast<uint4 *>(&tile[r * RS + 8 * sl]) = v;
+    }
+    __syncthreads();
+    unsigned short *col0 = vt_cache + (size_t)kvh * 128 * max_len;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = tid + 256 * i, d = u >> 3, kc8 = 8 * (u & 7);
+        const long long key = (long long)L + r0 + kc8;              // cache position of this piece's first key
+        int live = n - r0 - kc8; live = live > 8 ? 8 : live;
+        if (key + live > max_len) live = (int)(max_len - key);      // never write past the cache (k_rope_kv: L + r >= max_len is skipped)
+        if (live <= 0) continue;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = tile[(kc8 + j) * RS + d];
+        unsigned short *dst = col0 + (size_t)d * max_len + key;
+        if (live == 8 && (key & 7) == 0) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16), e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (j < live) dst[j] = e[j];
+        }
+    }
+}
+
 // out = silu(gate) * up, gate|up concatenated per row: gu[r] = [gate(I) | up(I)]
 template <typename T>
 __global__ __launch_bounds__(256) void k_silu_mul(const T *__restrict__ gu, T *__restrict__ out, int inter, int n_part, long long part_stride) {
@@ -364,8 +406,14 @@ static int rope_kv_write(const void *d_qkv, const int32_t *d_rel_pos, const int3
     if (!d_qkv || !d_rel_pos || !d_cache_length || !d_n || ((!d_cos || !d_sin) && !d_cs) || !d_q_out || !d_k_cache || (!d_v_cache && !v_transposed) || rows < 1 ||
         head_dim % 2 != 0 || head_dim > 2048) { samd_set_error("samd_rope_kv_write: invalid argument"); return SAMD_E_INVALID; }
     hipStream_t st = (hipStream_t)stream;
-    if (rows >= 128 && head_dim == 128 && n_partials == 0 && !d_cs && d_cos && d_sin && (!v_transposed || !d_v_cache) && (dtype == SAMD_F16 || dtype == SAMD_BF16)) {
-        const dim3 wgrid(rows, (n_heads + 2 * n_kv_heads + 7) / 8);                    // the prompt's rows: 16-byte lanes
+    if (rows >= 128 && head_dim == 128 && n_partials == 0 && !d_cs && d_cos && d_sin && (dtype == SAMD_F16 || dtype == SAMD_BF16)) {
+        if (v_transposed && d_v_cache) {          // the prompt's V^T columns: a tiled transposition of their own (round 6); q and K rows below
+            if (max_len % 8 != 0) { samd_set_error("samd_rope_kv_write_vt: max_len must be a multiple of 8"); return SAMD_E_INVALID; }
+            hipLaunchKernelGGL(k_v_rows_to_vt, dim3((rows + 63) / 64, n_kv_heads), dim3(256), 0, st, (const unsigned short *)d_qkv, d_cache_length, d_n,
+                               (unsigned short *)d_v_cache, rows, n_heads, n_kv_heads, (long long)max_len);
+            d_v_cache = nullptr;
+        }
+        const dim3 wgrid(rows, (n_heads + (d_v_cache ? 2 : 1) * n_kv_heads + 7) / 8);    // the prompt's rows: 16-byte lanes (no workgroups for V heads nobody writes)
         if (dtype == SAMD_F16) hipLaunchKernelGGL(k_rope_kv_wide<_Float16>, wgrid, dim3(64), 0, st, (const _Float16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (_Float16 *)d_q_out, (_Float16 *)d_k_cache, (_Float16 *)d_v_cache, n_heads, n_kv_heads, (long long)max_len, max_pos);
         else hipLaunchKernelGGL(k_rope_kv_wide<__bf16>, wgrid, dim3(64), 0, st, (const __bf16 *)d_qkv, d_rel_pos, d_cache_length, d_n, d_cos, d_sin, (__bf16 *)d_q_out, (__bf16 *)d_k_cache, (__bf16 *)d_v_cache, n_heads, n_kv_heads, (long long)max_len, max_pos);
         LAUNCHCHK();

@@ -124,11 +124,10 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
 #pragma unroll
     for (int it = 0; it < VC; it++) { const int item = tid + NT * it; v_off[it] = (uint32_t)((2 * ((item >> 3) & 31)) * 256 + 16 * ((item & 7) + 8 * (item >> 8))); }
     // VTS: piece u = tid + NT i (i < KC) = column d = u >> 3, keys 8 (u & 7) .. + 8 of the tile; byte offset d max_len 2 + 16 (u & 7) (the host checks max_len < 2^24)
-    uint32_t vt_off[VTS ? KC : 1];
-    if constexpr (VTS) {
-#pragma unroll
-        for (int c = 0; c < KC; c++) { const int u = tid + NT * c; vt_off[c] = (uint32_t)(u >> 3) * (uint32_t)max_len * 2u + 16u * (uint32_t)(u & 7); }
-    }
+    // NT is a multiple of 8: every piece of a thread has the same 8-key chunk tid & 7, and piece c lies (NT / 8) c columns below piece 0 -- ONE per-lane
+    // offset; the rest of a piece's address is wave-uniform
+    const uint32_t vt_off0 = VTS ? (uint32_t)(tid >> 3) * (uint32_t)max_len * 2u + 16u * (uint32_t)(tid & 7) : 0u;
+    const long long vt_step = (long long)(NT >> 3) * max_len * 2;           // bytes between two pieces of a thread
     auto load_stage = [&](int key0) {
         // A tile that lies inside the cache (every tile but the last one of a cache whose length is not a multiple of 64, and the never-used
         // request past the last tile) takes the precomputed offsets.  The cache's LAST, partial tile clamps every ROW to max_len - 1 instead
@@ -155,21 +154,15 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
         st_k0 = *reinterpret_cast<const uint4 *>(kt + ko[0]); st_k1 = *reinterpret_cast<const uint4 *>(kt + ko[1]);
         if (KC == 4) { st_k2 = *reinterpret_cast<const uint4 *>(kt + ko[2]); st_k3 = *reinterpret_cast<const uint4 *>(kt + ko[3]); }
         if constexpr (VTS) {
-            const char *vcol = reinterpret_cast<const char *>(vbase);
-            uint32_t vo[KC];
-            if (kc0 + KT <= max_len) {                              // wave-uniform: the whole tile lies inside the cache
-#pragma unroll
-                for (int c = 0; c < KC; c++) vo[c] = vt_off[c] + (uint32_t)kc0 * 2u;
-            } else {                                                // the cache's last, partial tile: 8-key pieces clamped into it (max_len % 8 == 0)
-#pragma unroll
-                for (int c = 0; c < KC; c++) {
-                    const uint32_t ch = (uint32_t)((tid + NT * c) & 7);
-                    long long k0 = kc0 + 8 * ch; k0 = k0 + 8 <= max_len ? k0 : max_len - 8;
-                    vo[c] = vt_off[c] - 16u * ch + (uint32_t)k0 * 2u;
-                }
+            const char *vcol = reinterpret_cast<const char *>(vbase) + kc0 * 2;      // wave-uniform
+            long long vo = vt_off0;
+            if (kc0 + KT > max_len) {                               // the cache's last, partial tile: 8-key pieces clamped into it (max_len % 8 == 0)
+                const long long ch = tid & 7;
+                const long long k0 = kc0 + 8 * ch + 8 <= max_len ? kc0 + 8 * ch : max_len - 8;
+                vo += 2 * (k0 - kc0 - 8 * ch);                      // (may be negative: kc0 itself is clamped to the cache's last row)
             }
-            st_va0 = *reinterpret_cast<const uint4 *>(vcol + vo[0]); st_vb0 = *reinterpret_cast<const uint4 *>(vcol + vo[1]);
-            if (KC == 4) { st_va1 = *reinterpret_cast<const uint4 *>(vcol + vo[KC - 2]); st_vb1 = *reinterpret_cast<const uint4 *>(vcol + vo[KC - 1]); }
+            st_va0 = *reinterpret_cast<const uint4 *>(vcol + vo); st_vb0 = *reinterpret_cast<const uint4 *>(vcol + vt_step + vo);
+            if (KC == 4) { st_va1 = *reinterpret_cast<const uint4 *>(vcol + 2 * vt_step + vo); st_vb1 = *reinterpret_cast<const uint4 *>(vcol + 3 * vt_step + vo); }
             return;
         }
         st_va0 = *reinterpret_cast<const uint4 *>(vtb + va[0]); st_vb0 = *reinterpret_cast<const uint4 *>(vtb + vb[0]);
@@ -201,20 +194,25 @@ __global__ __launch_bounds__(64 * NW * NG, NG == 2 ? 2 : (NW == 4 ? PA_MINW4 : P
             }
         };
         if constexpr (VTS) {
-            auto vt_put = [&](int c, uint4 v) {
-                const int u = tid + NT * c, d = u >> 3, ch = u & 7;
-                const int live = total - key0 - 8 * ch;                    // keys of this piece that exist: the others are zero (P = 0 there, but 0 x garbage could be NaN)
-                if (live < 8) {
-                    unsigned m[4];
+            const int ch = tid & 7;                                         // the same 8-key chunk for every piece of this thread
+            if (key0 + KT > total) {                                        // wave-uniform: the prompt's last tile -- keys that do not exist are zero
+                const int live = total - key0 - 8 * ch;                     // (P = 0 there, but 0 x garbage could be NaN)
+                unsigned m[4];
 #pragma unroll
-                    for (int d2 = 0; d2 < 4; d2++) m[d2] = (2 * d2 < live ? 0xFFFFu : 0u) | (2 * d2 + 1 < live ? 0xFFFF0000u : 0u);
-                    v.x &= m[0]; v.y &= m[1]; v.z &= m[2]; v.w &= m[3];
+                for (int d2 = 0; d2 < 4; d2++) m[d2] = (2 * d2 < live ? 0xFFFFu : 0u) | (2 * d2 + 1 < live ? 0xFFFF0000u : 0u);
+                st_va0.x &= m[0]; st_va0.y &= m[1]; st_va0.z &= m[2]; st_va0.w &= m[3];
+                st_vb0.x &= m[0]; st_vb0.y &= m[1]; st_vb0.z &= m[2]; st_vb0.w &= m[3];
+                if (KC == 4) {
+                    st_va1.x &= m[0]; st_va1.y &= m[1]; st_va1.z &= m[2]; st_va1.w &= m[3];
+                    st_vb1.x &= m[0]; st_vb1.y &= m[1]; st_vb1.z &= m[2]; st_vb1.w &= m[3];
                 }
-                // key pairs 4 ch .. 4 ch + 3 of column d; the pair column XORed with 4 x (d chunk & 7) as v_put does (a multiple of 4: the four pairs stay together)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(vt) + d * (VT_STRIDE * 2) + 16 * (ch ^ ((d >> 3) & 7))) = v;
-            };
-            vt_put(0, st_va0); vt_put(1, st_vb0);
-            if (KC == 4) { vt_put(KC - 2, st_va1); vt_put(KC - 1, st_vb1); }
+            }
+            // piece c = column d = (tid >> 3) + (NT / 8) c, key pairs 4 ch .. 4 ch + 3; the pair column XORed with 4 x (d chunk & 7) as v_put does (a multiple
+            // of 4: the four pairs stay together).  (d >> 3) & 7 = (wave + (NT / 64) c) & 7: with NT = 256 it alternates between two values
+            char *vrow = reinterpret_cast<char *>(vt) + (tid >> 3) * (VT_STRIDE * 2);
+            auto slot = [&](int c) { return 16 * (ch ^ (((tid >> 6) + (NT >> 6) * c) & 7)) + c * (NT >> 3) * (VT_STRIDE * 2); };
+            *reinterpret_cast<uint4 *>(vrow + slot(0)) = st_va0; *reinterpret_cast<uint4 *>(vrow + slot(1)) = st_vb0;
+            if (KC == 4) { *reinterpret_cast<uint4 *>(vrow + slot(KC - 2)) = st_va1; *reinterpret_cast<uint4 *>(vrow + slot(KC - 1)) = st_vb1; }
             return;
         }
         v_put(0, st_va0, st_vb0);

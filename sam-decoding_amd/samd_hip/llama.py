@@ -701,10 +701,9 @@ class LlamaRunner:
             self._pf_mm(h, w["wqkv"], qkv, "wqkv")
             if self.v_transposed:
                 check(L.samd_rope_kv_write_vt(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
-                                              _ptr(self.kv[li, 0]), None, N, s.heads, s.kv_heads, s.head_dim, self.max_len,
-                                              self.rope_rows, dt, 0, 0, st))                                         # q and K rows
-                vv = qkv_p[:, (s.heads + s.kv_heads) * s.head_dim:].view(Np, s.kv_heads, s.head_dim).transpose(0, 1)  # V straight from the projection
-                self.kv[li, 1].view(s.kv_heads, s.head_dim, self.max_len)[:, :, :N].copy_(vv[:, :N].transpose(1, 2))     # V^T columns of the cache
+                                              _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), N, s.heads, s.kv_heads, s.head_dim, self.max_len,
+                                              self.rope_rows, dt, 0, 0, st))                                         # q, K rows, V^T columns of the cache
+                vv = qkv_p[:, (s.heads + s.kv_heads) * s.head_dim:].view(Np, s.kv_heads, s.head_dim).transpose(0, 1)  # (SDPA below: V straight from the projection)
             else:
                 check(L.samd_rope_kv_write(_ptr(qkv), _ptr(relpos), _ptr(d_L), _ptr(d_n), _ptr(self.cos), _ptr(self.sin), _ptr(q),
                                            _ptr(self.kv[li, 0]), _ptr(self.kv[li, 1]), N, s.heads, s.kv_heads, s.head_dim, self.max_len,

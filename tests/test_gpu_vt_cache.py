@@ -247,3 +247,34 @@ def test_runner_over_the_transposed_cache_gives_the_row_major_runner_bit_for_bit
     assert odd.v_transposed is False
     sess = samd_hip.Session(515)
     assert torch.equal(odd.prefill(sess, prompt).float(), res["rows"][0][0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,Hkv,rows,L,max_len", [(32, 32, 200, 0, 2048), (32, 8, 1333, 5, 2048), (8, 2, 128, 704, 2048), (4, 4, 300, 8, 304), (2, 1, 129, 3, 136)])
+def test_prompt_rows_reach_the_transposed_cache_through_the_tiled_writer(dtype, H, Hkv, rows, L, max_len):
+    """samd_rope_kv_write_vt from 128 rows on: q and K rows by the 16-byte-lane kernel, the V^T columns by a tiled transposition of their own
+    (16-byte pieces of 8 keys; element stores where L is not a multiple of 8 and for the prompt's last, partial piece).  Held to the row-major
+    samd_rope_kv_write on the same rows; rows >= n, positions outside [L, L + n) and positions past the cache stay untouched."""
+    lib, D = samd_hip.lib(), 128
+    g = torch.Generator(device="cuda").manual_seed(rows + H)
+    qkv = torch.randn((rows, (H + 2 * Hkv) * D), generator=g, device="cuda").to(dtype)
+    ang = torch.outer(torch.arange(max_len, dtype=torch.float64), 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float64) / D)))
+    cos, sin = ang.cos().float().cuda().contiguous(), ang.sin().float().cuda().contiguous()
+    dc = samd_hip.torch_dtype_code(dtype)
+    n = rows - 3
+    rel = torch.arange(rows, dtype=torch.int32, device="cuda")
+    d_L, d_n = dev([L]), dev([n])
+    res = []
+    for fn in (lib.samd_rope_kv_write, lib.samd_rope_kv_write_vt):
+        q = torch.full((rows, H, D), 7.0, device="cuda").to(dtype)
+        k = torch.full((Hkv, max_len, D), 5.0, device="cuda").to(dtype)
+        v = torch.full((Hkv, max_len, D), 3.0, device="cuda").to(dtype)
+        samd_hip.check(fn(P(qkv), P(rel), P(d_L), P(d_n), P(cos), P(sin), P(q), P(k), P(v), rows, H, Hkv, D, max_len, max_len, dc, 0, 0, samd_hip.current_stream()))
+        torch.cuda.synchronize()
+        res.append((q, k, v))
+    (q0, k0, v0), (q1, k1, v1) = res
+    live = min(n, max_len - L)                       # rows whose position lies inside the cache
+    v1t = v1.view(Hkv, D, max_len)
+    assert torch.equal(q0, q1) and torch.equal(k0, k1)
+    assert torch.equal(v1t[:, :, L:L + live].transpose(1, 2), v0[:, L:L + live]) and (v0[:, L:L + live] != 3.0).any()
+    assert (v1t[:, :, :L] == 3.0).all() and (v1t[:, :, L + live:] == 3.0).all()
