@@ -382,24 +382,26 @@ __global__ __launch_bounds__(64) void k_tree_attention_direct(const typename TT:
     __shared__ __attribute__((aligned(16))) E Pw[16 * P_STRIDE];
     const int h = att_head_of_block(blockIdx.x, n_heads), split = blockIdx.y;
     if (split >= ATT_SPLITS) {
+        if (blockIdx.z != 0) return;
         const unsigned a = warm_next_projection(warm, (split - ATT_SPLITS) * n_heads + h);
         if (a == 0x9E3779B9u && n_q_pad < 0) ws[0] = 0.f;
         return;
     }
     const int l = threadIdx.x, lr = l & 15, lg = l >> 4;
+    const int row_base = 16 * (int)blockIdx.z;         // (experiment: wider drafts as independent 16-row blocks, each wave loading the tile itself)
     V8 qa[4];
     {
-        const E *qp = q + ((size_t)lr * n_heads + h) * ATT_D + 8 * lg;
+        const E *qp = q + ((size_t)(row_base + lr) * n_heads + h) * ATT_D + 8 * lg;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             uint4 raw = make_uint4(0, 0, 0, 0);
-            if (lr < n_q_pad) raw = *reinterpret_cast<const uint4 *>(qp + 32 * kk);
+            if (row_base + lr < n_q_pad) raw = *reinterpret_cast<const uint4 *>(qp + 32 * kk);
             qa[kk] = __builtin_bit_cast(V8, raw);
         }
     }
     unsigned long long mrow[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) mrow[r] = 4 * lg + r < n_q_pad ? mask[4 * lg + r] : 0ull;
+    for (int r = 0; r < 4; r++) mrow[r] = row_base + 4 * lg + r < n_q_pad ? mask[row_base + 4 * lg + r] : 0ull;
     const int kvh = h / (n_heads / n_kv_heads);
     const E *kbase = kc + (size_t)kvh * max_len * ATT_D;
     const E *vbase = vt + (size_t)kvh * max_len * ATT_D;
@@ -426,9 +428,9 @@ __global__ __launch_bounds__(64) void k_tree_attention_direct(const typename TT:
     int n = d_n[0]; n = n > n_q_pad ? n_q_pad : n;
     const int total = L + n;
     const int ntiles = (total + ATT_TILE - 1) / ATT_TILE;
-    if (split >= ntiles) return;
+    if (split >= ntiles || row_base >= n) return;
 #pragma unroll
-    for (int r = 0; r < 4; r++) if (4 * lg + r >= n) mrow[r] = 0ull;
+    for (int r = 0; r < 4; r++) if (row_base + 4 * lg + r >= n) mrow[r] = 0ull;
     float m_run[4], l_run[4];
     floatx4 o[8];
 #pragma unroll
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(64) void k_tree_attention_direct(const typename TT:
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int row = 4 * lg + r;
+        const int row = row_base + 4 * lg + r;
         float *dst = ws + (((size_t)split * n_q_pad + row) * n_heads + h) * (ATT_D + 2);
         if (row < n) {
 #pragma unroll
@@ -1231,9 +1233,9 @@ int samd_tree_attention(const void *d_q, const void *d_k_cache, const void *d_v_
                                     scale, d_workspace, workspace_bytes, nullptr, stream);
 }
 
-static bool att_direct_on() {                  // SAMD_ATT_DIRECT=0: the four-wave kernel also at <= 16 rows of a transposed-V cache (A/B switch)
-    static const bool on = [] { const char *e = getenv("SAMD_ATT_DIRECT"); return !(e && e[0] == '0'); }();
-    return on;
+static int att_direct_rows() {                 // SAMD_ATT_DIRECT_ROWS: the widest row bucket that takes the one-wave kernel over a transposed-V cache (0: none; A/B switch)
+    static const int rows = [] { const char *e = getenv("SAMD_ATT_DIRECT_ROWS"); return e ? atoi(e) : 16; }();
+    return rows;
 }
 
 static int tree_attention_impl(const void *d_q, const void *d_k_cache, const void *d_v_cache, void *d_out, int32_t dtype, int32_t n_q_pad,
@@ -1256,8 +1258,8 @@ static int tree_attention_impl(const void *d_q, const void *d_k_cache, const voi
     hipStream_t st = (hipStream_t)stream;
     const float scale_log2 = scale * 1.4426950408889634f;
     float *ws = (float *)d_workspace;
-#define ATT_GO(TT, ET, W) if (v_transposed && n_q_pad <= 16 && att_direct_on()) \
-                          hipLaunchKernelGGL((k_tree_attention_direct<TT>), dim3(n_heads, ATT_SPLITS + warm_splits), dim3(64), 0, st, (const ET *)d_q, \
+#define ATT_GO(TT, ET, W) if (v_transposed && n_q_pad <= att_direct_rows()) \
+                          hipLaunchKernelGGL((k_tree_attention_direct<TT>), dim3(n_heads, ATT_SPLITS + warm_splits, (n_q_pad + 15) / 16), dim3(64), 0, st, (const ET *)d_q, \
                            (const ET *)d_k_cache, (const ET *)d_v_cache, ws, n_q_pad, n_heads, n_kv_heads, (long long)max_len, \
                            (const unsigned long long *)d_mask, d_cache_length, d_n, scale_log2, wa_split); \
                       else if (v_transposed) hipLaunchKernelGGL((k_tree_attention<TT, W, true>), dim3(n_heads, ATT_SPLITS + warm_splits, row_tiles), dim3(256), 0, st, (const ET *)d_q, \

@@ -1,15 +1,17 @@
 #!/bin/bash
 # round-6 closing measurements at HEAD (GPU box).  Every step under its own timeout; core dumps off.
-#   A: the GPU suite (plain + a subset on a NaN-poisoned allocator), the traversal-kernel sweep (12 rows), its counters
+#   A: the GPU suite (plain + a subset on a NaN-poisoned allocator; T = only these), the traversal-kernel sweep (12 rows), its counters
 #   B: bench lines -- the driver's window, the 2000-step default, the summarization leg at 24 requests, rocprofv3 kernel stats, variants
 #   C: per-kernel tables of the 8- and 64-row layers, the attention pair, the EAGLE-2 draft
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ulimit -c 0
 O=gpurun_out/final6; mkdir -p $O
 what=${1:-all}
-if [ "$what" = all ] || [ "$what" = A ]; then
+if [ "$what" = all ] || [ "$what" = A ] || [ "$what" = T ]; then
   timeout 900 python3 -m pytest tests -m gpu -q > $O/gputest.log 2>&1; echo "pytest rc $?" >> $O/gputest.log; tail -3 $O/gputest.log
-  SAMD_TEST_POISON=1 SAMD_TEST_POISON_GIB=24 timeout 900 python3 -m pytest tests/test_gpu_wide_drafts.py tests/test_gpu_sam.py tests/test_gpu_api.py tests/test_gpu_llama.py tests/test_gpu_verify.py tests/test_gpu_prefill_shaping.py -m gpu -q > $O/gputest_poison.log 2>&1; echo "pytest rc $?" >> $O/gputest_poison.log; tail -3 $O/gputest_poison.log
+  SAMD_TEST_POISON=1 SAMD_TEST_POISON_GIB=24 timeout 900 python3 -m pytest tests/test_gpu_wide_drafts.py tests/test_gpu_sam.py tests/test_gpu_api.py tests/test_gpu_llama.py tests/test_gpu_verify.py tests/test_gpu_prefill_shaping.py tests/test_gpu_vt_cache.py -m gpu -q > $O/gputest_poison.log 2>&1; echo "pytest rc $?" >> $O/gputest_poison.log; tail -3 $O/gputest_poison.log
+fi
+if [ "$what" = all ] || [ "$what" = A ]; then
   timeout 2700 python3 scripts/walk_sweep.py $O/walk_sweep.json > $O/walk_sweep.log 2>&1; echo "sweep rc $?"; tail -14 $O/walk_sweep.log
   bash scripts/pmc_walk.sh final6/walk_pmc > $O/pmc_walk.log 2>&1; tail -2 $O/pmc_walk.log | cut -c1-400
 fi
@@ -31,6 +33,6 @@ if [ "$what" = all ] || [ "$what" = C ]; then
     cp $(ls $O/layer$R/*kernel_stats.csv | head -1) $O/layer${R}_kernel_stats.csv
     python3 scripts/show_stats.py $O/layer${R}_kernel_stats.csv | head -14
   done
-  for i in 1 2; do python3 scripts/attn_ab.py 800 300 1500; python3 scripts/attn_ab.py 800 gqa; done > $O/attn_ab.log 2>&1; cat $O/attn_ab.log
+  for i in 1 2; do python3 scripts/attn_ab.py vt 800 300 1500; python3 scripts/attn_ab.py vt 800 gqa; done > $O/attn_ab.log 2>&1; cat $O/attn_ab.log
   python3 scripts/gemm_groups_ab.py > $O/gemm_groups_ab.log 2>&1; cat $O/gemm_groups_ab.log
 fi
