@@ -489,7 +489,7 @@ def lm_roofline(runner, iters=10, rows=16):
             if fold:
                 check((L.samd_gemm_qkv_rope_norm_vt if runner.v_transposed else L.samd_gemm_qkv_rope_norm)(
                     _ptr(b["x"]), _ptr(b["ssq"]), _ptr(w["ln1"]), s.eps, _ptr(p["wqkv64"]), 16, s.hidden, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n),
-                                                _ptr(b["q"]), _ptr(runner.kv[li, 0]), _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
+                    _ptr(b["q"]), _ptr(runner.kv[li, 0]), _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
                 check(L.samd_gemm_cs_residual(_ptr(attn2d), _ptr(p["wo_g"]), 16, s.hidden, attn2d.shape[1], _ptr(b["x"]), _ptr(b["ssq"]), dt, st))
                 check(L.samd_gemm_pairs_silu_norm(_ptr(b["x"]), _ptr(b["ssq"]), _ptr(w["ln2"]), s.eps, _ptr(p["wgu"]), 16, s.inter, s.hidden, _ptr(b["act"]), dt, st))
                 check(L.samd_gemm_cs_residual(_ptr(b["act"]), _ptr(p["wdown_g"]), 16, s.hidden, s.inter, _ptr(b["x"]), _ptr(b["ssq"]), dt, st))
@@ -500,7 +500,7 @@ def lm_roofline(runner, iters=10, rows=16):
                 if key == "wqkv" and p.get("wqkv64") is not None:          # the launch the runner makes: RoPE + K/V write in the epilogue
                     check((L.samd_gemm_qkv_rope_vt if runner.v_transposed else L.samd_gemm_qkv_rope)(
                         _ptr(a), _ptr(p["wqkv64"]), RP, k, _ptr(b["cs"]), _ptr(d_L), _ptr(d_n), _ptr(b["q"]), _ptr(runner.kv[li, 0]),
-                                               _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
+                        _ptr(runner.kv[li, 1]), s.heads, s.kv_heads, s.head_dim, runner.max_len, dt, st))
                 elif p.get(key) is not None:
                     check(L.samd_gemm_skinny(_ptr(a), _ptr(p[key]), RP, n, k, L.samd_gemm_splits(n, k, RP), _ptr(part), _ptr(out), dt, st))
                 else:                                                      # round 6: o / down stream their one group-major copy at every row bucket
@@ -1173,7 +1173,7 @@ def main():
                        "static_sam_states": int(sam_info["n_states"]), "static_sam_bytes": int(sam_info["device_bytes"]),
                        "static_sam_derived_bytes": derived_decode,
                        "acceptance": args.acceptance, "variant": args.variant, "parallelism": f"request-parallel x{world} (replicas, no data-path collective)",
-                       "hipgraphs": not args.no_graphs},
+                       "hipgraphs": not args.no_graphs, "v_cache_layout": "transposed" if getattr(runner, "v_transposed", False) else "rows"},
             "mean_accepted_tokens": round(n_tok / max(n_steps, 1), 3),
             "draft_steps": {k: {"steps": v[0], "mean_accept": round(v[1] / max(v[0], 1), 3)} for k, v in stats.items()},
             "per_rank": [dict(r, ms_per_step=round(r["seconds"] / args.steps * 1e3, 4)) for r in per_rank], "bucket_histogram": bucket_hist,
