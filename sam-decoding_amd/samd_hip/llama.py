@@ -103,7 +103,8 @@ class LlamaRunner:
         self.warm_where = int(os.environ.get("SAMD_L2_WARM_WHERE", 0))        # output projection: 0 = from the attention splits, 1 = from their merge
         # the attention block of a layer (profiles/r02_attention_variants.md has the per-layer times at Vicuna-7B head geometry):
         #   "split"  = samd_rope_kv_write_cs (per-row cos | sin prepared once per forward: one memory round trip instead of two),
-        #              samd_tree_attention over 16 KV splits, its merge -- three launches, row-major V cache;
+        #              samd_tree_attention(_vt) over 16 KV splits, its merge -- three launches (two with the projection's RoPE epilogue); V cached
+        #              transposed since round 6 (see v_layout_t below), row-major before;
         #   "split3" = the round-1 form of the same: RoPE from the position tables (kept for A/B);
         #   "split2" = samd_tree_attention_rope: the splits rotate their own Q rows, one more workgroup owns the n new keys (RoPE, K/V
         #              row write), then the merge of the 17 slots -- two launches; measured SLOWER than three (every split redoes the

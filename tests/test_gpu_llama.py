@@ -37,7 +37,7 @@ def dev(a):
 @pytest.mark.parametrize("attention", ["split", "split2", "split3", "block"])
 @pytest.mark.parametrize("kv_heads", [2, 1])
 def test_prefill_and_tree_verify_match_hf(kv_heads, attention):
-    """both attention modes of the runner: "split" (RoPE / split attention / merge launches, row-major V cache) and "block"
+    """both attention modes of the runner: "split" (RoPE / split attention / merge launches; V cached transposed since round 6, "split2" keeps it row-major) and "block"
     (samd_attention_block: one launch, V cached transposed)"""
     from transformers import DynamicCache
     lm = tiny_llama(kv_heads)
