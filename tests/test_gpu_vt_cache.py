@@ -278,3 +278,40 @@ def test_prompt_rows_reach_the_transposed_cache_through_the_tiled_writer(dtype, 
     assert torch.equal(q0, q1) and torch.equal(k0, k1)
     assert torch.equal(v1t[:, :, L:L + live].transpose(1, 2), v0[:, L:L + live]) and (v0[:, L:L + live] != 3.0).any()
     assert (v1t[:, :, :L] == 3.0).all() and (v1t[:, :, L + live:] == 3.0).all()
+
+
+@pytest.mark.parametrize("where", [0, 1])
+def test_attention_launches_carrying_warm_up_workgroups_give_the_same_rows(where, monkeypatch):
+    """SAMD_L2_WARM_KB > 0 (off by default): the attention's split launch (where = 0) or its merge (where = 1) carries extra workgroups that read the
+    head of the output projection's weight stream.  Over the transposed cache the <= 16-row split launch is the one-wave kernel: the extra
+    workgroups must leave every bucket's logits untouched (both layouts, the non-fold launch sequence that passes the hints)."""
+    from samd_hip.llama import LlamaRunner
+    from test_gpu_wide_drafts import small_llama
+    monkeypatch.setenv("SAMD_QKV_FUSED", "force")
+    monkeypatch.setenv("SAMD_NORM_FOLD", "0")
+    lm, cfg = small_llama(seed=9)
+    V, max_len = cfg["vocab_size"], 512
+    prompt = torch.tensor([np.random.default_rng(5).integers(3, V, 140).tolist()], device="cuda")
+    res = {}
+    for layout in ("t", "rows"):
+        for kb in (0, 64):
+            monkeypatch.setenv("SAMD_V_LAYOUT", layout)
+            monkeypatch.setenv("SAMD_L2_WARM_KB", str(kb))
+            monkeypatch.setenv("SAMD_L2_WARM_WHERE", str(where))
+            runner = LlamaRunner.from_hf(lm, max_cache_len=max_len, dtype=torch.float16, share_weights=False)
+            assert runner.warm_kb == kb and not runner.norm_fold
+            sess = samd_hip.Session(max_len)
+            runner.prefill(sess, prompt)
+            got = []
+            for n, shape in ((6, "chain"), (15, "bushy"), (40, "random")):
+                anc = random_parents(np.random.default_rng(n), n, shape)
+                depth = [0] * n
+                for i in range(1, n):
+                    depth[i] = depth[anc[i]] + 1
+                _, mask = mask_words(anc, n)
+                got.append(runner.forward_tokens(sess, dev(np.random.default_rng(n + 1).integers(3, V, n)), dev(depth), mask, n, prompt.numel()).float().clone())
+            res[(layout, kb)] = got
+            del runner
+            torch.cuda.empty_cache()
+    for a, b, c, d in zip(res[("t", 0)], res[("t", 64)], res[("rows", 0)], res[("rows", 64)]):
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, d)
