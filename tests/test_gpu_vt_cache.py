@@ -17,7 +17,6 @@ torch = pytest.importorskip("torch")
 
 import samd_hip
 from samd_hip import _ptr as P
-from oracle import sam_oracle as O
 from test_gpu_verify import reference_attention
 from test_gpu_wide_drafts import mask_words
 from util import random_parents
